@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference imports ``h5py`` at module top but only uses it when
+``save_to_disk=True``; h5py is not installed here, so an empty stub module is put
+in ``sys.modules`` first.  Nothing of the reference is
+copied: only its *outputs* (arrays, scalars) on seeded inputs are stored.
+
+Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
+  g1_functions_64.npz     per-function vectors, CoupledModel 64^2
+  g2_coupled_*.npz        CoupledModel LambDipole trajectories (notebook parameters)
+  g3_qg_*.npz             QGModel LambDipole trajectories (examples/LambDipole_qg.py)
+  g4_quirks_64.npz        UnCoupledModel tdiags dependence (Q1), set order (Q2)
+  g6_notebook_diags.npz   diagnostics time series of the 128^2 notebook run (400 steps)
+  g7_checksums.npz        scalar checksums at 256^2 / 512^2
+"""
+import os
+import sys
+import types
+import logging
+
+import numpy as np
+
+sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+sys.path.insert(0, "/root/reference")
+
+from niwqg import CoupledModel, UnCoupledModel, QGModel      # noqa: E402
+from niwqg import InitialConditions as ic                    # noqa: E402
+
+logging.getLogger("niwqg.Kernel").setLevel(logging.ERROR)
+logging.getLogger("niwqg.QGModel").setLevel(logging.ERROR)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote", name, "%.1f KiB" % (os.path.getsize(path) / 1024.0))
+
+
+# ---- shared physical parameters (examples/LambDipole_CoupledModel.ipynb cells 3-7) ----
+F0, NB, L = 1e-4, 0.01, 2 * np.pi * 200e3
+MZ = 2 * np.pi / 280.0
+K0 = 10 * (2 * np.pi / L)
+U0 = 0.1
+TE = 1.0 / (U0 * K0)
+
+
+def notebook_kwargs(nx, use_filter, nsteps, tdiags=1):
+    dt = 0.025 * TE * 128 / nx
+    return dict(L=L, nx=nx, tmax=(nsteps - 0.5) * dt, dt=dt, m=MZ, N=NB, f=F0,
+                twrite=10 ** 9, nu4=5e11 * (128.0 / nx) ** 4, nu4w=0.0, nu=20, nuw=50.0,
+                mu=0.0, muw=0.0, use_filter=use_filter, U=-U0, tdiags=tdiags,
+                save_to_disk=False, dealias=False)
+
+
+def lamb_and_uniform(m):
+    q = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+    phi = (np.ones_like(q) + 1j) * (2 * U0) / np.sqrt(2)
+    return q, phi
+
+
+def step_to(m, n):
+    while m.tc < n:
+        m._step_forward()
+
+
+# ---------------------------------------------------------------- G1
+def g1():
+    nx = 64
+    out = {}
+    for mode, kw in (("exp", dict(use_filter=True)), ("twothirds", dict(use_filter=False, dealias=True)),
+                     ("none", dict(use_filter=False))):
+        m = CoupledModel.Model(nx=nx, **kw)
+        out["filtr_" + mode] = m.filtr
+    m = CoupledModel.Model(**notebook_kwargs(nx, True, 1))
+    q, _ = lamb_and_uniform(m)
+    phi = 0.2 * ic.WavePacket(m, k=3 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2)
+    m.set_q(q)
+    m.set_phi(phi)
+    m._invert()                      # make ph/qwh consistent with phi (undo quirk Q2 for this vector)
+    m._calc_rel_vorticity()
+    out.update(q0=q, phi0=phi, kk=m.kk, ll=m.ll,
+               expch=m.expch, expch_h=m.expch_h, Qh=m.Qh, f0=m.f0, fab=m.fab, fc=m.fc,
+               expchw=m.expchw, expch_hw=m.expch_hw, Qhw=m.Qhw, f0w=m.f0w, fabw=m.fabw, fcw=m.fcw,
+               ph=m.ph, qwh=m.qwh, q_psi=m.q_psi, phix=m.phix, phiy=m.phiy, qh=m.qh, phih=m.phih)
+    out["jac_psi_q"] = m.jacobian_psi_q()
+    out["u"], out["v"] = m.u, m.v
+    out["jac_psi_phi"] = m.jacobian_psi_phi()
+    out["jac_phic_phi"] = m.jacobian_phic_phi()
+    out["refraction"] = m.fft(m.phi * m.q_psi)
+    m._calc_energy_conversion()
+    out["budget"] = np.array([m.gamma1, m.gamma2, m.xi1, m.xi2, m.pi,
+                              m._calc_ep_psi(), m._calc_chi_phi(), m._calc_ep_phi()])
+    out["energies"] = np.array([m._calc_ke_qg(), m._calc_ke_niw(), m._calc_pe_niw(), m._calc_cfl()])
+    out["params"] = np.array([m.dt, m.nu4, m.L, m.U, m.f, m.kappa2])
+    save("g1_functions_64.npz", **out)
+
+
+# ---------------------------------------------------------------- G2
+def g2():
+    for nx, snaps, full in ((64, (1, 10, 100), True), (128, (100,), False)):
+        for use_filter in (False, True):
+            m = CoupledModel.Model(**notebook_kwargs(nx, use_filter, max(snaps), tdiags=10 ** 9))
+            q, phi = lamb_and_uniform(m)
+            m.set_q(q)
+            m.set_phi(phi)
+            out = dict(q0=q, phi0=phi, snaps=np.array(snaps))
+            for n in snaps:
+                step_to(m, n)
+                out["q_%d" % n] = m.q.copy()
+                out["phi_%d" % n] = m.phi.copy()
+                out["budgets_%d" % n] = np.array([m.Ke, m.Pw, m.Kw])
+                if full or n == max(snaps):
+                    out["qh_%d" % n] = m.qh.copy()
+                    out["phih_%d" % n] = m.phih.copy()
+                    out["ph_%d" % n] = m.ph.copy()
+            save("g2_coupled_%d_%s.npz" % (nx, "filter" if use_filter else "nofilter"), **out)
+
+
+# ---------------------------------------------------------------- G3
+def g3():
+    for nx, snaps in ((64, (1, 10, 200)), (256, (200,))):
+        dt = 0.05 * TE * 128 / nx if nx < 128 else 0.05 * TE
+        m = QGModel.Model(L=L, nx=nx, tmax=1e30, dt=dt, twrite=10 ** 9, nu4=7.5e8, use_filter=False,
+                          save_to_disk=False, U=-U0, tdiags=10 ** 9, beta=0.0, passive_scalar=False)
+        q = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+        m.set_q(q)
+        out = dict(q0=q, snaps=np.array(snaps), dt=np.array(dt))
+        for n in snaps:
+            step_to(m, n)
+            out["q_%d" % n] = m.q.copy()
+            out["qh_%d" % n] = m.qh.copy()
+            out["Ke_%d" % n] = np.array(m.Ke)
+        save("g3_qg_%d.npz" % nx, **out)
+    # beta-plane + filter variant (exercises beta term and exponential filter on the half spectrum)
+    nx = 64
+    m = QGModel.Model(L=L, nx=nx, tmax=1e30, dt=0.05 * TE * 2, twrite=10 ** 9, nu4=7.5e8, nu=5.0, mu=1e-8,
+                      use_filter=True, save_to_disk=False, U=-U0, tdiags=10 ** 9, beta=2e-11,
+                      passive_scalar=False)
+    q = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+    m.set_q(q)
+    step_to(m, 20)
+    save("g3_qg_64_beta.npz", q0=q, q_20=m.q.copy(), qh_20=m.qh.copy(), Ke_20=np.array(m.Ke),
+         dt=np.array(m.dt))
+
+
+# ---------------------------------------------------------------- G4
+def g4():
+    nx, out = 64, {}
+    rng = np.random.default_rng(0)
+    for tag, tdiags in (("td1", 1), ("tdinf", 10 ** 9)):
+        kw = notebook_kwargs(nx, True, 20, tdiags=tdiags)
+        m = UnCoupledModel.Model(**kw)
+        q = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+        phi = 0.1 * ic.WavePacket(m, k=3 * K0, l=0, R=L / 6, x0=L / 2, y0=L / 2)
+        m.set_q(q)
+        m.set_phi(phi)
+        step_to(m, 20)
+        out.update({"unc_q0": q, "unc_phi0": phi, "unc_q_" + tag: m.q.copy(),
+                    "unc_phi_" + tag: m.phi.copy(), "unc_qh_" + tag: m.qh.copy(),
+                    "unc_phih_" + tag: m.phih.copy(),
+                    "unc_budgets_" + tag: np.array([m.Ke, m.Pw, m.Kw])})
+    for tag in ("q_then_phi", "phi_then_q"):
+        m = CoupledModel.Model(**notebook_kwargs(nx, True, 1, tdiags=10 ** 9))
+        q, _ = lamb_and_uniform(m)
+        phi = 0.2 * ic.WavePacket(m, k=3 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2)
+        if tag == "q_then_phi":
+            m.set_q(q); m.set_phi(phi)
+        else:
+            m.set_phi(phi); m.set_q(q)
+        out["order_ph0_" + tag] = m.ph.copy()
+        step_to(m, 1)
+        out["order_q_" + tag] = m.q.copy()
+        out["order_phi_" + tag] = m.phi.copy()
+    out["order_q0"], out["order_phi0"] = q, phi
+    # random-phase rough field, two-thirds dealiasing, nonzero nu4w/mu/muw: exercises every budget term
+    kw = notebook_kwargs(nx, False, 5, tdiags=10 ** 9)
+    kw.update(dealias=True, nu4w=1e10, mu=1e-8, muw=2e-8)
+    m = CoupledModel.Model(**kw)
+    q = 1e-5 * rng.standard_normal((nx, nx))
+    phi = 0.05 * (rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx)))
+    m.set_q(q)
+    m.set_phi(phi)
+    step_to(m, 5)
+    out.update(rough_q0=q, rough_phi0=phi, rough_q=m.q.copy(), rough_phi=m.phi.copy(),
+               rough_qh=m.qh.copy(), rough_phih=m.phih.copy(),
+               rough_budgets=np.array([m.Ke, m.Pw, m.Kw]))
+    save("g4_quirks_64.npz", **out)
+
+
+# ---------------------------------------------------------------- G6
+def g6():
+    nx = 128
+    dt = 0.025 * TE
+    m = CoupledModel.Model(L=L, nx=nx, tmax=10 * TE, dt=dt, m=MZ, N=NB, f=F0,
+                           twrite=int(1 * (2 * np.pi / F0) / dt), nu4=5e11, nu4w=0e10, nu=20, nuw=50e0,
+                           mu=0.0, muw=0.0, use_filter=False, U=-U0, tdiags=1, save_to_disk=False,
+                           dealias=False)
+    q, phi = lamb_and_uniform(m)
+    m.set_q(q)
+    m.set_phi(phi)
+    status = []
+    while m.t < m.tmax:
+        m._step_forward()
+        if (m.tc % m.twrite) == 0:
+            status.append([m.tc, m.t, m.ke, m.kew, m.pew, m.cfl])
+    out = {k: np.asarray(v["value"]) for k, v in m.diagnostics.items()}
+    out["status"] = np.array(status)
+    out["final_q"] = m.q
+    out["final_phi"] = m.phi
+    save("g6_notebook_diags.npz", **out)
+
+
+# ---------------------------------------------------------------- G7
+def g7():
+    out = {}
+    for nx in (256, 512):
+        m = CoupledModel.Model(**notebook_kwargs(nx, True, 3, tdiags=10 ** 9))
+        q, phi = lamb_and_uniform(m)
+        m.set_q(q)
+        m.set_phi(phi)
+        step_to(m, 3)
+        out["c%d" % nx] = np.array([m.spec_var(m.qh), m.spec_var(m.phih), m.q.mean(), np.abs(m.q).max(),
+                                    np.abs(m.phi).max(), m.phi.mean().real, m.phi.mean().imag,
+                                    m.Ke, m.Pw, m.Kw, (m.q ** 2).sum(), (np.abs(m.phi) ** 2).sum()])
+    save("g7_checksums.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7"]
+    for w in which:
+        globals()[w]()

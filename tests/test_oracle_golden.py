@@ -1,0 +1,195 @@
+"""Pin the CPU oracle (oracle/niwqg_oracle.py) to the reference.
+
+Every expected value here comes from the reference itself: the .npz fixtures were
+produced by tests/golden/make_golden.py importing /root/reference, and
+g5_notebook_cell9_log.txt is the logged output stored in
+examples/LambDipole_CoupledModel.ipynb (cell 9).  CPU only.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import niwqg_oracle as O
+
+F0, NB, L = 1e-4, 0.01, 2 * np.pi * 200e3
+MZ = 2 * np.pi / 280.0
+K0 = 10 * (2 * np.pi / L)
+U0 = 0.1
+TE = 1.0 / (U0 * K0)
+
+
+def notebook_kwargs(nx, use_filter, tdiags=10 ** 9):
+    dt = 0.025 * TE * 128 / nx
+    return dict(L=L, nx=nx, tmax=1e30, dt=dt, m=MZ, N=NB, f=F0, twrite=10 ** 9,
+                nu4=5e11 * (128.0 / nx) ** 4, nu4w=0.0, nu=20, nuw=50.0, mu=0.0, muw=0.0,
+                use_filter=use_filter, U=-U0, tdiags=tdiags, dealias=False)
+
+
+def rel(a, b):
+    return np.linalg.norm(np.ravel(a) - np.ravel(b)) / np.linalg.norm(np.ravel(b))
+
+
+def steps(m, n):
+    while m.tc < n:
+        m._step_forward()
+
+
+def test_filter_modes_and_tables(golden):
+    g = golden("g1_functions_64.npz")
+    for mode, kw in (("exp", dict(use_filter=True)), ("twothirds", dict(use_filter=False, dealias=True)),
+                     ("none", dict(use_filter=False))):
+        m = O.NIWQGOracle("coupled", nx=64, **kw)
+        assert np.array_equal(m.filtr, g["filtr_" + mode])
+    m = O.NIWQGOracle("coupled", **notebook_kwargs(64, True))
+    assert np.array_equal(m.kk, g["kk"]) and np.array_equal(m.ll, g["ll"])
+    names = (("E", "expch"), ("Eh", "expch_h"), ("Q", "Qh"), ("f0", "f0"), ("fab", "fab"), ("fc", "fc"))
+    for ours, theirs in names:
+        for mine, ref in ((m.coef_q[ours], g[theirs]), (m.coef_w[ours], g[theirs + "w"])):
+            # element-wise in modulus; f0,fab,fc are cancellation-prone so numpy temporary-elision
+            # (FMA vs non-FMA complex loops) alone moves them by ~5e-14 relative
+            assert np.all(np.abs(mine - ref) <= 1e-12 * np.abs(ref)), (ours, theirs)
+
+
+def test_per_function_vectors(golden):
+    g = golden("g1_functions_64.npz")
+    m = O.NIWQGOracle("coupled", **notebook_kwargs(64, True))
+    m.set_q(g["q0"])
+    m.set_phi(g["phi0"])
+    m._invert()
+    m._calc_rel_vorticity()
+    for name in ("ph", "qwh", "q_psi", "phix", "phiy", "qh", "phih"):
+        assert rel(getattr(m, name), g[name]) < 1e-14, name
+    assert rel(m.jacobian_psi_q(), g["jac_psi_q"]) < 1e-13
+    assert rel(m.u, g["u"]) < 1e-14 and rel(m.v, g["v"]) < 1e-14
+    assert rel(m.jacobian_psi_phi(), g["jac_psi_phi"]) < 1e-13
+    assert rel(m.jacobian_phic_phi(), g["jac_phic_phi"]) < 1e-13
+    assert rel(m.fft(m.phi * m.q_psi), g["refraction"]) < 1e-14
+    m._calc_energy_conversion()
+    b = np.array([m.gamma1, m.gamma2, m.xi1, m.xi2, m.pi, m._calc_ep_psi(), m._calc_chi_phi(),
+                  m._calc_ep_phi()])
+    assert np.allclose(b, g["budget"], rtol=1e-10, atol=1e-25)
+    e = np.array([m._calc_ke_qg(), m._calc_ke_niw(), m._calc_pe_niw(), m._calc_cfl()])
+    assert np.allclose(e, g["energies"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("use_filter", [False, True])
+def test_coupled_trajectory_64(golden, use_filter):
+    g = golden("g2_coupled_64_%s.npz" % ("filter" if use_filter else "nofilter"))
+    m = O.NIWQGOracle("coupled", **notebook_kwargs(64, use_filter))
+    m.set_q(g["q0"])
+    m.set_phi(g["phi0"])
+    for n in g["snaps"]:
+        steps(m, n)
+        assert rel(m.q, g["q_%d" % n]) < 1e-13
+        assert rel(m.phi, g["phi_%d" % n]) < 1e-13
+        assert rel(m.qh, g["qh_%d" % n]) < 1e-13
+        assert rel(m.phih, g["phih_%d" % n]) < 1e-13
+        assert np.allclose([m.Ke, m.Pw, m.Kw], g["budgets_%d" % n], rtol=1e-11)
+    # 104 transforms per step (28 fwd + 76 inv) + set_q/set_phi (5, 10) + the one diagnostics tick at
+    # tc == 0 that even tdiags=inf triggers (15 inverse)
+    assert m.fft_calls == [28 * 100 + 5, 76 * 100 + 10 + 15]
+
+
+def test_lamb_dipole_matches_reference_inputs(golden):
+    g = golden("g2_coupled_128_filter.npz")
+    grid = O.SpectralGrid(128, L)
+    assert np.array_equal(O.lamb_dipole(grid, U=U0, R=2 * np.pi / K0), g["q0"])
+
+
+def test_qg_trajectory(golden):
+    g = golden("g3_qg_64.npz")
+    m = O.QGOracle(L=L, nx=64, tmax=1e30, dt=float(g["dt"]), twrite=10 ** 9, nu4=7.5e8,
+                   use_filter=False, U=-U0, tdiags=10 ** 9, beta=0.0)
+    m.set_q(g["q0"])
+    for n in g["snaps"]:
+        steps(m, n)
+        assert rel(m.q, g["q_%d" % n]) < 1e-11
+        assert rel(m.qh, g["qh_%d" % n]) < 1e-11
+        assert np.isclose(m.Ke, float(g["Ke_%d" % n]), rtol=1e-12)
+    print(m.fft_calls)
+    assert m.fft_calls[0] == 8 * 200 + 1 and m.fft_calls[1] // 200 == 25   # 33 transforms per step
+    g = golden("g3_qg_64_beta.npz")
+    m = O.QGOracle(L=L, nx=64, tmax=1e30, dt=float(g["dt"]), twrite=10 ** 9, nu4=7.5e8, nu=5.0,
+                   mu=1e-8, use_filter=True, U=-U0, tdiags=10 ** 9, beta=2e-11)
+    m.set_q(g["q0"])
+    steps(m, 20)
+    assert rel(m.q, g["q_20"]) < 1e-11 and rel(m.qh, g["qh_20"]) < 1e-11
+    assert np.isclose(m.Ke, float(g["Ke_20"]), rtol=1e-12)
+
+
+def test_uncoupled_quirk_q1_and_set_order_q2(golden):
+    g = golden("g4_quirks_64.npz")
+    res = {}
+    for tag, td in (("td1", 1), ("tdinf", 10 ** 9)):
+        m = O.NIWQGOracle("uncoupled", **notebook_kwargs(64, True, tdiags=td))
+        m.set_q(g["unc_q0"])
+        m.set_phi(g["unc_phi0"])
+        steps(m, 20)
+        assert rel(m.phi, g["unc_phi_" + tag]) < 1e-13
+        assert rel(m.q, g["unc_q_" + tag]) < 1e-13
+        assert np.allclose([m.Ke, m.Pw, m.Kw], g["unc_budgets_" + tag], rtol=1e-10)
+        res[tag] = m.phi
+    assert rel(res["td1"], res["tdinf"]) > 1e-3      # Q1 really is observable
+    for tag in ("q_then_phi", "phi_then_q"):
+        m = O.NIWQGOracle("coupled", **notebook_kwargs(64, True))
+        if tag == "q_then_phi":
+            m.set_q(g["order_q0"]); m.set_phi(g["order_phi0"])
+        else:
+            m.set_phi(g["order_phi0"]); m.set_q(g["order_q0"])
+        assert rel(m.ph, g["order_ph0_" + tag]) < 1e-14
+        steps(m, 1)
+        assert rel(m.q, g["order_q_" + tag]) < 1e-13
+        assert rel(m.phi, g["order_phi_" + tag]) < 1e-13
+    kw = notebook_kwargs(64, False)
+    kw.update(dealias=True, nu4w=1e10, mu=1e-8, muw=2e-8)
+    m = O.NIWQGOracle("coupled", **kw)
+    m.set_q(g["rough_q0"])
+    m.set_phi(g["rough_phi0"])
+    steps(m, 5)
+    assert rel(m.q, g["rough_q"]) < 1e-12 and rel(m.phi, g["rough_phi"]) < 1e-12
+    assert np.allclose([m.Ke, m.Pw, m.Kw], g["rough_budgets"], rtol=1e-9)
+
+
+def test_notebook_run_status_lines_and_diagnostics(golden):
+    """G5/G6: the oracle reproduces the notebook's logged lines (known answers the reference
+    ships) and the reference's full diagnostics series for the same run."""
+    g = golden("g6_notebook_diags.npz")
+    dt = 0.025 * TE
+    m = O.NIWQGOracle("coupled", L=L, nx=128, tmax=10 * TE, dt=dt, m=MZ, N=NB, f=F0,
+                      twrite=int((2 * np.pi / F0) / dt), nu4=5e11, nu4w=0.0, nu=20, nuw=50.0,
+                      use_filter=False, U=-U0, tdiags=1)
+    m.set_q(O.lamb_dipole(m.grid, U=U0, R=2 * np.pi / K0))
+    m.set_phi((np.ones((128, 128)) + 1j) * (2 * U0) / np.sqrt(2))
+    lines = []
+    while m.t < m.tmax:
+        m._step_forward()
+        if (m.tc % m.twrite) == 0:
+            lines.append("INFO: Step: %4i, Time: %2.1e, P: %2.1e, Ke: %4.3e, Kw: %4.3e, Pw: %4.3e, CFL: %3.2f"
+                         % (m.tc, m.t, m.t / m.tmax, m.ke, m.kew, m.pew, m.cfl))
+    logged = open(os.path.join(os.path.dirname(__file__), "golden", "g5_notebook_cell9_log.txt")).read()
+    logged = [re.sub(r"\s+$", "", s) for s in logged.splitlines() if s.strip()]
+    assert lines == logged
+    for name in ("Ke", "Pw", "Kw", "ke_qg", "ke_niw", "pe_niw", "gamma_r", "gamma_a", "xi_r", "xi_a",
+                 "ep_psi", "chi_phi", "ep_phi", "pi", "ens", "ke_qg_q", "ke_qg_w", "ke_qg_qw", "chi_q",
+                 "skew", "time"):
+        atol = 1e-12 if name == "skew" else 1e-22      # initial skewness is a roundoff-level residual
+        assert np.allclose(m.diag(name), g[name], rtol=1e-9, atol=atol), name
+    assert rel(m.q, g["final_q"]) < 1e-12 and rel(m.phi, g["final_phi"]) < 1e-12
+
+
+def test_checksums_256_512(golden):
+    g = golden("g7_checksums.npz")
+    nx = 256
+    m = O.NIWQGOracle("coupled", **notebook_kwargs(nx, True))
+    m.set_q(O.lamb_dipole(m.grid, U=U0, R=2 * np.pi / K0))
+    m.set_phi((np.ones((nx, nx)) + 1j) * (2 * U0) / np.sqrt(2))
+    steps(m, 3)
+    c = np.array([m.spec_var(m.qh), m.spec_var(m.phih), m.q.mean(), np.abs(m.q).max(),
+                  np.abs(m.phi).max(), m.phi.mean().real, m.phi.mean().imag, m.Ke, m.Pw, m.Kw,
+                  (m.q ** 2).sum(), (np.abs(m.phi) ** 2).sum()])
+    ref = g["c%d" % nx]
+    ok = np.isclose(c, ref, rtol=1e-10, atol=1e-24)
+    ok[2] = abs(c[2] - ref[2]) < 1e-20          # mean(q) is roundoff around zero
+    assert ok.all(), (c, ref)

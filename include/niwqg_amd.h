@@ -1,0 +1,122 @@
+/* niwqg_amd -- C ABI of the MI355X-native ETDRK4 pseudo-spectral stepper.
+ *
+ * The reference (cesar-rocha/niwqg) is pure Python and has no FFI of its own; its drop-in boundary
+ * is the Python class surface.  This header is the boundary a maintainer of
+ * the reference would bind with ctypes (INTEGRATION.md shows the stub); every entry point names the
+ * reference method it stands in for (file:line in the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; host buffers are caller-owned, device buffers context-owned;
+ *   - one host thread per context, one HIP stream per context;
+ *   - every function returns 0 on success or a negative error code; nq_last_error() gives text;
+ *   - complex arrays are interleaved (re, im) doubles, i.e. numpy complex128;
+ *   - all 2-D host arrays are C-contiguous in the reference's layouts: physical (ny, nx);
+ *     Kernel-family spectral (ny, nx) index [l, k]; QGModel spectral (ny, nx/2+1).
+ */
+#ifndef NIWQG_AMD_H
+#define NIWQG_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nq_ctx nq_ctx;
+
+enum { NQ_MODEL_COUPLED = 0, NQ_MODEL_UNCOUPLED = 1, NQ_MODEL_QG = 2 };
+
+/* field ids for nq_get_field */
+enum {
+  NQ_F_Q = 0,      /* real (ny,nx)       q      = Re ifft(qh)                 Kernel.py:97/CoupledModel.py:97 */
+  NQ_F_QH = 1,     /* cplx spectral      qh     (full plane; (ny,nx/2+1) for QG)                                */
+  NQ_F_P = 2,      /* real               p      streamfunction                CoupledModel.py:93               */
+  NQ_F_PH = 3,     /* cplx spectral      ph                                                                     */
+  NQ_F_PHI = 4,    /* cplx (ny,nx)       phi                                  Kernel.py:337                    */
+  NQ_F_PHIH = 5,   /* cplx spectral      phih                                                                   */
+  NQ_F_U = 6,      /* real               u = Re ifft(-il ph)                  Kernel.py:481                    */
+  NQ_F_V = 7,      /* real               v = Re ifft( ik ph)                                                    */
+  NQ_F_QPSI = 8,   /* real               q_psi                                CoupledModel.py:145-152          */
+  NQ_F_QW = 9,     /* real               qw                                                                     */
+  NQ_F_QWH = 10,   /* cplx spectral      qwh                                  CoupledModel.py:86-88            */
+  NQ_F_PHIX = 11,  /* cplx               phix (as last refreshed: quirk Q1)   Kernel.py:610                    */
+  NQ_F_PHIY = 12   /* cplx               phiy                                                                   */
+};
+
+/* scalar ids for nq_get_scalar */
+enum {
+  NQ_S_KE = 0, NQ_S_PW = 1, NQ_S_KW = 2,   /* budget accumulators Ke, Pw, Kw       Kernel.py:390-392 */
+  NQ_S_KE_QG = 3,                          /* _calc_ke_qg()                        Kernel.py:600-602 */
+  NQ_S_KE_NIW = 4,                         /* _calc_ke_niw()                       Kernel.py:604-606 */
+  NQ_S_PE_NIW = 5,                         /* _calc_pe_niw() (no side effect here) Kernel.py:608-611 */
+  NQ_S_CFL = 6                             /* _calc_cfl()                          Kernel.py:660-662 */
+};
+
+typedef struct nq_params {
+  int model;          /* NQ_MODEL_*                                                             */
+  int nx;             /* grid is nx x nx (the reference ignores ny, Kernel.py:100-101)          */
+  int budgets;        /* 1: accumulate Ke,Pw,Kw inside the step like Kernel.py:319-322,:390-392 */
+  int reserved;
+  double dt;
+  double U;           /* uniform zonal flow                                                     */
+  double f;           /* Coriolis                                                               */
+  double kappa2;      /* (m f / N)^2                                                            */
+  double nu, nu4, mu;       /* q equation   Kernel.py:417-418 / QGModel.py:426-428              */
+  double nuw, nu4w, muw;    /* phi equation Kernel.py:440-442                                   */
+  double beta;        /* QGModel only                                                           */
+} nq_params;
+
+/* Kernel.__init__ / QGModel.__init__ (Kernel.py:139-152): builds grid-dependent tables on the device.
+ *   kk   : nk wavenumbers (nk = nx for the Kernel family, nx/2+1 for QG)   Kernel.py:242-244 / QGModel.py:249
+ *   ll   : nx wavenumbers
+ *   filtr: host (nx, nk) real plane, the reference's `filtr`                  Kernel.py:267-284
+ *   contour: 32 complex roots of unity r_j used by the ETDRK4 contour mean    Kernel.py:424-426
+ * The ETDRK4 coefficient planes (Kernel.py:417-454) are computed on the device.                      */
+int nq_create(const nq_params* p, const double* kk, const double* ll, const double* filtr,
+              const double* contour, int device, nq_ctx** out);
+int nq_destroy(nq_ctx* ctx);
+const char* nq_last_error(const nq_ctx* ctx);     /* ctx may be NULL: last global error */
+
+/* Kernel.set_q (Kernel.py:520-535) / QGModel.set_q (QGModel.py:507-520) */
+int nq_set_q(nq_ctx* ctx, const double* q_host);
+/* Kernel.set_phi (Kernel.py:538-551): phi_host is complex (ny,nx) */
+int nq_set_phi(nq_ctx* ctx, const double* phi_host);
+/* replay of the side effect of _calc_pe_niw on phix/phiy (Kernel.py:610, quirk Q1) */
+int nq_refresh_grad_phi(nq_ctx* ctx);
+
+/* nsteps x Kernel._step_etdrk4 (Kernel.py:307-397) / QGModel._step_etdrk4 (QGModel.py:328-407).
+ * Asynchronous on the context's stream.                                                              */
+int nq_step(nq_ctx* ctx, int nsteps);
+int nq_sync(nq_ctx* ctx);
+
+/* copy a field to the host in the reference's layout (blocking) */
+int nq_get_field(nq_ctx* ctx, int field_id, double* host_out);
+int nq_get_scalar(nq_ctx* ctx, int scalar_id, double* out);
+
+/* the FFT seam, Kernel.fft / Kernel.ifft (Kernel.py:562-566): complex (ny,nx) -> complex (ny,nx);
+ * QGModel.fft / ifft (QGModel.py:551-552): real (ny,nx) <-> complex (ny,nx/2+1).                     */
+int nq_fft2(nq_ctx* ctx, const double* in_cplx, double* out_cplx);
+int nq_ifft2(nq_ctx* ctx, const double* in_cplx, double* out_cplx);
+int nq_rfft2(nq_ctx* ctx, const double* in_real, double* out_cplx);
+int nq_irfft2(nq_ctx* ctx, const double* in_cplx, double* out_real);
+
+/* Kernel.jacobian_psi_q (Kernel.py:471-486), jacobian_psi_phi (:457-469),
+ * CoupledModel.jacobian_phic_phi (CoupledModel.py:59-73): full-plane complex result on the host.     */
+int nq_jacobian_psi_q(nq_ctx* ctx, double* out_cplx);
+int nq_jacobian_psi_phi(nq_ctx* ctx, double* out_cplx);
+int nq_jacobian_phic_phi(nq_ctx* ctx, double* out_cplx);
+
+/* copy of one ETDRK4 coefficient plane (0:E 1:Eh 2:Q 3:f0 4:fab 5:fc) of equation eq (0:q 1:phi),
+ * without the filter folded in; host layout as the reference's expch, expch_h, Qh, f0, fab, fc.      */
+int nq_get_coeff(nq_ctx* ctx, int eq, int which, double* out_cplx);
+
+/* timing of the hot loop with HIP events on the context's stream */
+int nq_timer_start(nq_ctx* ctx);
+int nq_timer_stop(nq_ctx* ctx, float* elapsed_ms);
+/* bytes of device memory held by the context */
+long long nq_device_bytes(const nq_ctx* ctx);
+/* stream handle (hipStream_t) so that callers can order their own work */
+void* nq_stream(nq_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,231 @@
+"""ctypes binding of libniwqg_amd.so (C ABI: include/niwqg_amd.h).
+
+The library is built in-tree by ``build()`` (hipcc, gfx950) and loaded from this directory.  There is
+no CPU fallback: if the library is missing or no GPU is present, constructing a model raises.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+try:                      # torch bundles its own libamdhip64.so.7; load it first so that our library
+    import torch          # binds to the same HIP runtime instance (one runtime per process)
+except Exception:         # pragma: no cover - torch is optional for single-GPU use
+    torch = None
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libniwqg_amd.so")
+SRC = os.path.join(HERE, "csrc", "nq_lib.hip")
+HEADERS = [os.path.join(HERE, "csrc", h) for h in ("nq_fft.hpp", "nq_generic.hpp", "nq_step.hpp")] + [
+    os.path.join(os.path.dirname(HERE), "include", "niwqg_amd.h")]
+
+COUPLED, UNCOUPLED, QG = 0, 1, 2
+(F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY) = range(13)
+(S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL) = range(7)
+
+EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_phi", "nq_refresh_grad_phi",
+           "nq_step", "nq_sync", "nq_get_field", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
+           "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_get_coeff",
+           "nq_timer_start", "nq_timer_stop", "nq_device_bytes", "nq_stream"]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("model", ctypes.c_int), ("nx", ctypes.c_int), ("budgets", ctypes.c_int),
+                ("reserved", ctypes.c_int), ("dt", ctypes.c_double), ("U", ctypes.c_double),
+                ("f", ctypes.c_double), ("kappa2", ctypes.c_double), ("nu", ctypes.c_double),
+                ("nu4", ctypes.c_double), ("mu", ctypes.c_double), ("nuw", ctypes.c_double),
+                ("nu4w", ctypes.c_double), ("muw", ctypes.c_double), ("beta", ctypes.c_double)]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in [SRC] + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           SRC, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and type the shared library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("niwqg_amd: %s is missing - run niwqg_amd._lib.build() (hipcc, gfx950); "
+                           "there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    dp = ctypes.POINTER(ctypes.c_double)
+    vp = ctypes.c_void_p
+    L.nq_create.argtypes = [ctypes.POINTER(Params), dp, dp, dp, dp, ctypes.c_int, ctypes.POINTER(vp)]
+    L.nq_last_error.argtypes = [vp]
+    L.nq_last_error.restype = ctypes.c_char_p
+    for name in ("nq_destroy", "nq_refresh_grad_phi", "nq_sync", "nq_timer_start"):
+        getattr(L, name).argtypes = [vp]
+    for name in ("nq_set_q", "nq_set_phi", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi"):
+        getattr(L, name).argtypes = [vp, dp]
+    for name in ("nq_fft2", "nq_ifft2", "nq_rfft2", "nq_irfft2"):
+        getattr(L, name).argtypes = [vp, dp, dp]
+    L.nq_step.argtypes = [vp, ctypes.c_int]
+    L.nq_get_field.argtypes = [vp, ctypes.c_int, dp]
+    L.nq_get_scalar.argtypes = [vp, ctypes.c_int, dp]
+    L.nq_get_coeff.argtypes = [vp, ctypes.c_int, ctypes.c_int, dp]
+    L.nq_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.nq_device_bytes.argtypes = [vp]
+    L.nq_device_bytes.restype = ctypes.c_longlong
+    L.nq_stream.argtypes = [vp]
+    L.nq_stream.restype = vp
+    _lib = L
+    return L
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+class Context:
+    """Thin object wrapper over nq_ctx; all arrays in and out are numpy."""
+
+    def __init__(self, model, nx, kk, ll, filtr, dt, U=0.0, f=1e-4, kappa2=1.0, nu=0.0, nu4=0.0, mu=0.0,
+                 nuw=0.0, nu4w=0.0, muw=0.0, beta=0.0, budgets=True, device=0):
+        self.L = lib()
+        self.model, self.nx = model, int(nx)
+        self.nk = nx if model != QG else nx // 2 + 1
+        p = Params(model=model, nx=nx, budgets=int(bool(budgets)), reserved=0, dt=dt, U=U, f=f, kappa2=kappa2,
+                   nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw, beta=beta)
+        kk = np.ascontiguousarray(kk, dtype=np.float64)
+        ll = np.ascontiguousarray(ll, dtype=np.float64)
+        filtr = np.ascontiguousarray(filtr, dtype=np.float64)
+        assert kk.shape == (self.nk,) and ll.shape == (nx,) and filtr.shape == (nx, self.nk)
+        # roots of unity of the ETDRK4 contour mean, built exactly like the reference (Kernel.py:424-426)
+        r = np.exp(2j * np.pi * (np.arange(1.0, 33.0) / 32.0))
+        r = np.ascontiguousarray(r).view(np.float64)
+        h = ctypes.c_void_p()
+        rc = self.L.nq_create(ctypes.byref(p), _dptr(kk), _dptr(ll), _dptr(filtr), _dptr(r), device, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError("nq_create failed (%d): %s" % (rc, self.L.nq_last_error(None).decode()))
+        self.h = h
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.L.nq_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.nq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- state
+    def set_q(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        assert q.shape == (self.nx, self.nx)
+        self._chk(self.L.nq_set_q(self.h, _dptr(q)), "nq_set_q")
+
+    def set_phi(self, phi):
+        phi = np.ascontiguousarray(phi, dtype=np.complex128)
+        assert phi.shape == (self.nx, self.nx)
+        self._chk(self.L.nq_set_phi(self.h, _dptr(phi.view(np.float64))), "nq_set_phi")
+
+    def refresh_grad_phi(self):
+        self._chk(self.L.nq_refresh_grad_phi(self.h), "nq_refresh_grad_phi")
+
+    def step(self, n=1):
+        self._chk(self.L.nq_step(self.h, int(n)), "nq_step")
+
+    def sync(self):
+        self._chk(self.L.nq_sync(self.h), "nq_sync")
+
+    # --- reads
+    _REAL = (F_Q, F_P, F_U, F_V, F_QPSI, F_QW)
+    _HALF = (F_QH, F_PH, F_QWH)
+
+    def field(self, fid):
+        n, h = self.nx, self.nx // 2 + 1
+        if fid in self._REAL:
+            out = np.empty((n, n), np.float64)
+        elif fid in self._HALF:
+            out = np.empty((n, h), np.complex128)
+        else:
+            out = np.empty((n, n), np.complex128)
+        self._chk(self.L.nq_get_field(self.h, fid, _dptr(out.view(np.float64))), "nq_get_field(%d)" % fid)
+        return out
+
+    def scalar(self, sid):
+        v = ctypes.c_double()
+        self._chk(self.L.nq_get_scalar(self.h, sid, ctypes.byref(v)), "nq_get_scalar(%d)" % sid)
+        return v.value
+
+    def coeff(self, eq, which):
+        n = self.nx
+        w = n // 2 + 1 if eq == 0 else n
+        out = np.empty((n, w), np.complex128)
+        self._chk(self.L.nq_get_coeff(self.h, eq, which, _dptr(out.view(np.float64))), "nq_get_coeff")
+        return out
+
+    # --- FFT seam
+    def _xf(self, fn, a, in_dtype, out_shape, out_dtype):
+        a = np.ascontiguousarray(a, dtype=in_dtype)
+        out = np.empty(out_shape, out_dtype)
+        self._chk(fn(self.h, _dptr(a.view(np.float64)), _dptr(out.view(np.float64))), fn.__name__)
+        return out
+
+    def fft2(self, a):
+        return self._xf(self.L.nq_fft2, a, np.complex128, (self.nx, self.nx), np.complex128)
+
+    def ifft2(self, a):
+        return self._xf(self.L.nq_ifft2, a, np.complex128, (self.nx, self.nx), np.complex128)
+
+    def rfft2(self, a):
+        return self._xf(self.L.nq_rfft2, a, np.float64, (self.nx, self.nx // 2 + 1), np.complex128)
+
+    def irfft2(self, a):
+        return self._xf(self.L.nq_irfft2, a, np.complex128, (self.nx, self.nx), np.float64)
+
+    # --- Jacobian pieces (device transforms; the model classes assemble the reference's arrays)
+    def products_uq_vq(self):
+        n, h = self.nx, self.nx // 2 + 1
+        out = np.empty((2, n, h), np.complex128)
+        self._chk(self.L.nq_jacobian_psi_q(self.h, _dptr(out.view(np.float64))), "nq_jacobian_psi_q")
+        return out[0], out[1]
+
+    def advection_phi(self):
+        out = np.empty((self.nx, self.nx), np.complex128)
+        self._chk(self.L.nq_jacobian_psi_phi(self.h, _dptr(out.view(np.float64))), "nq_jacobian_psi_phi")
+        return out
+
+    def wave_jacobian(self):
+        out = np.empty((self.nx, self.nx // 2 + 1), np.complex128)
+        self._chk(self.L.nq_jacobian_phic_phi(self.h, _dptr(out.view(np.float64))), "nq_jacobian_phic_phi")
+        return out
+
+    # --- timing
+    def timer_start(self):
+        self._chk(self.L.nq_timer_start(self.h), "nq_timer_start")
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        self._chk(self.L.nq_timer_stop(self.h, ctypes.byref(ms)), "nq_timer_stop")
+        return ms.value
+
+    def device_bytes(self):
+        return int(self.L.nq_device_bytes(self.h))

@@ -1,0 +1,215 @@
+// Workgroup-cooperative complex128 FFT for gfx950 (MI355X), data resident in registers.
+//
+// WgFft<N, P, C, LINE_MAJOR>::run<INV>() transforms C independent lines of length N with
+// T = N/P threads per line (block = C*T threads).  Thread (j, c) holds, before and after,
+//        r[t] = x_c[j + t*T],   t = 0..P-1          ("canonical distribution")
+// so consecutive j are consecutive elements: global loads/stores of a contiguous line coalesce
+// without any staging, and the same holds for column tiles (consecutive c = adjacent columns).
+//
+// Algorithm: Stockham autosort, radices <= 16 chosen at compile time.  With the canonical
+// distribution every stage's butterfly inputs are already thread-local (butterfly jj = j + b*T
+// reads x[jj + u*N/R] = r[b + u*P/R]); only the outputs have to be re-distributed, through LDS,
+// between stages -- (stages-1) exchanges of 16 B/point, the last stage lands canonical again.
+// LDS rows are padded by one element per 16 so the strided stage-1 scatter is conflict-free.
+//
+// 64-wide wavefronts; no MFMA (there is no contraction here); fp64 throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nq {
+
+typedef double2 cd;
+
+__device__ __forceinline__ cd cmul(cd a, cd b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cd cmulc(cd a, cd b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
+__device__ __forceinline__ cd cadd(cd a, cd b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cd csub(cd a, cd b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cd cscale(cd a, double s) { return make_double2(a.x * s, a.y * s); }
+__device__ __forceinline__ cd cconj(cd a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ cd cmul_i(cd a) { return make_double2(-a.y, a.x); }    // a * i
+__device__ __forceinline__ cd cmul_mi(cd a) { return make_double2(a.y, -a.x); }   // a * (-i)
+__device__ __forceinline__ cd cmake(double x, double y) { return make_double2(x, y); }
+
+// ---- small DFTs on register arrays, natural order in and out ------------------------------
+// forward: X[k] = sum x[n] exp(-2 pi i n k / R);  INV: conjugate kernel, no scaling.
+template <bool INV> __device__ __forceinline__ cd rot90(cd a) { return INV ? cmul_i(a) : cmul_mi(a); }  // * exp(-+ i pi/2)
+
+template <bool INV> __device__ __forceinline__ void dft2(cd& a, cd& b) {
+  cd t = csub(a, b);
+  a = cadd(a, b);
+  b = t;
+}
+
+template <bool INV> __device__ __forceinline__ void dft4(cd& a0, cd& a1, cd& a2, cd& a3) {
+  cd t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = rot90<INV>(csub(a1, a3));
+  a0 = cadd(t0, t2);
+  a1 = cadd(t1, t3);
+  a2 = csub(t0, t2);
+  a3 = csub(t1, t3);
+}
+
+// exp(-+ 2 pi i m/16), m = 0..15 (only the ones used)
+#define NQ_C1 0.92387953251128673848   // cos(pi/8)
+#define NQ_S1 0.38268343236508978178   // sin(pi/8)
+#define NQ_R2 0.70710678118654752440   // sqrt(1/2)
+
+template <bool INV> __device__ __forceinline__ cd tw16(cd a, int m) {
+  // multiply by w16^m (forward: exp(-2 pi i m/16)); m is a compile-time constant after unrolling
+  switch (m & 15) {
+    case 0: return a;
+    case 1: return INV ? cmul(a, cmake(NQ_C1, NQ_S1)) : cmul(a, cmake(NQ_C1, -NQ_S1));
+    case 2: return INV ? cscale(cmake(a.x - a.y, a.x + a.y), NQ_R2) : cscale(cmake(a.x + a.y, a.y - a.x), NQ_R2);
+    case 3: return INV ? cmul(a, cmake(NQ_S1, NQ_C1)) : cmul(a, cmake(NQ_S1, -NQ_C1));
+    case 4: return rot90<INV>(a);
+    case 5: return INV ? cmul(a, cmake(-NQ_S1, NQ_C1)) : cmul(a, cmake(-NQ_S1, -NQ_C1));
+    case 6: return INV ? cscale(cmake(-a.x - a.y, a.x - a.y), NQ_R2) : cscale(cmake(a.y - a.x, -a.x - a.y), NQ_R2);
+    case 7: return INV ? cmul(a, cmake(-NQ_C1, NQ_S1)) : cmul(a, cmake(-NQ_C1, -NQ_S1));
+    case 8: return cmake(-a.x, -a.y);
+    case 9: return INV ? cmul(a, cmake(-NQ_C1, -NQ_S1)) : cmul(a, cmake(-NQ_C1, NQ_S1));
+    default: return a;   // 10..15 never needed (max index 3*3 = 9)
+  }
+}
+
+template <int R, bool INV> struct Dft;
+
+template <bool INV> struct Dft<2, INV> {
+  __device__ __forceinline__ static void run(cd (&v)[2]) { dft2<INV>(v[0], v[1]); }
+};
+template <bool INV> struct Dft<4, INV> {
+  __device__ __forceinline__ static void run(cd (&v)[4]) { dft4<INV>(v[0], v[1], v[2], v[3]); }
+};
+template <bool INV> struct Dft<8, INV> {
+  // 8 = 2 (n1) x 4 (n2): n = 4*n1 + n2, k = k1 + 2*k2
+  __device__ __forceinline__ static void run(cd (&v)[8]) {
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft2<INV>(v[n2], v[4 + n2]);          // over n1 -> k1 at v[4*k1+n2]
+#pragma unroll
+    for (int n2 = 1; n2 < 4; ++n2) v[4 + n2] = tw16<INV>(v[4 + n2], 2 * n2);   // w8^(n2*k1), k1 = 1
+    dft4<INV>(v[0], v[1], v[2], v[3]);                                  // k1 = 0: over n2 -> k2
+    dft4<INV>(v[4], v[5], v[6], v[7]);                                  // k1 = 1
+    // now v[4*k1 + k2] = X[k1 + 2*k2]  -> reorder to natural
+    cd o[8];
+#pragma unroll
+    for (int k1 = 0; k1 < 2; ++k1)
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) o[k1 + 2 * k2] = v[4 * k1 + k2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = o[i];
+  }
+};
+template <bool INV> struct Dft<16, INV> {
+  // 16 = 4 (n1) x 4 (n2): n = 4*n1 + n2, k = k1 + 4*k2
+  __device__ __forceinline__ static void run(cd (&v)[16]) {
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);   // -> v[4*k1+n2]
+#pragma unroll
+    for (int k1 = 1; k1 < 4; ++k1)
+#pragma unroll
+      for (int n2 = 1; n2 < 4; ++n2) v[4 * k1 + n2] = tw16<INV>(v[4 * k1 + n2], n2 * k1);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+    cd o[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) o[k1 + 4 * k2] = v[4 * k1 + k2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = o[i];
+  }
+};
+
+// ---- radix plan -----------------------------------------------------------------------------
+__host__ __device__ constexpr int nq_min(int a, int b) { return a < b ? a : b; }
+__host__ __device__ constexpr int plan_radix(int N, int P, int stage) {
+  int rem = N, R = 1;
+  for (int s = 0; s <= stage; ++s) {
+    R = nq_min(rem, nq_min(P, 16));
+    rem /= R;
+  }
+  return R;
+}
+__host__ __device__ constexpr int plan_stages(int N, int P) {
+  int rem = N, n = 0;
+  while (rem > 1) {
+    rem /= nq_min(rem, nq_min(P, 16));
+    ++n;
+  }
+  return n;
+}
+__host__ __device__ constexpr int plan_ns(int N, int P, int stage) {   // product of radices before `stage`
+  int ns = 1;
+  for (int s = 0; s < stage; ++s) ns *= plan_radix(N, P, s);
+  return ns;
+}
+
+__device__ __forceinline__ int lds_pad(int p) { return p + (p >> 4); }
+template <int N> __host__ __device__ constexpr int lds_line_elems() { return N + (N >> 4) + 1; }
+
+// Twiddle table: tw[m] = exp(-2 pi i m / NT), m in [0, NT); NT is a multiple of N.
+template <int N, int P, int C, bool LINE_MAJOR>
+struct WgFft {
+  static constexpr int T = N / P;
+  static constexpr int STAGES = plan_stages(N, P);
+  static constexpr int LDS_ELEMS = (STAGES > 1) ? lds_line_elems<N>() * C : 0;   // cd elements
+  static_assert(N % P == 0, "P must divide N");
+
+  __device__ __forceinline__ static int lds_index(int p, int c) {
+    return LINE_MAJOR ? c * lds_line_elems<N>() + lds_pad(p) : lds_pad(p) * C + c;
+  }
+
+  template <bool INV, int STAGE>
+  __device__ __forceinline__ static void stage(cd (&r)[P], int j, int c, cd* lds, const cd* __restrict__ tw, int tw_step) {
+    constexpr int R = plan_radix(N, P, STAGE);
+    constexpr int NS = plan_ns(N, P, STAGE);
+    constexpr int NB = P / R;                     // butterflies per thread in this stage
+    constexpr bool LAST = (STAGE == STAGES - 1);
+    static_assert(P % R == 0, "radix must divide P");
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      cd v[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) v[u] = r[b + u * NB];
+      const int jj = j + b * T;
+      const int jr = jj % NS;
+      if (NS > 1) {
+        const int base = jr * (N / (NS * R)) * tw_step;
+#pragma unroll
+        for (int u = 1; u < R; ++u) {
+          cd w = tw[u * base];
+          v[u] = INV ? cmulc(v[u], w) : cmul(v[u], w);
+        }
+      }
+      Dft<R, INV>::run(v);
+      if (LAST) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) r[b + u * NB] = v[u];
+      } else {
+        const int pos = (jj / NS) * (NS * R) + jr;
+#pragma unroll
+        for (int u = 0; u < R; ++u) lds[lds_index(pos + u * NS, c)] = v[u];
+      }
+    }
+    if (!LAST) {
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < P; ++t) r[t] = lds[lds_index(j + t * T, c)];
+      __syncthreads();
+    }
+  }
+
+  template <bool INV, int STAGE>
+  __device__ __forceinline__ static void stages_from(cd (&r)[P], int j, int c, cd* lds, const cd* __restrict__ tw, int tw_step) {
+    if constexpr (STAGE < STAGES) {
+      stage<INV, STAGE>(r, j, c, lds, tw, tw_step);
+      stages_from<INV, STAGE + 1>(r, j, c, lds, tw, tw_step);
+    }
+  }
+
+  // tw_step = NT / N  (table stride for w_N)
+  template <bool INV>
+  __device__ __forceinline__ static void run(cd (&r)[P], int j, int c, cd* lds, const cd* __restrict__ tw, int tw_step) {
+    stages_from<INV, 0>(r, j, c, lds, tw, tw_step);
+  }
+};
+
+}  // namespace nq

@@ -1,0 +1,198 @@
+// Generic 2-D transform building blocks (not the fused hot path): row FFTs along x and the two
+// coalesced sub-passes of the y transform.  Used by the FFT seam (nq_fft2 ...), set_q/set_phi and
+// field downloads; the fused step kernels in nq_step.hpp reuse the same index conventions.
+//
+// y transform of length N = S1*S2 (y = y1 + S1*y2, l = l1 + S2*l2):
+//   forward  A: for fixed y1, FFT_{S2} over y2 -> l1, times w_N^(y1*l1), stored at row y1 + S1*l1
+//            B: for fixed l1, FFT_{S1} over y1 (rows S1*l1 + y1, contiguous) -> l2, stored at the
+//               NATURAL row l = l1 + S2*l2
+//   inverse  B^-1 then A^-1, conjugated.
+// Both sub-passes touch memory only in segments of CL*16 bytes (CL = 32 columns -> 512 B), which is
+// what makes them run at streaming bandwidth (tools/access_bench.hip).
+#pragma once
+#include "nq_fft.hpp"
+
+namespace nq {
+
+constexpr int CL = 32;   // columns per workgroup in the y sub-passes
+
+template <int S> struct YPlan {
+  static constexpr int P = (S >= 128) ? 16 : 8;
+  static constexpr int T = S / P;
+  static constexpr int THREADS = CL * T;
+  typedef WgFft<S, P, CL, false> F;
+  static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cd);
+};
+
+template <int N> struct XPlan {
+  static constexpr int P = (N >= 128) ? 16 : 8;
+  static constexpr int T = N / P;
+  static constexpr int C = (T >= 64) ? 1 : 64 / T;     // rows per workgroup (>= one wave)
+  static constexpr int THREADS = C * T;
+  typedef WgFft<N, P, C, true> F;
+  static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cd) + 16 * C;   // + per-row scratch words
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char nq_smem[];
+
+// ---------------------------------------------------------------- x direction, generic
+// mode 0: complex in (pitch_in) -> complex out; mode 1: multiply input by i*kk[kx] first
+template <int N, bool INV>
+__global__ void __launch_bounds__(XPlan<N>::THREADS)
+k_x_c2c(const cd* __restrict__ in, cd* __restrict__ out, int pitch_in, int pitch_out, int nrows, double scale,
+        const cd* __restrict__ tw, const double* __restrict__ kk, int mul_ik) {
+  typedef XPlan<N> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const int row = blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd r[P];
+  const bool ok = row < nrows;
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int kx = j + t * T;
+    cd v = ok ? in[(size_t)row * pitch_in + kx] : cmake(0, 0);
+    if (mul_ik) v = cscale(cmul_i(v), kk[kx]);
+    r[t] = v;
+  }
+  X::F::template run<INV>(r, j, c, lds, tw, 1);
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) out[(size_t)row * pitch_out + j + t * T] = cscale(r[t], scale);
+  }
+}
+
+// real rows -> half spectrum (N/2+1 entries per row)
+template <int N>
+__global__ void __launch_bounds__(XPlan<N>::THREADS)
+k_x_r2c(const double* __restrict__ in, cd* __restrict__ out, int pitch_in, int pitch_out, int nrows,
+        const cd* __restrict__ tw) {
+  typedef XPlan<N> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const int row = blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd r[P];
+  const bool ok = row < nrows;
+#pragma unroll
+  for (int t = 0; t < P; ++t) r[t] = cmake(ok ? in[(size_t)row * pitch_in + j + t * T] : 0.0, 0.0);
+  X::F::template run<false>(r, j, c, lds, tw, 1);
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t <= P / 2; ++t) {
+      const int kx = j + t * T;
+      if (kx <= N / 2) out[(size_t)row * pitch_out + kx] = r[t];
+    }
+  }
+}
+
+// half-spectrum rows (mixed space) -> real rows; imaginary parts of kx = 0 and N/2 are ignored,
+// exactly like numpy.fft.irfft.
+template <int N>
+__global__ void __launch_bounds__(XPlan<N>::THREADS)
+k_x_c2r(const cd* __restrict__ in, double* __restrict__ out, int pitch_in, int pitch_out, int nrows, double scale,
+        const cd* __restrict__ tw) {
+  typedef XPlan<N> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const int row = blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd r[P];
+  const bool ok = row < nrows;
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int kx = j + t * T;
+    cd v = cmake(0, 0);
+    if (ok) {
+      if (kx <= N / 2) {
+        v = in[(size_t)row * pitch_in + kx];
+        if (kx == 0 || kx == N / 2) v.y = 0.0;
+      } else {
+        v = cconj(in[(size_t)row * pitch_in + (N - kx)]);
+      }
+    }
+    r[t] = v;
+  }
+  X::F::template run<true>(r, j, c, lds, tw, 1);
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) out[(size_t)row * pitch_out + j + t * T] = r[t].x * scale;
+  }
+}
+
+// ---------------------------------------------------------------- y direction, generic
+struct ArrayList {        // up to 6 arrays processed by one launch (blockIdx.z selects)
+  cd* ptr[6];
+  int width[6];
+  int pitch[6];
+};
+
+// "A" sub-pass, in place.  grid = (col tiles, S1, narrays); S2 = transform length.
+template <int S2, bool INV>
+__global__ void __launch_bounds__(YPlan<S2>::THREADS)
+k_y_A(ArrayList al, int S1, const cd* __restrict__ tw, int tw_step_N /* NT/N */) {
+  typedef YPlan<S2> Y;
+  constexpr int P = Y::P, T = Y::T;
+  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
+  cd* data = al.ptr[blockIdx.z];
+  const int width = al.width[blockIdx.z], pitch = al.pitch[blockIdx.z];
+  const int col = blockIdx.x * CL + c;
+  if (blockIdx.x * CL >= width) return;            // whole tile outside this array (uniform)
+  const int y1 = blockIdx.y;
+  const bool ok = col < width;
+  const int N = S1 * S2;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd r[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int i2 = j + t * T;                       // y2 (forward) or l1 (inverse)
+    cd v = ok ? data[(size_t)(y1 + S1 * i2) * pitch + col] : cmake(0, 0);
+    if (INV) v = cmulc(v, tw[(size_t)(y1 * i2) * tw_step_N]);
+    r[t] = v;
+  }
+  Y::F::template run<INV>(r, j, c, lds, tw, tw_step_N * (N / S2));
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const int o2 = j + t * T;                     // l1 (forward) or y2 (inverse)
+      cd v = r[t];
+      if (!INV) v = cmul(v, tw[(size_t)(y1 * o2) * tw_step_N]);
+      data[(size_t)(y1 + S1 * o2) * pitch + col] = v;
+    }
+  }
+}
+
+// "B" sub-pass, out of place.  grid = (col tiles, S2, 1); S1 = transform length.
+// forward: in = half-transformed rows S1*l1 + y1, out = natural rows l1 + S2*l2
+// inverse: in = natural rows, out = half-transformed rows; `scale` applied on output.
+template <int S1, bool INV>
+__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+k_y_B(const cd* __restrict__ in, cd* __restrict__ out, int width, int pitch_in, int pitch_out, int S2, double scale,
+      const cd* __restrict__ tw, int tw_step_N) {
+  typedef YPlan<S1> Y;
+  constexpr int P = Y::P, T = Y::T;
+  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
+  const int col = blockIdx.x * CL + c;
+  const int l1 = blockIdx.y;
+  const bool ok = col < width;
+  const int N = S1 * S2;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd r[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int i = j + t * T;
+    const size_t row = INV ? (size_t)(l1 + S2 * i) : (size_t)(l1 * S1 + i);
+    r[t] = ok ? in[row * pitch_in + col] : cmake(0, 0);
+  }
+  Y::F::template run<INV>(r, j, c, lds, tw, tw_step_N * (N / S1));
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const int i = j + t * T;
+      const size_t row = INV ? (size_t)(l1 * S1 + i) : (size_t)(l1 + S2 * i);
+      out[row * pitch_out + col] = cscale(r[t], scale);
+    }
+  }
+}
+
+}  // namespace nq

@@ -1,0 +1,829 @@
+// niwqg_amd: context, precompute kernels and the C ABI (include/niwqg_amd.h).
+// gfx950 only; build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC nq_lib.hip -o libniwqg_amd.so
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/niwqg_amd.h"
+#include "nq_step.hpp"
+
+using namespace nq;
+
+static thread_local std::string g_last_error;
+
+#define NQ_FAIL(ctx, code, ...)                                  \
+  do {                                                           \
+    char buf_[512];                                              \
+    snprintf(buf_, sizeof(buf_), __VA_ARGS__);                   \
+    g_last_error = buf_;                                         \
+    if (ctx) (ctx)->err = buf_;                                  \
+    return (code);                                               \
+  } while (0)
+
+#define HIPCHK(ctx, call)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) NQ_FAIL(ctx, -5, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+struct EqState {           // ETDRK4 state of one equation
+  cd* y[3] = {nullptr, nullptr, nullptr};   // rotating: y[cur] = y(t_n)
+  int cur = 0;
+  cd *fn0 = nullptr, *fna = nullptr;
+  cd* coef[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // E, Eh, Q, f0, fab, fc (filter folded in)
+};
+
+struct nq_ctx {
+  nq_params p;
+  int N = 0, S1 = 0, S2 = 0, Wh = 0, Ph = 0, nk = 0;
+  bool kernel_family = true;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  long long bytes = 0;
+  std::vector<void*> allocs;
+  // tables
+  cd* tw = nullptr;
+  double *kk = nullptr, *ll = nullptr, *filt_h = nullptr, *filt_f = nullptr;
+  cd* contour = nullptr;
+  // equations
+  EqState q, w;
+  // half-spectrum aux spectra
+  cd *qwh = nullptr, *ph = nullptr;
+  // mixed arrays
+  cd *Mphi = nullptr, *Mphiy = nullptr, *Mgx = nullptr, *Mgy = nullptr, *Mj = nullptr, *Mr = nullptr;   // full width
+  cd *Ma = nullptr, *Mb = nullptr, *Mu = nullptr, *Mp = nullptr, *Mq = nullptr, *Mqw = nullptr, *Muq = nullptr,
+     *Mvq = nullptr;                                                                                     // half width
+  // scratch for the generic transforms / downloads
+  cd *scr_f0 = nullptr, *scr_f1 = nullptr, *scr_h0 = nullptr, *scr_h1 = nullptr;
+  double* scr_r = nullptr;
+  double scal[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // Ke, Pw, Kw accumulators (host copies)
+  bool have_q = false, have_phi = false;
+};
+
+template <typename Tp>
+static int dev_alloc(nq_ctx* c, Tp** out, size_t count) {
+  void* p = nullptr;
+  HIPCHK(c, hipMalloc(&p, count * sizeof(Tp)));
+  HIPCHK(c, hipMemsetAsync(p, 0, count * sizeof(Tp), c->stream));
+  c->allocs.push_back(p);
+  c->bytes += (long long)(count * sizeof(Tp));
+  *out = reinterpret_cast<Tp*>(p);
+  return 0;
+}
+#define ALLOC(c, ptr, count)                    \
+  do {                                          \
+    int rc_ = dev_alloc((c), &(ptr), (count));  \
+    if (rc_) return rc_;                        \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// ETDRK4 coefficient planes on the device (ref Kernel.py:417-454, QGModel.py:426-443).
+// eq 0: q (Kernel family), 1: phi, 2: q (QGModel, with beta).  One thread per spectral element.
+__device__ __forceinline__ cd cexp_d(cd z) {
+  double s, c;
+  sincos(z.y, &s, &c);
+  const double e = exp(z.x);
+  return cmake(e * c, e * s);
+}
+__device__ __forceinline__ cd cdiv(cd a, cd b) {
+  const double d = b.x * b.x + b.y * b.y;
+  return cmake((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+
+__global__ void k_etdrk4_coeffs(int eq, int N, int width, int pitch, nq_params p, const double* __restrict__ kk,
+                                const double* __restrict__ ll, const double* __restrict__ filt,
+                                const cd* __restrict__ contour, cd* E, cd* Eh, cd* Q, cd* f0, cd* fab, cd* fc) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = blockIdx.y;
+  if (k >= width) return;
+  const double kx = kk[k], ly = ll[l];
+  const double wv2 = kx * kx + ly * ly, wv4 = wv2 * wv2;
+  cd c;
+  if (eq == 0) {
+    c = cmake(-p.nu4 * wv4 - p.nu * wv2 - p.mu, -kx * p.U);
+  } else if (eq == 1) {
+    c = cmake(-p.nu4w * wv4 - p.nuw * wv2 - p.muw, -kx * p.U - 0.5 * p.f * (wv2 / p.kappa2));
+  } else {
+    const double wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
+    c = cmake(-p.nu4 * wv4 - p.nu * wv2 - p.mu, -kx * p.U + p.beta * kx * wv2i);
+  }
+  const cd ch = cscale(c, p.dt);
+  cd sQ = cmake(0, 0), s0 = cmake(0, 0), sab = cmake(0, 0), sc = cmake(0, 0);
+  for (int m = 0; m < 32; ++m) {
+    const cd LR = cadd(ch, contour[m]);
+    const cd LR2 = cmul(LR, LR), LR3 = cmul(LR2, LR);
+    const cd eLR = cexp_d(LR), eh = cexp_d(cscale(LR, 0.5));
+    sQ = cadd(sQ, cdiv(cmake(eh.x - 1.0, eh.y), LR));
+    // (-4 - LR + e^LR (4 - 3 LR + LR^2)) / LR^3
+    cd t = cmul(eLR, cmake(4.0 - 3.0 * LR.x + LR2.x, -3.0 * LR.y + LR2.y));
+    s0 = cadd(s0, cdiv(cmake(-4.0 - LR.x + t.x, -LR.y + t.y), LR3));
+    // (2 + LR + e^LR (-2 + LR)) / LR^3
+    t = cmul(eLR, cmake(-2.0 + LR.x, LR.y));
+    sab = cadd(sab, cdiv(cmake(2.0 + LR.x + t.x, LR.y + t.y), LR3));
+    // (-4 - 3 LR - LR^2 + e^LR (4 - LR)) / LR^3
+    t = cmul(eLR, cmake(4.0 - LR.x, -LR.y));
+    sc = cadd(sc, cdiv(cmake(-4.0 - 3.0 * LR.x - LR2.x + t.x, -3.0 * LR.y - LR2.y + t.y), LR3));
+  }
+  const size_t idx = (size_t)l * pitch + k;
+  const double fl = filt ? filt[idx] : 1.0;
+  const double s = p.dt / 32.0 * fl;
+  E[idx] = cscale(cexp_d(ch), fl);
+  Eh[idx] = cscale(cexp_d(cscale(ch, 0.5)), fl);
+  Q[idx] = cscale(sQ, s);
+  f0[idx] = cscale(s0, s);
+  fab[idx] = cscale(sab, s);
+  fc[idx] = cscale(sc, s);
+}
+
+// small helper kernels -------------------------------------------------------------------------
+// out = mult(l,k) * in on a spectral plane; mode 0: copy, 1: -i*l, 2: i*k, 3: -wv2i (psi from q, no wave part)
+__global__ void k_spec_mul(const cd* __restrict__ in, cd* __restrict__ out, int width, int pitch, int mode,
+                           const double* __restrict__ kk, const double* __restrict__ ll, int N, int kernel_family) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+  if (k >= width) return;
+  const size_t idx = (size_t)l * pitch + k;
+  const cd v = in[idx];
+  const double kx = kk[k], ly = ll[l];
+  cd o = v;
+  if (mode == 1) {
+    const double lz = (kernel_family && l == N / 2 && width != N) ? 0.0 : ly;
+    o = cmake(lz * v.y, -lz * v.x);
+  } else if (mode == 2) {
+    o = cmake(-kx * v.y, kx * v.x);
+  } else if (mode == 3) {
+    const double wv2 = kx * kx + ly * ly;
+    const double wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
+    o = cmake(-wv2i * v.x, -wv2i * v.y);
+  }
+  out[idx] = o;
+}
+
+// reductions: sum over a real/complex plane of a pointwise expression; result in out[0..] via atomics
+// kind 0: sum |a|^2 (complex plane, width N)       -> out[0]
+// kind 1: sum weight_k * wv2 * |a|^2 (half spectrum psi -> 2*ke_qg*M^2), skipping [0,0]
+// kind 2: sum wv2 * |a|^2 (full complex plane)
+// kind 3: max |a| over complex plane (out[0] as max via atomicMax on bits, values >= 0)
+__global__ void k_reduce(const cd* __restrict__ a, int width, int pitch, int N, int kind, const double* __restrict__ kk,
+                         const double* __restrict__ ll, double* out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+  double v = 0.0;
+  if (k < width) {
+    const cd z = a[(size_t)l * pitch + k];
+    const double m2 = z.x * z.x + z.y * z.y;
+    if (kind == 0) v = m2;
+    else if (kind == 1) {
+      const double w = (k == 0 || k == N / 2) ? 1.0 : 2.0;
+      v = (l == 0 && k == 0) ? 0.0 : w * (kk[k] * kk[k] + ll[l] * ll[l]) * m2;
+    } else if (kind == 2) v = (kk[k] * kk[k] + ll[l] * ll[l]) * m2;
+    else v = sqrt(m2);
+  }
+  __shared__ double sh[256];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] = (kind == 3) ? fmax(sh[threadIdx.x], sh[threadIdx.x + s]) : sh[threadIdx.x] + sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (kind == 3) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(sh[0]));
+    else atomicAdd(out, sh[0]);
+  }
+}
+__global__ void k_reduce_real_max(const double* __restrict__ a, size_t n, double* out) {
+  double v = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v = fmax(v, fabs(a[i]));
+  __shared__ double sh[256];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(sh[0]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// size dispatch
+#define NQ_FOR_SIZES(M) M(64, 8, 8) M(128, 8, 16) M(256, 16, 16) M(512, 16, 32) M(1024, 32, 32) M(2048, 32, 64) M(4096, 64, 64) M(8192, 64, 128)
+
+static bool plan_for(int N, int* S1, int* S2) {
+#define CASE_(n, a, b) if (N == n) { *S1 = a; *S2 = b; return true; }
+  NQ_FOR_SIZES(CASE_)
+#undef CASE_
+  return false;
+}
+
+// generic launches -----------------------------------------------------------------------------
+template <int N>
+static void launch_x_c2c_n(nq_ctx* c, bool inv, const cd* in, cd* out, int pin, int pout, int nrows, double scale, int mul_ik) {
+  typedef XPlan<N> X;
+  dim3 grid((nrows + X::C - 1) / X::C), block(X::THREADS);
+  if (inv) hipLaunchKernelGGL((k_x_c2c<N, true>), grid, block, X::LDS_BYTES, c->stream, in, out, pin, pout, nrows, scale, c->tw, c->kk, mul_ik);
+  else hipLaunchKernelGGL((k_x_c2c<N, false>), grid, block, X::LDS_BYTES, c->stream, in, out, pin, pout, nrows, scale, c->tw, c->kk, mul_ik);
+}
+static void launch_x_c2c(nq_ctx* c, bool inv, const cd* in, cd* out, int pin, int pout, double scale, int mul_ik = 0) {
+  switch (c->N) {
+#define CASE_(n, a, b) case n: launch_x_c2c_n<n>(c, inv, in, out, pin, pout, c->N, scale, mul_ik); break;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+  }
+}
+static void launch_x_r2c(nq_ctx* c, const double* in, cd* out) {
+  switch (c->N) {
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_r2c<n>), dim3((c->N + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, in, out, c->N, c->Ph, c->N, c->tw); } break;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+  }
+}
+static void launch_x_c2r(nq_ctx* c, const cd* in, double* out, double scale) {
+  switch (c->N) {
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_c2r<n>), dim3((c->N + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, in, out, c->Ph, c->N, c->N, scale, c->tw); } break;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+  }
+}
+
+template <int S>
+static void launch_A_s(nq_ctx* c, bool inv, const ArrayList& al, int n, int maxw) {
+  typedef YPlan<S> Y;
+  dim3 grid((maxw + CL - 1) / CL, c->S1, n), block(Y::THREADS);
+  if (inv) hipLaunchKernelGGL((k_y_A<S, true>), grid, block, Y::LDS_BYTES, c->stream, al, c->S1, c->tw, 1);
+  else hipLaunchKernelGGL((k_y_A<S, false>), grid, block, Y::LDS_BYTES, c->stream, al, c->S1, c->tw, 1);
+}
+// A sub-pass on a list of arrays; `half[i]` selects half-spectrum geometry
+static void launch_A(nq_ctx* c, bool inv, std::initializer_list<cd*> arrs, bool half) {
+  ArrayList al;
+  int n = 0, maxw = 0;
+  for (cd* a : arrs) {
+    al.ptr[n] = a;
+    al.width[n] = half ? c->Wh : c->N;
+    al.pitch[n] = half ? c->Ph : c->N;
+    maxw = al.width[n] > maxw ? al.width[n] : maxw;
+    ++n;
+  }
+  for (int i = n; i < 6; ++i) { al.ptr[i] = nullptr; al.width[i] = 0; al.pitch[i] = 0; }
+  switch (c->S2) {
+    case 8: launch_A_s<8>(c, inv, al, n, maxw); break;
+    case 16: launch_A_s<16>(c, inv, al, n, maxw); break;
+    case 32: launch_A_s<32>(c, inv, al, n, maxw); break;
+    case 64: launch_A_s<64>(c, inv, al, n, maxw); break;
+    case 128: launch_A_s<128>(c, inv, al, n, maxw); break;
+  }
+}
+template <int S>
+static void launch_B_s(nq_ctx* c, bool inv, const cd* in, cd* out, int width, int pitch, double scale) {
+  typedef YPlan<S> Y;
+  dim3 grid((width + CL - 1) / CL, c->S2), block(Y::THREADS);
+  if (inv) hipLaunchKernelGGL((k_y_B<S, true>), grid, block, Y::LDS_BYTES, c->stream, in, out, width, pitch, pitch, c->S2, scale, c->tw, 1);
+  else hipLaunchKernelGGL((k_y_B<S, false>), grid, block, Y::LDS_BYTES, c->stream, in, out, width, pitch, pitch, c->S2, scale, c->tw, 1);
+}
+static void launch_B(nq_ctx* c, bool inv, const cd* in, cd* out, bool half, double scale) {
+  const int width = half ? c->Wh : c->N, pitch = half ? c->Ph : c->N;
+  switch (c->S1) {
+    case 8: launch_B_s<8>(c, inv, in, out, width, pitch, scale); break;
+    case 16: launch_B_s<16>(c, inv, in, out, width, pitch, scale); break;
+    case 32: launch_B_s<32>(c, inv, in, out, width, pitch, scale); break;
+    case 64: launch_B_s<64>(c, inv, in, out, width, pitch, scale); break;
+  }
+}
+
+// whole 2-D transforms on device arrays (generic path) --------------------------------------------
+// complex physical (N,N) -> spectral (N,N), unnormalised; `tmp` is a full-plane scratch
+static void fwd2d_full(nq_ctx* c, const cd* phys, cd* spec, cd* tmp) {
+  launch_x_c2c(c, false, phys, tmp, c->N, c->N, 1.0);
+  launch_A(c, false, {tmp}, false);
+  launch_B(c, false, tmp, spec, false, 1.0);
+}
+static void inv2d_full(nq_ctx* c, const cd* spec, cd* phys, cd* tmp) {
+  launch_B(c, true, spec, tmp, false, 1.0 / ((double)c->N * c->N));
+  launch_A(c, true, {tmp}, false);
+  launch_x_c2c(c, true, tmp, phys, c->N, c->N, 1.0);
+}
+// real physical -> half spectrum
+static void fwd2d_half(nq_ctx* c, const double* phys, cd* spec, cd* tmp_h) {
+  launch_x_r2c(c, phys, tmp_h);
+  launch_A(c, false, {tmp_h}, true);
+  launch_B(c, false, tmp_h, spec, true, 1.0);
+}
+static void inv2d_half(nq_ctx* c, const cd* spec, double* phys, cd* tmp_h) {
+  launch_B(c, true, spec, tmp_h, true, 1.0 / ((double)c->N * c->N));
+  launch_A(c, true, {tmp_h}, true);
+  launch_x_c2r(c, tmp_h, phys, 1.0);
+}
+
+// fused-stage launches ----------------------------------------------------------------------------
+static void launch_wavepv(nq_ctx* c) {
+  switch (c->N) {
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mphi, c->Mphiy, c->Ma, c->Mb, c->Ph, c->tw, c->kk); } break;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+  }
+}
+template <int MODE>
+static void launch_products_m(nq_ctx* c) {
+  const cd* gx = (MODE == MODE_UNCOUPLED) ? c->Mgx : c->Mphi;
+  const cd* gy = (MODE == MODE_UNCOUPLED) ? c->Mgy : c->Mphiy;
+  const int vz = c->kernel_family ? 1 : 0;
+  switch (c->N) {
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mu, c->Mp, c->Mq, c->Mqw, c->Mphi, gx, gy, c->Muq, c->Mvq, c->Mj, c->Mr, c->Ph, c->tw, c->kk, vz); } break;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+  }
+}
+static void launch_products(nq_ctx* c) {
+  if (c->p.model == NQ_MODEL_COUPLED) launch_products_m<MODE_COUPLED>(c);
+  else if (c->p.model == NQ_MODEL_UNCOUPLED) launch_products_m<MODE_UNCOUPLED>(c);
+  else launch_products_m<MODE_QG>(c);
+}
+
+static EtdArrays etd_arrays(EqState& e, int stage, int* out_slot) {
+  // slots: cur = y(t_n); a = (cur+1)%3 holds the stage-0 result; b = (cur+2)%3 scratch
+  const int cur = e.cur, a = (cur + 1) % 3, b = (cur + 2) % 3;
+  EtdArrays ea;
+  ea.y_in = (stage == 2) ? e.y[a] : e.y[cur];
+  const int out = (stage == 0) ? a : (stage == 3 ? cur : b);
+  ea.y_out = e.y[out];
+  ea.fn0 = e.fn0;
+  ea.fna = e.fna;
+  ea.E = e.coef[0];
+  ea.Eh = e.coef[1];
+  ea.Q = e.coef[2];
+  ea.f0 = e.coef[3];
+  ea.fab = e.coef[4];
+  ea.fc = e.coef[5];
+  *out_slot = out;
+  return ea;
+}
+
+template <int S>
+static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage) {
+  typedef YPlan<S> Y;
+  hipLaunchKernelGGL((k_s_q<S>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Muq, c->Mvq, ea, stage, c->Wh, c->Ph, c->S2, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1);
+}
+template <int S>
+static void launch_sphi_s(nq_ctx* c, const EtdArrays& ea, int stage) {
+  typedef YPlan<S> Y;
+  hipLaunchKernelGGL((k_s_phi<S>), dim3(c->N / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Mj, c->Mr, ea, stage, c->S2, c->Mphi, c->Mphiy, 1.0 / ((double)c->N * c->N), c->ll, c->tw, 1);
+}
+template <int S>
+static void launch_emit_phi_s(nq_ctx* c, const cd* phih) {
+  typedef YPlan<S> Y;
+  hipLaunchKernelGGL((k_s_emit_phi<S>), dim3(c->N / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, phih, c->S2, c->Mphi, c->Mphiy, 1.0 / ((double)c->N * c->N), c->ll, c->tw, 1);
+}
+template <int S, int MODE>
+static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux) {
+  typedef YPlan<S> Y;
+  hipLaunchKernelGGL((k_s_invert<S, MODE>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Ma, c->Mb, qh, c->filt_h, c->Mu, c->Mp, c->Mq, c->Mqw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, c->Wh, c->Ph, c->S2, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1);
+}
+#define NQ_S1_SWITCH(c, CALL)         \
+  switch ((c)->S1) {                  \
+    case 8: CALL(8); break;           \
+    case 16: CALL(16); break;         \
+    case 32: CALL(32); break;         \
+    case 64: CALL(64); break;         \
+  }
+
+static void launch_sq(nq_ctx* c, const EtdArrays& ea, int stage) {
+#define CALL_(s) launch_sq_s<s>(c, ea, stage)
+  NQ_S1_SWITCH(c, CALL_)
+#undef CALL_
+}
+static void launch_sphi(nq_ctx* c, const EtdArrays& ea, int stage) {
+#define CALL_(s) launch_sphi_s<s>(c, ea, stage)
+  NQ_S1_SWITCH(c, CALL_)
+#undef CALL_
+}
+static void launch_emit_phi(nq_ctx* c, const cd* phih) {
+#define CALL_(s) launch_emit_phi_s<s>(c, phih)
+  NQ_S1_SWITCH(c, CALL_)
+#undef CALL_
+}
+static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux) {
+  if (c->p.model == NQ_MODEL_COUPLED) {
+#define CALL_(s) launch_invert_sm<s, MODE_COUPLED>(c, qh, store_aux)
+    NQ_S1_SWITCH(c, CALL_)
+#undef CALL_
+  } else {
+#define CALL_(s) launch_invert_sm<s, MODE_UNCOUPLED>(c, qh, store_aux)
+    NQ_S1_SWITCH(c, CALL_)
+#undef CALL_
+  }
+}
+
+// the inversion of the current qh (and, Coupled, current Mphi/Mphiy) into Mu, Mp, Mq, Mqw
+static void do_invert(nq_ctx* c, const cd* qh, bool store_aux) {
+  if (c->p.model == NQ_MODEL_COUPLED) {
+    launch_wavepv(c);
+    launch_A(c, false, {c->Ma, c->Mb}, true);
+  }
+  launch_invert(c, qh, store_aux);
+  if (c->p.model == NQ_MODEL_COUPLED) launch_A(c, true, {c->Mu, c->Mp, c->Mq, c->Mqw}, true);
+  else launch_A(c, true, {c->Mu, c->Mp, c->Mq}, true);
+}
+
+static void do_step(nq_ctx* c) {
+  const bool waves = c->p.model != NQ_MODEL_QG;
+  for (int s = 0; s < 4; ++s) {
+    launch_products(c);
+    int qslot = 0, wslot = 0;
+    if (waves) launch_A(c, false, {c->Mj, c->Mr}, false);
+    launch_A(c, false, {c->Muq, c->Mvq}, true);
+    EtdArrays eq = etd_arrays(c->q, s, &qslot);
+    launch_sq(c, eq, s);
+    if (waves) {
+      EtdArrays ew = etd_arrays(c->w, s, &wslot);
+      launch_sphi(c, ew, s);
+      launch_A(c, true, {c->Mphi, c->Mphiy}, false);
+    }
+    do_invert(c, c->q.y[qslot], s == 3);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* nq_last_error(const nq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int nq_create(const nq_params* p, const double* kk, const double* ll, const double* filtr, const double* contour,
+              int device, nq_ctx** out) {
+  if (!p || !kk || !ll || !filtr || !contour || !out) NQ_FAIL((nq_ctx*)nullptr, -1, "nq_create: null argument");
+  int S1, S2;
+  if (!plan_for(p->nx, &S1, &S2)) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d unsupported (power of two in [64, 8192])", p->nx);
+  if (p->model < 0 || p->model > 2) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: unknown model %d", p->model);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: no HIP device available");
+  if (device < 0 || device >= ndev) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: device %d out of range (%d devices)", device, ndev);
+  nq_ctx* c = new nq_ctx();
+  c->p = *p;
+  c->N = p->nx;
+  c->S1 = S1;
+  c->S2 = S2;
+  c->Wh = c->N / 2 + 1;
+  c->Ph = c->N / 2 + 8;
+  c->kernel_family = p->model != NQ_MODEL_QG;
+  c->nk = c->kernel_family ? c->N : c->Wh;
+  c->device = device;
+  const int N = c->N;
+  const size_t full = (size_t)N * N, half = (size_t)N * c->Ph;
+#define FAILC(rc)        \
+  do {                   \
+    g_last_error = c->err; \
+    nq_destroy(c);       \
+    return (rc);         \
+  } while (0)
+#define TRY(call)              \
+  do {                         \
+    int rc__ = (call);         \
+    if (rc__) FAILC(rc__);     \
+  } while (0)
+  auto setup = [&]() -> int {
+    HIPCHK(c, hipSetDevice(device));
+    HIPCHK(c, hipStreamCreate(&c->stream));
+    HIPCHK(c, hipEventCreate(&c->ev0));
+    HIPCHK(c, hipEventCreate(&c->ev1));
+    // twiddles, long-double accurate
+    std::vector<double> twh(2 * (size_t)N);
+    for (int m = 0; m < N; ++m) {
+      const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)N;
+      twh[2 * m] = (double)cosl(a);
+      twh[2 * m + 1] = (double)sinl(a);
+    }
+    ALLOC(c, c->tw, (size_t)N);
+    HIPCHK(c, hipMemcpyAsync(c->tw, twh.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
+    ALLOC(c, c->kk, (size_t)N);
+    ALLOC(c, c->ll, (size_t)N);
+    HIPCHK(c, hipMemcpyAsync(c->kk, kk, sizeof(double) * c->nk, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->ll, ll, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    ALLOC(c, c->contour, (size_t)32);
+    HIPCHK(c, hipMemcpyAsync(c->contour, contour, sizeof(double) * 64, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // filter planes: half-spectrum copy (pitch Ph) and, for the Kernel family, the full plane
+    ALLOC(c, c->filt_h, half);
+    HIPCHK(c, hipMemcpy2DAsync(c->filt_h, sizeof(double) * c->Ph, filtr, sizeof(double) * c->nk, sizeof(double) * c->Wh, N, hipMemcpyHostToDevice, c->stream));
+    if (c->kernel_family) {
+      ALLOC(c, c->filt_f, full);
+      HIPCHK(c, hipMemcpyAsync(c->filt_f, filtr, sizeof(double) * full, hipMemcpyHostToDevice, c->stream));
+    }
+    // equations
+    for (int i = 0; i < 3; ++i) ALLOC(c, c->q.y[i], half);
+    ALLOC(c, c->q.fn0, half);
+    ALLOC(c, c->q.fna, half);
+    for (int i = 0; i < 6; ++i) ALLOC(c, c->q.coef[i], half);
+    dim3 blk(64), grdh((c->Wh + 63) / 64, N), grdf((N + 63) / 64, N);
+    hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, c->kernel_family ? 0 : 2, N, c->Wh, c->Ph, c->p, c->kk, c->ll, c->filt_h, c->contour, c->q.coef[0], c->q.coef[1], c->q.coef[2], c->q.coef[3], c->q.coef[4], c->q.coef[5]);
+    ALLOC(c, c->ph, half);
+    ALLOC(c, c->qwh, half);
+    ALLOC(c, c->Ma, half);
+    ALLOC(c, c->Mb, half);
+    ALLOC(c, c->Mu, half);
+    ALLOC(c, c->Mp, half);
+    ALLOC(c, c->Mq, half);
+    ALLOC(c, c->Mqw, half);
+    ALLOC(c, c->Muq, half);
+    ALLOC(c, c->Mvq, half);
+    ALLOC(c, c->scr_h0, half);
+    ALLOC(c, c->scr_h1, half);
+    ALLOC(c, c->scr_r, full);
+    ALLOC(c, c->scr_f0, full);
+    ALLOC(c, c->scr_f1, full);
+    if (c->kernel_family) {
+      for (int i = 0; i < 3; ++i) ALLOC(c, c->w.y[i], full);
+      ALLOC(c, c->w.fn0, full);
+      ALLOC(c, c->w.fna, full);
+      for (int i = 0; i < 6; ++i) ALLOC(c, c->w.coef[i], full);
+      hipLaunchKernelGGL(k_etdrk4_coeffs, grdf, blk, 0, c->stream, 1, N, N, N, c->p, c->kk, c->ll, c->filt_f, c->contour, c->w.coef[0], c->w.coef[1], c->w.coef[2], c->w.coef[3], c->w.coef[4], c->w.coef[5]);
+      ALLOC(c, c->Mphi, full);
+      ALLOC(c, c->Mphiy, full);
+      ALLOC(c, c->Mj, full);
+      ALLOC(c, c->Mr, full);
+      if (c->p.model == NQ_MODEL_UNCOUPLED) {
+        ALLOC(c, c->Mgx, full);
+        ALLOC(c, c->Mgy, full);
+      }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  };
+  TRY(setup());
+  *out = c;
+  return 0;
+}
+
+int nq_destroy(nq_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (void* p : c->allocs) hipFree(p);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+void* nq_stream(nq_ctx* c) { return c ? (void*)c->stream : nullptr; }
+long long nq_device_bytes(const nq_ctx* c) { return c ? c->bytes : 0; }
+
+int nq_sync(nq_ctx* c) {
+  if (!c) return -1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int nq_timer_start(nq_ctx* c) {
+  if (!c) return -1;
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  return 0;
+}
+int nq_timer_stop(nq_ctx* c, float* ms) {
+  if (!c || !ms) return -1;
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev1));
+  HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+
+int nq_set_q(nq_ctx* c, const double* q_host) {
+  if (!c || !q_host) return -1;
+  const size_t full = (size_t)c->N * c->N;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->scr_r, q_host, sizeof(double) * full, hipMemcpyHostToDevice, c->stream));
+  fwd2d_half(c, c->scr_r, c->q.y[c->q.cur], c->scr_h0);
+  do_invert(c, c->q.y[c->q.cur], true);
+  c->have_q = true;
+  return nq_sync(c);
+}
+
+int nq_set_phi(nq_ctx* c, const double* phi_host) {
+  if (!c || !phi_host) return -1;
+  if (!c->kernel_family) NQ_FAIL(c, -4, "nq_set_phi: QGModel has no wave field");
+  const size_t full = (size_t)c->N * c->N;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->scr_f0, phi_host, sizeof(cd) * full, hipMemcpyHostToDevice, c->stream));
+  fwd2d_full(c, c->scr_f0, c->w.y[c->w.cur], c->scr_f1);
+  launch_emit_phi(c, c->w.y[c->w.cur]);
+  launch_A(c, true, {c->Mphi, c->Mphiy}, false);
+  c->have_phi = true;
+  int rc = nq_refresh_grad_phi(c);
+  if (rc) return rc;
+  return nq_sync(c);
+}
+
+int nq_refresh_grad_phi(nq_ctx* c) {
+  if (!c) return -1;
+  if (c->p.model == NQ_MODEL_UNCOUPLED) {
+    const size_t full = (size_t)c->N * c->N;
+    HIPCHK(c, hipMemcpyAsync(c->Mgx, c->Mphi, sizeof(cd) * full, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->Mgy, c->Mphiy, sizeof(cd) * full, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return 0;
+}
+
+int nq_step(nq_ctx* c, int nsteps) {
+  if (!c) return -1;
+  if (nsteps < 0) NQ_FAIL(c, -1, "nq_step: nsteps < 0");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int i = 0; i < nsteps; ++i) do_step(c);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ---- FFT seam ----------------------------------------------------------------------------------
+int nq_fft2(nq_ctx* c, const double* in, double* out) {
+  if (!c || !in || !out) return -1;
+  const size_t full = (size_t)c->N * c->N;
+  HIPCHK(c, hipMemcpyAsync(c->scr_f0, in, sizeof(cd) * full, hipMemcpyHostToDevice, c->stream));
+  fwd2d_full(c, c->scr_f0, c->scr_f0, c->scr_f1);
+  HIPCHK(c, hipMemcpyAsync(out, c->scr_f0, sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+int nq_ifft2(nq_ctx* c, const double* in, double* out) {
+  if (!c || !in || !out) return -1;
+  const size_t full = (size_t)c->N * c->N;
+  HIPCHK(c, hipMemcpyAsync(c->scr_f0, in, sizeof(cd) * full, hipMemcpyHostToDevice, c->stream));
+  inv2d_full(c, c->scr_f0, c->scr_f0, c->scr_f1);
+  HIPCHK(c, hipMemcpyAsync(out, c->scr_f0, sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+int nq_rfft2(nq_ctx* c, const double* in, double* out) {
+  if (!c || !in || !out) return -1;
+  const int N = c->N;
+  HIPCHK(c, hipMemcpyAsync(c->scr_r, in, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
+  fwd2d_half(c, c->scr_r, c->scr_h1, c->scr_h0);
+  HIPCHK(c, hipMemcpy2DAsync(out, sizeof(cd) * c->Wh, c->scr_h1, sizeof(cd) * c->Ph, sizeof(cd) * c->Wh, N, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+int nq_irfft2(nq_ctx* c, const double* in, double* out) {
+  if (!c || !in || !out) return -1;
+  const int N = c->N;
+  HIPCHK(c, hipMemcpy2DAsync(c->scr_h1, sizeof(cd) * c->Ph, in, sizeof(cd) * c->Wh, sizeof(cd) * c->Wh, N, hipMemcpyHostToDevice, c->stream));
+  inv2d_half(c, c->scr_h1, c->scr_r, c->scr_h0);
+  HIPCHK(c, hipMemcpyAsync(out, c->scr_r, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+
+// ---- downloads ---------------------------------------------------------------------------------
+static int get_half_spec(nq_ctx* c, const cd* dev, double* host) {
+  HIPCHK(c, hipMemcpy2DAsync(host, sizeof(cd) * c->Wh, dev, sizeof(cd) * c->Ph, sizeof(cd) * c->Wh, c->N, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+static int get_real_from_half(nq_ctx* c, const cd* spec, int mul_mode, double* host) {
+  const size_t full = (size_t)c->N * c->N;
+  const cd* src = spec;
+  if (mul_mode) {
+    hipLaunchKernelGGL(k_spec_mul, dim3((c->Wh + 63) / 64, c->N), dim3(64), 0, c->stream, spec, c->scr_h1, c->Wh, c->Ph, mul_mode, c->kk, c->ll, c->N, c->kernel_family ? 1 : 0);
+    src = c->scr_h1;
+  }
+  inv2d_half(c, src, c->scr_r, c->scr_h0);
+  HIPCHK(c, hipMemcpyAsync(host, c->scr_r, sizeof(double) * full, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+
+int nq_get_field(nq_ctx* c, int id, double* host) {
+  if (!c || !host) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t full = (size_t)c->N * c->N;
+  const cd* qh = c->q.y[c->q.cur];
+  const bool waves = c->kernel_family;
+  switch (id) {
+    case NQ_F_QH: return get_half_spec(c, qh, host);
+    case NQ_F_PH: return get_half_spec(c, c->ph, host);
+    case NQ_F_QWH:
+      if (c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qwh exists only in the coupled model");
+      return get_half_spec(c, c->qwh, host);
+    case NQ_F_Q: return get_real_from_half(c, qh, 0, host);
+    case NQ_F_P: return get_real_from_half(c, c->ph, 0, host);
+    case NQ_F_U: return get_real_from_half(c, c->ph, 1, host);
+    case NQ_F_V: {
+      // v = Re ifft(ik psi): psi must be Hermitian-projected on the Nyquist column first;
+      // equivalently its k = N/2 column does not contribute for the Kernel family.
+      hipLaunchKernelGGL(k_spec_mul, dim3((c->Wh + 63) / 64, c->N), dim3(64), 0, c->stream, c->ph, c->scr_h1, c->Wh, c->Ph, 2, c->kk, c->ll, c->N, 1);
+      if (c->kernel_family) HIPCHK(c, hipMemset2DAsync(c->scr_h1 + c->N / 2, sizeof(cd) * c->Ph, 0, sizeof(cd), c->N, c->stream));
+      inv2d_half(c, c->scr_h1, c->scr_r, c->scr_h0);
+      HIPCHK(c, hipMemcpyAsync(host, c->scr_r, sizeof(double) * full, hipMemcpyDeviceToHost, c->stream));
+      return nq_sync(c);
+    }
+    case NQ_F_QW:
+      if (c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qw exists only in the coupled model");
+      return get_real_from_half(c, c->qwh, 0, host);
+    case NQ_F_PHIH:
+      if (!waves) NQ_FAIL(c, -4, "no wave field in QGModel");
+      HIPCHK(c, hipMemcpyAsync(host, c->w.y[c->w.cur], sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
+      return nq_sync(c);
+    case NQ_F_PHI:
+      if (!waves) NQ_FAIL(c, -4, "no wave field in QGModel");
+      launch_x_c2c(c, true, c->Mphi, c->scr_f0, c->N, c->N, 1.0);
+      HIPCHK(c, hipMemcpyAsync(host, c->scr_f0, sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
+      return nq_sync(c);
+    case NQ_F_PHIX:
+    case NQ_F_PHIY: {
+      if (!waves) NQ_FAIL(c, -4, "no wave field in QGModel");
+      const bool unc = c->p.model == NQ_MODEL_UNCOUPLED;
+      const cd* src = (id == NQ_F_PHIX) ? (unc ? c->Mgx : c->Mphi) : (unc ? c->Mgy : c->Mphiy);
+      launch_x_c2c(c, true, src, c->scr_f0, c->N, c->N, 1.0, id == NQ_F_PHIX ? 1 : 0);
+      HIPCHK(c, hipMemcpyAsync(host, c->scr_f0, sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
+      return nq_sync(c);
+    }
+    default: NQ_FAIL(c, -1, "nq_get_field: unknown field id %d", id);
+  }
+}
+
+int nq_get_scalar(nq_ctx* c, int id, double* out) {
+  if (!c || !out) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = c->N;
+  const double M = (double)N * N;
+  double* d = reinterpret_cast<double*>(c->scr_h0);    // 2 doubles of scratch for the reductions
+  double h[2] = {0, 0};
+  HIPCHK(c, hipMemsetAsync(d, 0, sizeof(double) * 2, c->stream));
+  if (id == NQ_S_KE || id == NQ_S_PW || id == NQ_S_KW) {
+    *out = c->scal[id];
+    return 0;
+  }
+  if (id == NQ_S_KE_QG) {
+    hipLaunchKernelGGL(k_reduce, dim3((c->Wh + 255) / 256, N), dim3(256), 0, c->stream, c->ph, c->Wh, c->Ph, N, 1, c->kk, c->ll, d);
+    HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    int rc = nq_sync(c);
+    *out = 0.5 * h[0] / (M * M);
+    return rc;
+  }
+  if (!c->kernel_family) NQ_FAIL(c, -4, "scalar %d needs the wave field", id);
+  const cd* phih = c->w.y[c->w.cur];
+  if (id == NQ_S_KE_NIW || id == NQ_S_PE_NIW) {
+    hipLaunchKernelGGL(k_reduce, dim3((N + 255) / 256, N), dim3(256), 0, c->stream, phih, N, N, N, id == NQ_S_KE_NIW ? 0 : 2, c->kk, c->ll, d);
+    HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    int rc = nq_sync(c);
+    *out = (id == NQ_S_KE_NIW) ? 0.5 * h[0] / (M * M) : 0.25 * h[0] / (M * M) / c->p.kappa2;
+    return rc;
+  }
+  NQ_FAIL(c, -1, "nq_get_scalar: id %d not available", id);
+}
+
+int nq_get_coeff(nq_ctx* c, int eq, int which, double* out) {
+  if (!c || !out || which < 0 || which > 5 || eq < 0 || eq > 1) return -1;
+  if (eq == 1 && !c->kernel_family) NQ_FAIL(c, -4, "no phi equation in QGModel");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = c->N;
+  const bool half = eq == 0;
+  const int width = half ? c->Wh : N, pitch = half ? c->Ph : N;
+  const size_t cnt = (size_t)N * pitch;
+  cd* tmp[6];
+  for (int i = 0; i < 6; ++i) {
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, cnt * sizeof(cd)));
+    tmp[i] = reinterpret_cast<cd*>(p);
+  }
+  const int e = half ? (c->kernel_family ? 0 : 2) : 1;
+  hipLaunchKernelGGL(k_etdrk4_coeffs, dim3((width + 63) / 64, N), dim3(64), 0, c->stream, e, N, width, pitch, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5]);
+  hipError_t er = hipMemcpy2DAsync(out, sizeof(cd) * width, tmp[which], sizeof(cd) * pitch, sizeof(cd) * width, N, hipMemcpyDeviceToHost, c->stream);
+  int rc = nq_sync(c);
+  for (int i = 0; i < 6; ++i) hipFree(tmp[i]);
+  if (er != hipSuccess) NQ_FAIL(c, -5, "nq_get_coeff: copy failed");
+  return rc;
+}
+
+// Jacobians for the public API: the device produces the transforms, the Python mirror assembles the
+// reference's full-plane arrays (multiplying by ik/il and expanding Hermitian halves).
+int nq_jacobian_psi_q(nq_ctx* c, double* out_cplx) {
+  // out: 2 half-spectrum planes (ny, nx/2+1): F[u q] then F[v q]
+  if (!c || !out_cplx) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  launch_products(c);
+  launch_A(c, false, {c->Muq, c->Mvq}, true);
+  launch_B(c, false, c->Muq, c->scr_h0, true, 1.0);
+  launch_B(c, false, c->Mvq, c->scr_h1, true, 1.0);
+  int rc = get_half_spec(c, c->scr_h0, out_cplx);
+  if (rc) return rc;
+  return get_half_spec(c, c->scr_h1, out_cplx + 2 * (size_t)c->N * c->Wh);
+}
+int nq_jacobian_psi_phi(nq_ctx* c, double* out_cplx) {
+  // out: full plane F[u phix + v phiy] (the caller zeroes [0,0])
+  if (!c || !out_cplx) return -1;
+  if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
+  HIPCHK(c, hipSetDevice(c->device));
+  launch_products(c);
+  launch_A(c, false, {c->Mj}, false);
+  launch_B(c, false, c->Mj, c->scr_f0, false, 1.0);
+  HIPCHK(c, hipMemcpyAsync(out_cplx, c->scr_f0, sizeof(cd) * (size_t)c->N * c->N, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+int nq_jacobian_phic_phi(nq_ctx* c, double* out_cplx) {
+  // out: half-spectrum plane F[Re i(phix* phiy - phiy* phix)]
+  if (!c || !out_cplx) return -1;
+  if (c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "jacobian_phic_phi exists only in the coupled model");
+  HIPCHK(c, hipSetDevice(c->device));
+  launch_wavepv(c);
+  launch_A(c, false, {c->Mb}, true);
+  launch_B(c, false, c->Mb, c->scr_h0, true, 1.0);
+  return get_half_spec(c, c->scr_h0, out_cplx);
+}
+
+}  // extern "C"

@@ -1,0 +1,422 @@
+// Fused kernels of one ETDRK4 stage.  See DESIGN.md for the data flow; in short, per stage
+//
+//   X2  rows : Mu,Mp,Mq,Mqw,Mphi,Mphiy --x-ifft--> u,v,q,qw,phi,phix,phiy --products--x-fft--> Muq,Mvq,Mj,Mr
+//   A   (generic, in place) on Muq,Mvq,Mj,Mr
+//   Sq  tiles: B-fft of Muq,Mvq -> N_q -> ETDRK4 stage update of qh               (half spectrum)
+//   Sw  tiles: B-fft of Mj,Mr   -> N_phi -> ETDRK4 stage update of phih -> B-ifft -> Hphi,Hphiy
+//   A^-1 on Hphi,Hphiy
+//   X1  rows : Mphi,Mphiy --x-ifft--> phi,phix,phiy --|phi|^2, J(phi*,phi)--x-fft--> Ma,Mb   (Coupled)
+//   A   on Ma,Mb
+//   Si  tiles: B-fft of Ma,Mb -> qwh, ph -> B-ifft -> Hu,Hp,Hq,Hqw                 (inversion)
+//   A^-1 on Hu,Hp,Hq,Hqw
+//
+// "M*" arrays live in mixed space [y][kx] (x spectral, y physical); inverse-direction ones carry the
+// full 1/(nx*ny) factor.  Spectra of real fields are half spectra: kx = 0..N/2, pitch Ph.
+#pragma once
+#include "nq_generic.hpp"
+
+namespace nq {
+
+enum { MODE_COUPLED = 0, MODE_UNCOUPLED = 1, MODE_QG = 2 };
+
+// ---- helpers for the row kernels ----------------------------------------------------------
+// Build Z = A + i*B at full-row position kx from two half-spectrum rows (Hermitian completion);
+// `a_mul_ik` multiplies B by i*kk first (for v = ifft(ik psi)).  Self-mirrored entries kx = 0, N/2
+// keep only their real part (what numpy's irfft does, and what `.real` does in the reference).
+template <int N>
+__device__ __forceinline__ cd pack_pair(const cd* __restrict__ rowA, const cd* __restrict__ rowB, int kx,
+                                        const double* __restrict__ kk, bool b_mul_ik, bool b_zero_nyq) {
+  const bool mirror = kx > N / 2;
+  const int m = mirror ? N - kx : kx;
+  cd a = rowA[m], b = rowB[m];
+  if (b_mul_ik) b = cscale(cmul_i(b), kk[m]);
+  if (m == 0 || m == N / 2) {
+    a.y = 0.0;
+    b.y = 0.0;
+    if (b_zero_nyq && m == N / 2) b.x = 0.0;
+  }
+  if (mirror) {
+    a.y = -a.y;
+    b.y = -b.y;
+  }
+  return cmake(a.x - b.y, a.y + b.x);
+}
+
+// After a forward row FFT of z = a + i*b (a, b real), split into the two half spectra and store
+// kx = 0..N/2.  Needs the mirrored element Z[N-kx], fetched through LDS.
+template <int N, int P, int T, typename F>
+__device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* lds, cd* __restrict__ rowA,
+                                                  cd* __restrict__ rowB, double scaleB = 1.0) {
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < P; ++t) lds[F::lds_index(j + t * T, c)] = r[t];
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t <= P / 2; ++t) {
+    const int kx = j + t * T;
+    if (kx <= N / 2) {
+      const cd z = r[t];
+      const cd zm = lds[F::lds_index((N - kx) % N, c)];
+      // A = (Z + conj Zm)/2 ; B = (Z - conj Zm)/(2i)
+      rowA[kx] = cmake(0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y));
+      rowB[kx] = cmake(scaleB * 0.5 * (z.y + zm.y), scaleB * 0.5 * (zm.x - z.x));
+    }
+  }
+  __syncthreads();
+}
+
+// ---- X1: wave potential-vorticity sources (CoupledModel._invert, ref CoupledModel.py:59-88) ------
+template <int N>
+__global__ void __launch_bounds__(XPlan<N>::THREADS)
+k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __restrict__ Ma, cd* __restrict__ Mb,
+           int Ph, const cd* __restrict__ tw, const double* __restrict__ kk) {
+  typedef XPlan<N> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const size_t row = (size_t)blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd phi[P], gx[P], z[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int kx = j + t * T;
+    phi[t] = Mphi[row * N + kx];
+    gx[t] = cscale(cmul_i(phi[t]), kk[kx]);
+  }
+  X::F::template run<true>(phi, j, c, lds, tw, 1);
+  X::F::template run<true>(gx, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) z[t].x = phi[t].x * phi[t].x + phi[t].y * phi[t].y;
+#pragma unroll
+  for (int t = 0; t < P; ++t) phi[t] = Mphiy[row * N + j + t * T];        // reuse registers for phiy
+  X::F::template run<true>(phi, j, c, lds, tw, 1);
+  double ma = 0.0, mb = 0.0;
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    z[t].y = -2.0 * (gx[t].x * phi[t].y - gx[t].y * phi[t].x);
+    ma = fmax(ma, z[t].x);
+    mb = fmax(mb, fabs(z[t].y));
+  }
+  // The two real fields share one complex transform; |phi|^2 is typically 1e8 times larger than
+  // J(phi*,phi), so the second is rescaled per row by a power of two (exactly undone after the
+  // split) to keep the roundoff of one from swamping the other.
+  unsigned long long* mx = reinterpret_cast<unsigned long long*>(lds + X::F::LDS_ELEMS) + 2 * c;
+  if (j == 0) {
+    mx[0] = 0ull;
+    mx[1] = 0ull;
+  }
+  __syncthreads();
+  atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
+  atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
+  __syncthreads();
+  ma = __longlong_as_double((long long)mx[0]);
+  mb = __longlong_as_double((long long)mx[1]);
+  int e = 0;
+  if (ma > 0.0 && mb > 0.0) e = ilogb(ma) - ilogb(mb);
+  e = e > 900 ? 900 : (e < -900 ? -900 : e);
+  const double sb = ldexp(1.0, e), isb = ldexp(1.0, -e);
+#pragma unroll
+  for (int t = 0; t < P; ++t) z[t].y *= sb;
+  X::F::template run<false>(z, j, c, lds, tw, 1);
+  unpack_pair_store<N, P, T, typename X::F>(z, j, c, lds, Ma + row * Ph, Mb + row * Ph, isb);
+}
+
+// ---- X2: all nonlinear products of one stage ------------------------------------------------
+// ref Kernel.py:471-486 (jacobian_psi_q), :457-469 (jacobian_psi_phi), :332 (refraction).
+// MODE_QG: only Muq, Mvq.  MODE_UNCOUPLED: q_psi = q, phix/phiy from the (possibly stale) Mgx/Mgy.
+template <int N, int MODE>
+__global__ void __launch_bounds__(XPlan<N>::THREADS)
+k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __restrict__ Mq,
+             const cd* __restrict__ Mqw, const cd* __restrict__ Mphi, const cd* __restrict__ Mgx,
+             const cd* __restrict__ Mgy, cd* __restrict__ Muq, cd* __restrict__ Mvq, cd* __restrict__ Mj,
+             cd* __restrict__ Mr, int Ph, const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq) {
+  typedef XPlan<N> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const size_t row = (size_t)blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd uv[P], w[P];
+  double qpsi[P];
+  // (u, v) = ifft of (-il psi, ik psi): Mu already holds T_y^-1[-il psi], Mp holds T_y^-1[psi]
+#pragma unroll
+  for (int t = 0; t < P; ++t) uv[t] = pack_pair<N>(Mu + row * Ph, Mp + row * Ph, j + t * T, kk, true, v_zero_nyq);
+  X::F::template run<true>(uv, j, c, lds, tw, 1);
+  // (q, qw)
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    if (MODE == MODE_COUPLED) {
+      w[t] = pack_pair<N>(Mq + row * Ph, Mqw + row * Ph, j + t * T, kk, false, false);
+    } else {
+      const int kx = j + t * T;
+      const bool mirror = kx > N / 2;
+      const int m = mirror ? N - kx : kx;
+      cd a = Mq[row * Ph + m];
+      if (m == 0 || m == N / 2) a.y = 0.0;
+      if (mirror) a.y = -a.y;
+      w[t] = a;
+    }
+  }
+  X::F::template run<true>(w, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const double q = w[t].x;
+    qpsi[t] = (MODE == MODE_COUPLED) ? q - w[t].y : q;
+    w[t] = cmake(uv[t].x * q, uv[t].y * q);                  // u q + i v q
+  }
+  X::F::template run<false>(w, j, c, lds, tw, 1);
+  unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, Muq + row * Ph, Mvq + row * Ph);
+  if (MODE == MODE_QG) return;
+  // refraction source phi * q_psi
+#pragma unroll
+  for (int t = 0; t < P; ++t) w[t] = Mphi[row * N + j + t * T];
+  X::F::template run<true>(w, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) w[t] = cscale(w[t], qpsi[t]);
+  X::F::template run<false>(w, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) Mr[row * N + j + t * T] = w[t];
+  // advection u phix + v phiy
+  cd acc[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int kx = j + t * T;
+    w[t] = cscale(cmul_i(Mgx[row * N + kx]), kk[kx]);
+  }
+  X::F::template run<true>(w, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) acc[t] = cscale(w[t], uv[t].x);
+#pragma unroll
+  for (int t = 0; t < P; ++t) w[t] = Mgy[row * N + j + t * T];
+  X::F::template run<true>(w, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) acc[t] = cmake(acc[t].x + w[t].x * uv[t].y, acc[t].y + w[t].y * uv[t].y);
+  X::F::template run<false>(acc, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) Mj[row * N + j + t * T] = acc[t];
+}
+
+// ---- ETDRK4 stage update of one spectral element -----------------------------------------------
+// ref Kernel.py:327,:347,:364,:381-382 (q) and :333,:351,:368,:386-387 (phi).  The filter is folded
+// into the coefficient planes (Ef = E*filtr ...), which is the same arithmetic up to rounding.
+struct EtdArrays {
+  const cd* y_in;      // stage 0,1,3: y(t_n) ; stage 2: y after stage 0
+  cd* y_out;
+  cd* fn0;
+  cd* fna;             // Na, then Na+Nb
+  const cd* Eh;        // exp(c dt/2) * filtr
+  const cd* Q;
+  const cd* E;
+  const cd* f0;
+  const cd* fab;
+  const cd* fc;
+};
+
+__device__ __forceinline__ cd etd_update(const EtdArrays& a, size_t idx, cd Nl, int stage) {
+  cd y;
+  if (stage == 0) {
+    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], Nl));
+    a.fn0[idx] = Nl;
+  } else if (stage == 1) {
+    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], Nl));
+    a.fna[idx] = Nl;
+  } else if (stage == 2) {
+    const cd n0 = a.fn0[idx];
+    const cd comb = cmake(2.0 * Nl.x - n0.x, 2.0 * Nl.y - n0.y);
+    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], comb));
+    const cd na = a.fna[idx];
+    a.fna[idx] = cadd(na, Nl);
+  } else {
+    const cd n0 = a.fn0[idx], nab = a.fna[idx];
+    y = cadd(cadd(cmul(a.E[idx], a.y_in[idx]), cmul(a.f0[idx], n0)),
+             cadd(cscale(cmul(a.fab[idx], nab), 2.0), cmul(a.fc[idx], Nl)));
+  }
+  a.y_out[idx] = y;
+  return y;
+}
+
+// ---- Sq: nonlinear term + stage update of q-hat on the half spectrum --------------------------------
+template <int S1>
+__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+k_s_q(const cd* __restrict__ Huq, const cd* __restrict__ Hvq, EtdArrays ea, int stage, int Wh, int Ph, int S2,
+      const double* __restrict__ kk, const double* __restrict__ ll, int kernel_family, const cd* __restrict__ tw,
+      int tw_step_N) {
+  typedef YPlan<S1> Y;
+  constexpr int P = Y::P, T = Y::T;
+  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
+  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const bool ok = k < Wh;
+  const int N = S1 * S2;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd f1[P], f2[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const size_t at = (size_t)(l1 * S1 + j + t * T) * Ph + k;
+    f1[t] = ok ? Huq[at] : cmake(0, 0);
+    f2[t] = ok ? Hvq[at] : cmake(0, 0);
+  }
+  Y::F::template run<false>(f1, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<false>(f2, j, c, lds, tw, tw_step_N * (N / S1));
+  if (!ok) return;
+  const double kx = kk[k];
+  const bool interior = (k > 0) && (k < N / 2);
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int l = l1 + S2 * (j + t * T);
+    double ly = ll[l];
+    if (kernel_family && interior && l == N / 2) ly = 0.0;      // see DESIGN.md "Nyquist row"
+    // N_q = -(ik F1 + il F2)
+    cd Nl = cmake(kx * f1[t].y + ly * f2[t].y, -(kx * f1[t].x + ly * f2[t].x));
+    if (kernel_family && l == 0 && k == 0) Nl = cmake(0, 0);   // jach[0,0] = 0 (QGModel does not)
+    etd_update(ea, (size_t)l * Ph + k, Nl, stage);
+  }
+}
+
+// ---- Sw: nonlinear term + stage update of phi-hat, then first half of the inverse y transform -----
+template <int S1>
+__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int stage, int S2,
+        cd* __restrict__ Hphi, cd* __restrict__ Hphiy, double invM, const double* __restrict__ ll,
+        const cd* __restrict__ tw, int tw_step_N) {
+  typedef YPlan<S1> Y;
+  constexpr int P = Y::P, T = Y::T;
+  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
+  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int N = S1 * S2;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd a[P], b[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const size_t at = (size_t)(l1 * S1 + j + t * T) * N + k;
+    a[t] = Hj[at];
+    b[t] = Hr[at];
+  }
+  Y::F::template run<false>(a, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<false>(b, j, c, lds, tw, tw_step_N * (N / S1));
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int l = l1 + S2 * (j + t * T);
+    cd J = a[t];
+    if (l == 0 && k == 0) J = cmake(0, 0);
+    // N_phi = -J - 0.5 i R
+    const cd Nl = cmake(-J.x + 0.5 * b[t].y, -J.y - 0.5 * b[t].x);
+    const cd y = etd_update(ea, (size_t)l * N + k, Nl, stage);
+    a[t] = cscale(y, invM);
+    b[t] = cscale(cmul_i(y), ll[l] * invM);
+  }
+  Y::F::template run<true>(a, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<true>(b, j, c, lds, tw, tw_step_N * (N / S1));
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const size_t at = (size_t)(l1 * S1 + j + t * T) * N + k;
+    Hphi[at] = a[t];
+    Hphiy[at] = b[t];
+  }
+}
+
+// emit-only variant (set_phi): phih -> Hphi, Hphiy
+template <int S1>
+__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+k_s_emit_phi(const cd* __restrict__ phih, int S2, cd* __restrict__ Hphi, cd* __restrict__ Hphiy, double invM,
+             const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N) {
+  typedef YPlan<S1> Y;
+  constexpr int P = Y::P, T = Y::T;
+  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
+  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int N = S1 * S2;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd a[P], b[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int l = l1 + S2 * (j + t * T);
+    const cd y = phih[(size_t)l * N + k];
+    a[t] = cscale(y, invM);
+    b[t] = cscale(cmul_i(y), ll[l] * invM);
+  }
+  Y::F::template run<true>(a, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<true>(b, j, c, lds, tw, tw_step_N * (N / S1));
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const size_t at = (size_t)(l1 * S1 + j + t * T) * N + k;
+    Hphi[at] = a[t];
+    Hphiy[at] = b[t];
+  }
+}
+
+// ---- Si: the psi inversion on the half spectrum + first half of the four inverse y transforms -----
+// MODE_COUPLED: ref CoupledModel.py:75-97 with ph = wv2i*(qwh - qh) instead of fft(ifft(.).real)
+// (oracle/reduced_pipeline.py proves the equivalence).  Other modes: ph = -wv2i*qh (Ha, Hb unused).
+template <int S1, int MODE>
+__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __restrict__ qh,
+           const double* __restrict__ filt, cd* __restrict__ Hu, cd* __restrict__ Hp, cd* __restrict__ Hq,
+           cd* __restrict__ Hqw, cd* __restrict__ qwh_out, cd* __restrict__ ph_out, int Wh, int Ph, int S2,
+           double invM, double f, const double* __restrict__ kk, const double* __restrict__ ll, int kernel_family,
+           const cd* __restrict__ tw, int tw_step_N) {
+  typedef YPlan<S1> Y;
+  constexpr int P = Y::P, T = Y::T;
+  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
+  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const bool ok = k < Wh;
+  const int N = S1 * S2;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd a[P], b[P], u[P], q[P];
+  if (MODE == MODE_COUPLED) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const size_t at = (size_t)(l1 * S1 + j + t * T) * Ph + k;
+      a[t] = ok ? Ha[at] : cmake(0, 0);
+      b[t] = ok ? Hb[at] : cmake(0, 0);
+    }
+    Y::F::template run<false>(a, j, c, lds, tw, tw_step_N * (N / S1));
+    Y::F::template run<false>(b, j, c, lds, tw, tw_step_N * (N / S1));
+  }
+  const double kx = ok ? kk[k] : 0.0;
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int l = l1 + S2 * (j + t * T);
+    const size_t idx = (size_t)l * Ph + k;
+    const double ly = ll[l];
+    const double wv2 = kx * kx + ly * ly;
+    const double wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
+    const cd qv = ok ? qh[idx] : cmake(0, 0);
+    cd qw = cmake(0, 0), psi;
+    if (MODE == MODE_COUPLED) {
+      cd B = b[t];
+      if (l == 0 && k == 0) B = cmake(0, 0);
+      const double g = 0.5 * (-wv2);
+      const double fl = ok ? filt[idx] : 0.0;
+      qw = cmake(0.5 * (g * a[t].x + B.x) / f * fl, 0.5 * (g * a[t].y + B.y) / f * fl);
+      psi = cmake(wv2i * (qw.x - qv.x), wv2i * (qw.y - qv.y));
+    } else {
+      psi = cmake(-wv2i * qv.x, -wv2i * qv.y);
+    }
+    if (ok && ph_out) {
+      ph_out[idx] = psi;
+      if (MODE == MODE_COUPLED) qwh_out[idx] = qw;
+    }
+    // u = Re ifft(-il psi) with psi Hermitian (ref Kernel.py:481): the whole Nyquist row drops out.
+    // On the two self-mirrored columns psi is kept un-projected here and the row kernels take the
+    // real part after the y transform; that commutes with -il everywhere except at l = N/2, where
+    // numpy's ll is not odd -- so the row is zeroed on every column (DESIGN.md "Nyquist lines").
+    const double lz = (kernel_family && l == N / 2) ? 0.0 : ly;
+    u[t] = cmake(lz * psi.y * invM, -lz * psi.x * invM);        // -i l psi
+    a[t] = cscale(psi, invM);
+    q[t] = cscale(qv, invM);
+    b[t] = cscale(qw, invM);
+  }
+  Y::F::template run<true>(u, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<true>(a, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<true>(q, j, c, lds, tw, tw_step_N * (N / S1));
+  if (MODE == MODE_COUPLED) Y::F::template run<true>(b, j, c, lds, tw, tw_step_N * (N / S1));
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const size_t at = (size_t)(l1 * S1 + j + t * T) * Ph + k;
+      Hu[at] = u[t];
+      Hp[at] = a[t];
+      Hq[at] = q[t];
+      if (MODE == MODE_COUPLED) Hqw[at] = b[t];
+    }
+  }
+}
+
+}  // namespace nq

@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Benchmark of the ETDRK4 hot path on MI355X (contract: task statement, section 4).
+
+    python bench.py --gpus 1 --steps K --warmup W
+
+One "step" = one full ETDRK4 time step (4 stages, 36 fused 2-D transforms + budgets) of
+CoupledModel 4096^2 fp64 (BASELINE.json configs[2]: LambDipole q, uniform phi, filter on), with the
+state resident in HBM.  Prints ONE JSON line.  `roofline` is for the dominant kernel (k_x_products),
+timed live with HIP events on the context's stream; `cpu_baseline` times the numpy oracle in its
+reference-faithful mode (104 c2c transforms per step, 1 thread) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F0, NB, L = 1e-4, 0.01, 2 * np.pi * 200e3
+MZ = 2 * np.pi / 280.0
+K0 = 10 * (2 * np.pi / L)
+U0 = 0.1
+TE = 1.0 / (U0 * K0)
+
+# algorithmic bytes per grid point ("bytes"): SURVEY 8(d) canonical figure per step, and the
+# bytes one k_x_products launch must move (4 half-spectrum + 2 full inputs, 2 half + 2 full outputs)
+CANONICAL_B_PER_PT_STEP = {"coupled": 3136, "uncoupled": 2240, "qg": 848}
+X_PRODUCTS_B_PER_PT = {"coupled": 4 * 8 + 2 * 16 + 2 * 8 + 2 * 16, "uncoupled": 3 * 8 + 3 * 16 + 2 * 8 + 2 * 16,
+                       "qg": 3 * 8 + 2 * 8}
+HBM_PEAK_GBS = 8000.0
+
+
+def c3_kwargs(nx, model):
+    dt = 0.025 * TE * 128 / nx
+    kw = dict(L=L, nx=nx, tmax=1e30, dt=dt, twrite=10 ** 9, tdiags=10 ** 9, use_filter=True, U=-U0)
+    if model == "qg":
+        kw.update(nu4=7.5e8 / 64 if nx == 2048 else 5e11 * (128.0 / nx) ** 4, dt=0.05 * TE * 128 / nx)
+    else:
+        kw.update(m=MZ, N=NB, f=F0, nu4=5e11 * (128.0 / nx) ** 4, nu4w=0.0, nu=20, nuw=50.0, mu=0.0, muw=0.0)
+    return kw
+
+
+def build_model(model, nx, device):
+    import niwqg_amd
+    from niwqg_amd import InitialConditions as ic
+    mod = {"coupled": niwqg_amd.CoupledModel, "uncoupled": niwqg_amd.UnCoupledModel, "qg": niwqg_amd.QGModel}[model]
+    m = mod.Model(device=device, **c3_kwargs(nx, model))
+    if model == "qg" and nx == 2048:
+        q = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx))
+    else:
+        q = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+    m.set_q(q)
+    if model != "qg":
+        m.set_phi((np.ones((nx, nx)) + 1j) * (2 * U0) / np.sqrt(2))
+    return m
+
+
+def cpu_baseline(model, nx_target, budget_s=20.0):
+    """Reference-faithful numpy oracle (oracle/niwqg_oracle.py), one thread, on a bounded sample:
+    the same model at a grid that finishes in ~20 s; steps/s is scaled to nx_target with N^2 log2 N."""
+    try:
+        import threadpoolctl
+        limiter = threadpoolctl.threadpool_limits(1)
+    except Exception:
+        limiter = None
+    from oracle import niwqg_oracle as O
+    nx = 512 if model != "qg" else 1024
+    kw = c3_kwargs(nx, model)
+    kw.pop("twrite"), kw.pop("tdiags")
+    if model == "qg":
+        m = O.QGOracle(twrite=10 ** 9, tdiags=10 ** 9, **kw)
+    else:
+        m = O.NIWQGOracle(model, twrite=10 ** 9, tdiags=10 ** 9, coeff_chunk=16, **kw)
+    m.set_q(O.lamb_dipole(m.grid, U=U0, R=2 * np.pi / K0))
+    if model != "qg":
+        m.set_phi((np.ones((nx, nx)) + 1j) * (2 * U0) / np.sqrt(2))
+    m._step_forward()                      # includes the one-off tc==0 diagnostics tick
+    t0, n = time.perf_counter(), 0
+    while True:
+        m._step_forward()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    sps = n / el
+    scale = (nx_target ** 2 * np.log2(nx_target)) / (nx ** 2 * np.log2(nx))
+    if limiter is not None:
+        limiter.unregister() if hasattr(limiter, "unregister") else None
+    return {"value": sps / scale, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": "%s oracle (numpy.fft, %d transforms/step) %d^2: %d steps in %.1f s = %.3f steps/s; "
+                      "scaled by N^2 log2 N to %d^2" % (model, sum(m.fft_calls) // (n + 1), nx, n, el, sps, nx_target),
+            "measured_steps_per_s_at_sample": sps, "sample_nx": nx, "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nx", type=int, default=4096)
+    ap.add_argument("--model", default="coupled", choices=["coupled", "uncoupled", "qg"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    # Round 1: the slab-decomposed multi-GPU path is not built yet; with N > 1 every rank
+    # advances its own replica of the full problem and the line says so ("replicas", weak scaling).
+    m = build_model(args.model, args.nx, local_rank)
+    ctx = m._ctx
+    ctx.step(args.warmup)
+    ctx.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    ctx.profile_enable(ctx.KERNEL_CLASSES["x_products"])
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    ctx.step(args.steps)
+    dev_ms = ctx.timer_stop()
+    barrier()
+    wall = time.perf_counter() - t0
+    launches, kms = ctx.profile_read()
+    ctx.profile_enable(-1)
+    if dist is not None:
+        tt = torch.tensor([wall], device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    if rank == 0:
+        npts = float(args.nx) ** 2
+        sps = world * args.steps / wall
+        k_ms = kms / max(launches, 1)
+        k_bytes = X_PRODUCTS_B_PER_PT[args.model] * npts
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9
+        step_bytes = CANONICAL_B_PER_PT_STEP[args.model] * npts
+        out = {
+            "metric": "time-steps/sec, %sModel %d^2 fp64 (achieved HBM GB/s in roofline)" % (
+                {"coupled": "Coupled", "uncoupled": "UnCoupled", "qg": "QG"}[args.model], args.nx),
+            "value": sps, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%sModel LambDipole %d^2 fp64, ETDRK4, filter on, budgets %s, 1 replica per GPU"
+                                   % (args.model, args.nx, "on" if ctx.budgets_enabled else "off"),
+                       "parallelism": "replicas x%d (slab decomposition not built yet)" % world if world > 1 else "single GPU",
+                       "device_ms_per_step_hip_events": dev_ms / args.steps,
+                       "device_bytes": ctx.device_bytes()},
+            "roofline": {"bound": "hbm", "kernel": "k_x_products", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": launches, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
+                         "step_canonical_bytes": step_bytes,
+                         "step_achieved_GBs": step_bytes / (wall / args.steps) / 1e9,
+                         "step_frac_of_peak": step_bytes / (wall / args.steps) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model, args.nx)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

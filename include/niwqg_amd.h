@@ -79,6 +79,9 @@ const char* nq_last_error(const nq_ctx* ctx);     /* ctx may be NULL: last globa
 int nq_set_q(nq_ctx* ctx, const double* q_host);
 /* Kernel.set_phi (Kernel.py:538-551): phi_host is complex (ny,nx) */
 int nq_set_phi(nq_ctx* ctx, const double* phi_host);
+/* CoupledModel._invert + _calc_rel_vorticity (CoupledModel.py:75-97,:145-152), UnCoupledModel._invert
+ * (UnCoupledModel.py:54-64), QGModel._invert (QGModel.py:497-505) on the current state */
+int nq_invert(nq_ctx* ctx);
 /* replay of the side effect of _calc_pe_niw on phix/phiy (Kernel.py:610, quirk Q1) */
 int nq_refresh_grad_phi(nq_ctx* ctx);
 
@@ -111,6 +114,11 @@ int nq_get_coeff(nq_ctx* ctx, int eq, int which, double* out_cplx);
 /* timing of the hot loop with HIP events on the context's stream */
 int nq_timer_start(nq_ctx* ctx);
 int nq_timer_stop(nq_ctx* ctx, float* elapsed_ms);
+/* Per-kernel timing with HIP events on the context's stream.  While enabled, every launch of the
+ * selected kernel class inside nq_step is bracketed by an event pair (cost ~2 us per launch).
+ * class: 0 x_products, 1 x_wavepv, 2 s_q, 3 s_phi, 4 s_invert, 5 y_A (all A sub-passes)              */
+int nq_profile_enable(nq_ctx* ctx, int kernel_class);     /* -1 disables */
+int nq_profile_read(nq_ctx* ctx, int* launches, float* total_ms);   /* synchronises, then resets */
 /* bytes of device memory held by the context */
 long long nq_device_bytes(const nq_ctx* ctx);
 /* stream handle (hipStream_t) so that callers can order their own work */

@@ -1,0 +1,48 @@
+"""Xie & Vanneste coupled NIW-QG model on the MI355X stepper.
+
+Drop-in for ``niwqg.CoupledModel.Model`` (ref: niwqg/CoupledModel.py:5-152): same constructor
+keywords, ``set_q``/``set_phi``/``run`` and attributes; the wave-PV inversion and the ETDRK4 stages
+run in HIP kernels (niwqg_amd/csrc/nq_step.hpp: k_x_wavepv, k_s_invert, k_x_products, k_s_q, k_s_phi).
+"""
+import numpy as np
+
+from . import Kernel, _lib
+from .Diagnostics import add_diagnostic
+from .Kernel import hermitian_full
+
+
+class Model(Kernel.Kernel):
+    model_id = _lib.COUPLED
+
+    def __init__(self, **kwargs):
+        self.model = " Coupled Model"
+        super(Model, self).__init__(**kwargs)
+
+    def jacobian_phic_phi(self):
+        """F[Re i(phix* phiy - phiy* phix)], [0,0] = 0; refreshes phix, phiy from the current phih.
+        ref: niwqg/CoupledModel.py:59-73"""
+        jach = hermitian_full(self._ctx.wave_jacobian())
+        jach[0, 0] = 0
+        return jach
+
+    def _calc_ke_qg_decomp(self):
+        """ref: niwqg/CoupledModel.py:99-113 (diagnostic tick, host arithmetic on downloaded spectra)"""
+        self.phq = -self.wv2i * self.qh
+        self.ke_qg_q = 0.5 * self.spec_var(self.wv * self.phq)
+        self.phw = self.wv2i * self.qwh
+        self.ke_qg_w = 0.5 * self.spec_var(self.wv * self.phw)
+        self.uq, self.vq = self.ifft(-self.il * self.phq).real, self.ifft(self.ik * self.phq).real
+        self.uw, self.vw = self.ifft(-self.il * self.phw).real, self.ifft(self.ik * self.phw).real
+        self.ke_qg_qw = (self.uq * self.uw).mean() + (self.vq * self.vw).mean()
+
+    def _initialize_class_diagnostics(self):
+        """ref: niwqg/CoupledModel.py:115-136"""
+        add_diagnostic(self, 'ke_qg_q', description='Quasigeostrophic Kinetic Energy, q-flow',
+                       units=r'm^2 s^{-2}', types='scalar', function=(lambda self: self.ke_qg_q))
+        add_diagnostic(self, 'ke_qg_w', description='Quasigeostrophic Kinetic Energy, w-flow',
+                       units=r'm^2 s^{-2}', types='scalar', function=(lambda self: self.ke_qg_w))
+        add_diagnostic(self, 'ke_qg_qw', description='Quasigeostrophic Kinetic Energy, cross-term q-w',
+                       units=r'm^2 s^{-2}', types='scalar', function=(lambda self: self.ke_qg_qw))
+
+    def _calc_class_derived_fields(self):
+        self._calc_ke_qg_decomp()

@@ -1,0 +1,438 @@
+"""Host-side mirror of ``niwqg.Kernel.Kernel`` for the MI355X stepper.
+
+Same constructor keywords, methods and attributes as the reference (ref: niwqg/Kernel.py:70-152 and
+SURVEY.md section 8b); every time step runs in HIP kernels behind the C ABI (include/niwqg_amd.h).
+Field attributes (``q``, ``phi``, ``qh`` ...) are fetched from the device on access and cached until
+the state changes.  There is no CPU path: without the HIP library and a GPU the constructor raises.
+"""
+import logging
+
+import numpy as np
+from numpy import pi
+
+from . import _lib
+from .Diagnostics import add_diagnostic, increment_diagnostics
+
+_DEVICE_FIELDS = {"q": _lib.F_Q, "p": _lib.F_P, "phi": _lib.F_PHI, "phih": _lib.F_PHIH, "u": _lib.F_U,
+                  "v": _lib.F_V, "phix": _lib.F_PHIX, "phiy": _lib.F_PHIY}
+
+
+def hermitian_full(half):
+    """(ny, nx/2+1) half spectrum of a real field -> the reference's (ny, nx) layout."""
+    n = half.shape[0]
+    full = np.empty((n, n), complex)
+    full[:, :n // 2 + 1] = half
+    inner = half[:, 1:n // 2]
+    full[:, n // 2 + 1:] = np.conj(np.roll(inner[::-1, :], 1, axis=0))[:, ::-1]
+    return full
+
+
+def project_self_mirrored_columns(half):
+    """Hermitian part (in l) of the k=0 and k=N/2 columns: what fft(real field) has there."""
+    out = half.copy()
+    for c in (0, half.shape[1] - 1):
+        col = half[:, c]
+        out[:, c] = 0.5 * (col + np.conj(np.roll(col[::-1], 1)))
+    return out
+
+
+class Kernel(object):
+    """Pseudo-spectral NIW-QG kernel; subclasses fix the inversion (``model_id``)."""
+
+    model_id = None
+
+    def __init__(self, nx=128, ny=None, L=5e5, dt=10000., twrite=1000., tmax=250000., use_filter=True,
+                 cflmax=0.8, U=.0, f=1.e-4, N=0.01, m=0.025, g=9.81, nu4=0, nu4w=0, nu=20, nuw=50., mu=0,
+                 muw=0, dealias=False, save_to_disk=False, overwrite=True, tsave_snapshots=10, tdiags=10,
+                 path='output/', use_mkl=False, nthreads=1, device=0, budgets=True):
+        # ref: niwqg/Kernel.py:100-137 -- note ny is ignored there too (quirk Q3)
+        self.nx = nx
+        self.ny = nx
+        self.L = L
+        self.W = L
+        self.dt = dt
+        self.twrite = twrite
+        self.tmax = tmax
+        self.dealias = dealias
+        self.U, self.g = U, g
+        self.nu4, self.nu4w, self.nu, self.nuw, self.mu, self.muw = nu4, nu4w, nu, nuw, mu, muw
+        self.f, self.N, self.m = f, N, m
+        self.kappa = self.m * self.f / self.N
+        self.kappa2 = self.kappa ** 2
+        self.cflmax = cflmax
+        self.hslash = self.f / self.kappa2
+        self.save_to_disk = save_to_disk
+        self.overwrite = overwrite
+        self.tsnaps = tsave_snapshots
+        self.tdiags = tdiags
+        self.path = path
+        self.use_filter = use_filter
+        self.use_mkl, self.nthreads = use_mkl, nthreads
+        if save_to_disk:
+            raise NotImplementedError("save_to_disk: HDF5 output is outside the accelerated path (SURVEY 8f)")
+        if dealias and not use_filter:
+            raise NotImplementedError(
+                "dealias=True: the reference's 2/3 mask (Kernel.py:277-281) is not mirror-symmetric, which "
+                "needs a second q-hat copy on the device; not built yet (DESIGN.md, known gaps)")
+
+        self._initialize_logger()
+        self.logger.info(self.model)
+        self._initialize_grid()
+        self._initialize_filter()
+        self._ctx = _lib.Context(self.model_id, nx, self.kk, self.ll, self.filtr, dt, U=U, f=f, kappa2=self.kappa2,
+                                 nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw, budgets=budgets, device=device)
+        self._cache = {}
+        self._user = {}
+        self._initialize_time()
+        self._initialize_diagnostics()
+        self.Ke = self.ke = 0.0
+        self.Pw = self.Kw = 0.0
+
+    # ------------------------------------------------------------------ setup
+    def _initialize_logger(self):
+        """ref: niwqg/Kernel.py:286-304"""
+        self.logger = logging.getLogger(__name__)
+        if not self.logger.handlers:
+            h = logging.StreamHandler()
+            h.setFormatter(logging.Formatter('%(levelname)s: %(message)s'))
+            self.logger.addHandler(h)
+        self.logger.setLevel(10)
+        self.logger.propagate = False
+        self.logger.info(' Logger initialized')
+
+    def _initialize_time(self):
+        self.t = 0
+        self.tc = 0
+
+    def _initialize_grid(self):
+        """1-D wavenumbers eagerly, 2-D planes lazily.  ref: niwqg/Kernel.py:227-265"""
+        self.dk = 2. * pi / self.L
+        self.dl = 2. * pi / self.L
+        self.nl = self.ny
+        self.nk = self.nl
+        self.ll = self.dl * np.append(np.arange(0., self.nx / 2), np.arange(-self.nx / 2, 0.))
+        self.kk = self.ll.copy()
+        self.dx = self.L / self.nx
+        self.dy = self.W / self.ny
+        self.M = self.nx * self.ny
+
+    _LAZY = ("x", "y", "k", "l", "ik", "il", "wv2", "wv", "wv4", "wv2i")
+
+    def __getattr__(self, name):
+        if name in Kernel._LAZY:
+            self._build_planes()
+            return self.__dict__[name]
+        if name in _DEVICE_FIELDS or name in ("qh", "ph", "qwh", "q_psi", "qw"):
+            return self._field(name)
+        raise AttributeError(name)
+
+    def _build_planes(self):
+        d = self.__dict__
+        d["x"], d["y"] = np.meshgrid(np.arange(0.5, self.nx, 1.) / self.nx * self.L,
+                                     np.arange(0.5, self.ny, 1.) / self.ny * self.W)
+        d["k"], d["l"] = np.meshgrid(self.kk, self.ll)
+        d["ik"], d["il"] = 1j * d["k"], 1j * d["l"]
+        d["wv2"] = d["k"] ** 2 + d["l"] ** 2
+        d["wv"] = np.sqrt(d["wv2"])
+        d["wv4"] = d["wv2"] ** 2
+        nz = d["wv2"] != 0.
+        d["wv2i"] = np.zeros_like(d["wv2"])
+        d["wv2i"][nz] = d["wv2"][nz] ** -1
+
+    def _initialize_filter(self):
+        """ref: niwqg/Kernel.py:267-284 (same arithmetic, built from the 1-D wavenumbers)"""
+        k, l = self.kk[None, :], self.ll[:, None]
+        if self.use_filter:
+            cphi = 0.65 * pi
+            wvx = np.sqrt((k * self.dx) ** 2. + (l * self.dy) ** 2.)
+            self.filtr = np.exp(-23.6 * (wvx - cphi) ** 4.)
+            self.filtr[wvx <= cphi] = 1.
+            self.logger.info(' Using filter')
+        else:
+            self.filtr = np.ones((self.nl, self.nk))
+            self.logger.info(' No dealiasing; no filter')
+
+    # ------------------------------------------------------------------ device state views
+    def _dirty(self):
+        self._cache.clear()
+        self._user.clear()
+
+    def _field(self, name):
+        if name in self._user:
+            return self._user[name]
+        if name not in self._cache:
+            c = self._ctx
+            if name == "qh":
+                v = hermitian_full(c.field(_lib.F_QH))
+            elif name == "ph":
+                v = hermitian_full(project_self_mirrored_columns(c.field(_lib.F_PH)))
+            elif name == "qwh":
+                v = hermitian_full(c.field(_lib.F_QWH)) if self.model_id == _lib.COUPLED else None
+            elif name == "qw":
+                v = c.field(_lib.F_QW)
+            elif name == "q_psi":
+                v = self._field("q") - self._field("qw") if self.model_id == _lib.COUPLED else self._field("q")
+            else:
+                v = c.field(_DEVICE_FIELDS[name])
+            self._cache[name] = v
+        return self._cache[name]
+
+    # ------------------------------------------------------------------ public API of the reference
+    def fft(self, x):
+        """ref: niwqg/Kernel.py:562-566 (numpy.fft.fft2 semantics)"""
+        return self._ctx.fft2(x)
+
+    def ifft(self, x):
+        return self._ctx.ifft2(x)
+
+    def set_q(self, q):
+        """ref: niwqg/Kernel.py:520-535 -- inverts with the current phi (quirk Q2)"""
+        self._ctx.set_q(q)
+        self._dirty()
+        self._user["q"] = q
+        self.Ke = self.ke = self._calc_ke_qg()
+
+    def set_phi(self, phi):
+        """ref: niwqg/Kernel.py:538-551 -- does NOT re-invert (quirk Q2)"""
+        self._ctx.set_phi(phi)
+        keep = {k: v for k, v in self._cache.items() if k not in ("phi", "phih", "phix", "phiy")}
+        keepu = {k: v for k, v in self._user.items() if k != "phi"}
+        self._cache, self._user = keep, keepu
+        self._user["phi"] = phi
+        self.Pw = self._calc_pe_niw()
+        self.Kw = self._calc_ke_niw()
+
+    def _invert(self):
+        self._ctx.invert()
+        self._dirty()
+
+    def _calc_rel_vorticity(self):
+        """q_psi is formed on the device inside the product kernel; nothing to do on the host."""
+
+    def jacobian_psi_q(self):
+        """ik F[u q] + il F[v q], [0,0] = 0.  ref: niwqg/Kernel.py:471-486"""
+        f1, f2 = self._ctx.products_uq_vq()
+        jach = self.ik * hermitian_full(f1) + self.il * hermitian_full(f2)
+        jach[0, 0] = 0
+        return jach
+
+    def jacobian_psi_phi(self):
+        """F[u phix + v phiy], [0,0] = 0.  ref: niwqg/Kernel.py:457-469"""
+        jach = self._ctx.advection_phi()
+        jach[0, 0] = 0
+        return jach
+
+    def spec_var(self, ph):
+        """ref: niwqg/Kernel.py:654-658"""
+        var_dens = np.abs(ph) ** 2 / self.M ** 2
+        var_dens[0, 0] = 0.
+        return var_dens.sum()
+
+    # ------------------------------------------------------------------ stepping
+    def _step_etdrk4(self):
+        """One ETDRK4 step on the device.  ref: niwqg/Kernel.py:307-397"""
+        self._ctx.step(1)
+        self._after_steps()
+
+    def _after_steps(self):
+        self._dirty()
+        if self._ctx.budgets_enabled:
+            dKe, dPw, dKw = self._ctx.take_budget_increments()
+            self.Ke += dKe
+            self.Pw += dPw
+            self.Kw += dKw
+
+    def _step_forward(self):
+        """ref: niwqg/Kernel.py:205-217 (snapshots are out of scope)"""
+        self._step_etdrk4()
+        increment_diagnostics(self)
+        self._print_status()
+
+    def _quiet_steps(self, n_left):
+        """How many of the next ``n_left`` steps need no host attention before the first one that
+        does: a diagnostics tick fires after a step when tc_before % tdiags == 0 (Diagnostics.py:43),
+        a status line when (tc_before + 1) % twrite == 0 (Kernel.py:587-590)."""
+        for j in range(n_left):
+            tcb = self.tc + j
+            if (tcb % self.tdiags) == 0 or ((tcb + 1) % self.twrite) == 0:
+                return j
+        return n_left - 1
+
+    def _steps_left(self, cap=1 << 30):
+        """Replays the reference's float clock ``while t < tmax: t += dt`` (Kernel.py:198,:588)."""
+        t, n = self.t, 0
+        while t < self.tmax and n < cap:
+            t += self.dt
+            n += 1
+        return n
+
+    def run(self):
+        """ref: niwqg/Kernel.py:183-203.  Steps between host-visible events are batched into one
+        nq_step call; the sequence of diagnostics ticks and status lines is the reference's."""
+        while self.t < self.tmax:
+            quiet = self._quiet_steps(self._steps_left(4096))
+            if quiet > 0:
+                self._ctx.step(quiet)
+                for _ in range(quiet):
+                    self.tc += 1
+                    self.t += self.dt
+                self._after_steps()
+            self._step_forward()
+
+    def run_with_snapshots(self, tsnapstart=0., tsnapint=432000.):
+        """ref: niwqg/Kernel.py:161-181"""
+        tsnapints = np.ceil(tsnapint / self.dt)
+        while self.t < self.tmax:
+            self._step_forward()
+            if self.t >= tsnapstart and (self.tc % tsnapints) == 0:
+                yield self.t
+        return
+
+    def _print_status(self):
+        """ref: niwqg/Kernel.py:568-598"""
+        self.tc += 1
+        self.t += self.dt
+        if (self.tc % self.twrite) == 0:
+            self.ke = self._calc_ke_qg()
+            self.kew = self._calc_ke_niw()
+            self.pew = self._calc_pe_niw()
+            self.cfl = self._calc_cfl()
+            self.logger.info('Step: %4i, Time: %2.1e, P: %2.1e, Ke: %4.3e, Kw: %4.3e, Pw: %4.3e, CFL: %3.2f',
+                             self.tc, self.t, self.t / self.tmax, self.ke, self.kew, self.pew, self.cfl)
+            assert self.cfl < self.cflmax, self.logger.error('CFL condition violated')
+
+    # ------------------------------------------------------------------ scalar integrals
+    def _calc_ke_qg(self):
+        """ref: niwqg/Kernel.py:600-602 (device reduction over the half spectrum)"""
+        return self._ctx.scalar(_lib.S_KE_QG)
+
+    def _calc_ke_niw(self):
+        """ref: niwqg/Kernel.py:604-606 (Parseval form, device reduction)"""
+        return self._ctx.scalar(_lib.S_KE_NIW)
+
+    def _calc_pe_niw(self):
+        """ref: niwqg/Kernel.py:608-611 -- including its side effect on phix/phiy (quirk Q1)"""
+        self._ctx.refresh_grad_phi()
+        self._cache.pop("phix", None)
+        self._cache.pop("phiy", None)
+        return self._ctx.scalar(_lib.S_PE_NIW)
+
+    def _calc_cfl(self):
+        """ref: niwqg/Kernel.py:660-662"""
+        return np.abs(np.hstack([self.u, self.v, np.abs(self.phi)])).max() * self.dt / self.dx
+
+    def _calc_ens(self):
+        return 0.5 * (self.q ** 2).mean()
+
+    def _calc_conc(self):
+        """ref: niwqg/Kernel.py:613-619"""
+        a2 = np.abs(self.phi) ** 2
+        self.upsilon = a2 - a2.mean()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return (self.upsilon * self.q_psi).mean() / self.upsilon.std() / self.q_psi.std()
+
+    def _calc_skewness(self):
+        return (self.q_psi ** 3).mean() / (((self.q_psi ** 2).mean()) ** 1.5)
+
+    def _calc_ep_phi(self):
+        """ref: niwqg/Kernel.py:629-633"""
+        return (-self.nu4w * (np.abs(self.lapphi) ** 2).mean()
+                - self.nuw * (np.abs(self.phix) ** 2 + np.abs(self.phiy) ** 2).mean()
+                - self.muw * (np.abs(self.phi) ** 2).mean())
+
+    def _calc_ep_psi(self):
+        """ref: niwqg/Kernel.py:635-640"""
+        lap2psi = self.ifft(self.wv4 * self.ph).real
+        lapq = self.ifft(-self.wv2 * self.qh).real
+        return (self.nu4 * (self.q * lap2psi).mean() - self.nu * (self.p * lapq).mean()
+                + self.mu * (self.p * self.q).mean())
+
+    def _calc_chi_q(self):
+        return -self.nu4 * self.spec_var(self.wv2 * self.qh)
+
+    def _calc_chi_phi(self):
+        """ref: niwqg/Kernel.py:646-652"""
+        lphix = self.ifft(-self.ik * self.wv2 * self.phih)
+        lphiy = self.ifft(-self.il * self.wv2 * self.phih)
+        return (-0.5 * self.nu4w * (np.abs(lphix) ** 2 + np.abs(lphiy) ** 2).mean() / self.kappa2
+                - 0.5 * self.nuw * (np.abs(self.lapphi) ** 2).mean() / self.kappa2
+                - 0.5 * self.muw * (np.abs(self.phix) ** 2 + np.abs(self.phiy) ** 2).mean() / self.kappa2)
+
+    def _calc_energy_conversion(self):
+        """Diagnostic-tick version of ref niwqg/Kernel.py:664-701 on downloaded fields (the in-step
+        budget rates are evaluated on the device)."""
+        u, v, phi, qpsi = self.u, self.v, self.phi, self.q_psi
+        J = u * self.phix + v * self.phiy
+        self.lapphi = self.ifft(-self.wv2 * self.phih)
+        lap2phi = self.ifft(self.wv4 * self.phih)
+        diss = -self.nu4w * lap2phi + self.nuw * self.lapphi - self.muw * phi
+        J_diss = -(diss * np.conj(J)).imag
+        L_diss = 0.5 * (diss * np.conj(phi)).real * qpsi
+        divFw = 0.5 * self.hslash * (np.conj(phi) * self.lapphi).imag
+        self.gamma1 = (0.5 * qpsi * divFw).mean() / self.f
+        self.gamma2 = 0.5 * self.hslash * ((np.conj(self.lapphi) * J).real).mean() / self.f
+        self.xi1 = J_diss.mean() / self.f
+        self.xi2 = L_diss.mean() / self.f
+        self.pi = (0.5 * phi.mean() * (qpsi * np.conj(phi)).mean()).imag
+
+    def _calc_icke_niw(self):
+        self.ke_niw = self._calc_ke_niw()
+        self.cke_niw = 0.5 * (np.abs(self.phi.mean()) ** 2)
+        self.ike_niw = self.ke_niw - self.cke_niw
+
+    # ------------------------------------------------------------------ diagnostics registry
+    def _initialize_diagnostics(self):
+        self.diagnostics = dict()
+        self._initialize_kernel_diagnostics()
+        self._initialize_class_diagnostics()
+
+    def _initialize_kernel_diagnostics(self):
+        """Names, order, units as ref niwqg/Kernel.py:718-868."""
+        table = [
+            ('time', 'Time', 'seconds', lambda s: s.t),
+            ('Ke', 'Quasigeostrophic Kinetic Energy, from energy equation', r'm^2 s^{-2}', lambda s: s.Ke),
+            ('Pw', 'NIW Potential Energy, from energy equation', r'm^2 s^{-2}', lambda s: s.Pw),
+            ('Kw', 'NIW Kinetic Energy, from energy equation', r'm^2 s^{-2}', lambda s: s.Kw),
+            ('ke_qg', 'Quasigeostrophic Kinetic Energy', r'm^2 s^{-2}', lambda s: s._calc_ke_qg()),
+            ('ens', 'Quasigeostrophic Potential Enstrophy', r's^{-2}', lambda s: 0.5 * (s.q ** 2).mean()),
+            ('ke_niw', 'Near-inertial Kinetic Energy', r'm^2 s^{-2}', lambda s: s.ke_niw),
+            ('cke_niw', 'Kinetic Energy of Laterally Coherent Near-Inertial Waves', r'm^2 s^{-2}',
+             lambda s: s.cke_niw),
+            ('ike_niw', 'Kinetic Energy of Laterally Incoherent Near-Inertial Waves', r'm^2 s^{-2}',
+             lambda s: s.ike_niw),
+            ('pe_niw', 'Near-inertial Potential Energy', r'm^2 s^{-2}', lambda s: s._calc_pe_niw()),
+            ('conc_niw', 'Correlation between relative vorticity and near-inertial KE', r'unitless',
+             lambda s: s._calc_conc()),
+            ('skew', 'Skewness', r'unitless', lambda s: s._calc_skewness()),
+            ('gamma_r', 'The energy conversion due to refraction', r'$m^2 s^{-3}$', lambda s: s.gamma1),
+            ('gamma_a', 'The energy conversion due to advection', r'$m^2 s^{-3}$', lambda s: s.gamma2),
+            ('xi_r', 'The QG energy generation due to wave dissipation, vorticity', r'$m^2 s^{-3}$',
+             lambda s: s.xi1),
+            ('xi_a', 'The QG energy generation due to wave dissipation, advection', r'$m^2 s^{-3}$',
+             lambda s: s.xi2),
+            ('pi', 'The NIW kinetic energy conversion from coherent to incoherent', r'$m^2 s^{-3}$',
+             lambda s: s.pi),
+            ('ep_phi', 'The hyperviscous dissipation of NIW kinetic energy', r'$m^2 s^{-3}$',
+             lambda s: s._calc_ep_phi()),
+            ('ep_psi', 'The hyperviscous dissipation of QG kinetic energy', r'$m^2 s^{-3}$',
+             lambda s: s._calc_ep_psi()),
+            ('chi_q', 'The hyperviscous dissipation of QG kinetic energy', r'$s^{-3}$', lambda s: s._calc_chi_q()),
+            ('chi_phi', 'The hyperviscous dissipation of NIW potential energy', r'$s^{-3}$',
+             lambda s: s._calc_chi_phi()),
+        ]
+        for name, desc, units, fn in table:
+            add_diagnostic(self, name, description=desc, units=units, types='scalar', function=fn)
+
+    def _initialize_class_diagnostics(self):
+        pass
+
+    def _calc_derived_fields(self):
+        self._calc_kernel_derived_fields()
+        self._calc_class_derived_fields()
+
+    def _calc_kernel_derived_fields(self):
+        self._calc_energy_conversion()
+        self._calc_icke_niw()
+
+    def _calc_class_derived_fields(self):
+        pass

@@ -1,0 +1,250 @@
+"""Barotropic QG model on the half spectrum, on the MI355X stepper.
+
+Drop-in for ``niwqg.QGModel.Model`` with ``passive_scalar=False`` (ref: niwqg/QGModel.py:10-737):
+spectral arrays have shape (ny, nx//2+1), ``fft``/``ifft`` have rfft2/irfft2 semantics.
+"""
+import logging
+
+import numpy as np
+from numpy import pi
+
+from . import _lib
+from .Diagnostics import add_diagnostic, increment_diagnostics
+
+
+class Model(object):
+
+    def __init__(self, nx=128, ny=None, L=5e5, dt=10000., twrite=1000, tswrite=10, tmax=250000.,
+                 use_filter=True, U=.0, nu4=5.e9, nu=0, mu=0, beta=0, passive_scalar=False, nu4c=5.e9,
+                 nuc=0, muc=0, dealias=False, save_to_disk=False, overwrite=True, tsave_snapshots=10,
+                 tdiags=10, path='output/', use_mkl=False, nthreads=1, device=0, budgets=True):
+        # ref: niwqg/QGModel.py:93-139
+        self.nx = nx
+        self.ny = nx
+        self.L = L
+        self.W = L
+        self.dt, self.twrite, self.tswrite, self.tmax, self.tdiags = dt, twrite, tswrite, tmax, tdiags
+        self.passive_scalar = passive_scalar
+        self.dealias = dealias
+        self.U, self.beta, self.nu4, self.nu, self.mu = U, beta, nu4, nu, mu
+        self.nu4c, self.nuc, self.muc = nu4c, nuc, muc
+        self.save_to_disk, self.overwrite, self.tsnaps, self.path = save_to_disk, overwrite, tsave_snapshots, path
+        self.use_filter = use_filter
+        self.use_mkl, self.nthreads = use_mkl, nthreads
+        if passive_scalar:
+            raise NotImplementedError("passive_scalar=True is not on the accelerated path yet (SURVEY 8f, rank 2)")
+        if save_to_disk:
+            raise NotImplementedError("save_to_disk: HDF5 output is outside the accelerated path (SURVEY 8f)")
+        if dealias and not use_filter:
+            raise TypeError("dealias=True: the reference itself fails here (float slice indices, "
+                            "niwqg/QGModel.py:295-296)")
+        self._initialize_logger()
+        self._initialize_grid()
+        self._initialize_filter()
+        self._ctx = _lib.Context(_lib.QG, nx, self.kk, self.ll, self.filtr, dt, U=U, nu=nu, nu4=nu4, mu=mu,
+                                 beta=beta, budgets=budgets, device=device)
+        self._cache, self._user = {}, {}
+        self.t, self.tc = 0, 0
+        self.cflmax = .5
+        self.Ke = 0.0
+        self._initialize_diagnostics()
+
+    def _initialize_logger(self):
+        self.logger = logging.getLogger(__name__)
+        if not self.logger.handlers:
+            h = logging.StreamHandler()
+            h.setFormatter(logging.Formatter('%(levelname)s: %(message)s'))
+            self.logger.addHandler(h)
+        self.logger.setLevel(10)
+        self.logger.propagate = False
+        self.logger.info(' Logger initialized')
+
+    def _initialize_grid(self):
+        """ref: niwqg/QGModel.py:232-269"""
+        self.dk = self.dl = 2. * pi / self.L
+        self.nl = self.ny
+        self.nk = self.nx // 2 + 1
+        self.ll = self.dl * np.append(np.arange(0., self.nx / 2), np.arange(-self.nx / 2, 0.))
+        self.kk = self.dk * np.arange(0., self.nk)
+        self.dx = self.L / self.nx
+        self.dy = self.W / self.ny
+        self.M = self.nx * self.ny
+
+    _LAZY = ("x", "y", "k", "l", "ik", "il", "wv2", "wv", "wv4", "wv2i")
+
+    def __getattr__(self, name):
+        if name in Model._LAZY:
+            d = self.__dict__
+            d["x"], d["y"] = np.meshgrid(np.arange(0.5, self.nx, 1.) / self.nx * self.L,
+                                         np.arange(0.5, self.ny, 1.) / self.ny * self.W)
+            d["k"], d["l"] = np.meshgrid(self.kk, self.ll)
+            d["ik"], d["il"] = 1j * d["k"], 1j * d["l"]
+            d["wv2"] = d["k"] ** 2 + d["l"] ** 2
+            d["wv"] = np.sqrt(d["wv2"])
+            d["wv4"] = d["wv2"] ** 2
+            nz = d["wv2"] != 0.
+            d["wv2i"] = np.zeros_like(d["wv2"])
+            d["wv2i"][nz] = d["wv2"][nz] ** -1
+            return d[name]
+        fields = {"q": _lib.F_Q, "qh": _lib.F_QH, "p": _lib.F_P, "ph": _lib.F_PH, "u": _lib.F_U, "v": _lib.F_V}
+        if name in fields:
+            if name in self._user:
+                return self._user[name]
+            if name not in self._cache:
+                self._cache[name] = self._ctx.field(fields[name])
+            return self._cache[name]
+        raise AttributeError(name)
+
+    def _initialize_filter(self):
+        """ref: niwqg/QGModel.py:283-300"""
+        k, l = self.kk[None, :], self.ll[:, None]
+        if self.use_filter:
+            cphi = 0.65 * pi
+            wvx = np.sqrt((k * self.dx) ** 2. + (l * self.dy) ** 2.)
+            self.filtr = np.exp(-23.6 * (wvx - cphi) ** 4.)
+            self.filtr[wvx <= cphi] = 1.
+            self.logger.info(' Using filter')
+        else:
+            self.filtr = np.ones((self.nl, self.nk))
+            self.logger.info(' No dealiasing; no filter')
+
+    def _dirty(self):
+        self._cache.clear()
+        self._user.clear()
+
+    # --- reference API
+    def fft(self, x):
+        """numpy.fft.rfft2 semantics.  ref: niwqg/QGModel.py:551"""
+        return self._ctx.rfft2(x)
+
+    def ifft(self, x):
+        """numpy.fft.irfft2 semantics.  ref: niwqg/QGModel.py:552"""
+        return self._ctx.irfft2(x)
+
+    def set_q(self, q):
+        """ref: niwqg/QGModel.py:507-520"""
+        self._ctx.set_q(q)
+        self._dirty()
+        self._user["q"] = q
+        self.Ke = self._calc_ke_qg()
+
+    def _invert(self):
+        self._ctx.invert()
+        self._cache.pop("ph", None)
+        self._cache.pop("p", None)
+
+    def jacobian_psi_q(self):
+        """ik F[u q] + il F[v q] on the half spectrum, [0,0] NOT zeroed.  ref: niwqg/QGModel.py:469-481"""
+        f1, f2 = self._ctx.products_uq_vq()
+        return self.ik * f1 + self.il * f2
+
+    def spec_var(self, ph):
+        """ref: niwqg/QGModel.py:611-619"""
+        var_dens = 2. * np.abs(ph) ** 2 / self.M ** 2
+        var_dens[:, 0] *= 0.5
+        var_dens[:, -1] *= 0.5
+        var_dens[0, 0] = 0
+        return var_dens.sum()
+
+    def _step_etdrk4(self):
+        self._ctx.step(1)
+        self._after_steps()
+
+    def _after_steps(self):
+        self._dirty()
+        if self._ctx.budgets_enabled:
+            self.Ke += self._ctx.scalar(_lib.S_KE)
+
+    def _step_forward(self):
+        self._step_etdrk4()
+        increment_diagnostics(self)
+        self._print_status()
+
+    def _quiet_steps(self, n_left):
+        for j in range(n_left):
+            tcb = self.tc + j
+            if (tcb % self.tdiags) == 0 or ((tcb + 1) % self.twrite) == 0:
+                return j
+        return n_left - 1
+
+    def _steps_left(self, cap):
+        t, n = self.t, 0
+        while t < self.tmax and n < cap:
+            t += self.dt
+            n += 1
+        return n
+
+    def run(self):
+        """ref: niwqg/QGModel.py:184-207"""
+        while self.t < self.tmax:
+            quiet = self._quiet_steps(self._steps_left(4096))
+            if quiet > 0:
+                self._ctx.step(quiet)
+                for _ in range(quiet):
+                    self.tc += 1
+                    self.t += self.dt
+                self._after_steps()
+            self._step_forward()
+
+    def run_with_snapshots(self, tsnapstart=0., tsnapint=432000.):
+        tsnapints = np.ceil(tsnapint / self.dt)
+        while self.t < self.tmax:
+            self._step_forward()
+            if self.t >= tsnapstart and (self.tc % tsnapints) == 0:
+                yield self.t
+        return
+
+    def _print_status(self):
+        """ref: niwqg/QGModel.py:554-578"""
+        self.tc += 1
+        self.t += self.dt
+        if (self.tc % self.twrite) == 0:
+            self.ke = self._calc_ke_qg()
+            self.cfl = self._calc_cfl()
+            self.logger.info('Step: %i, Time: %4.3e, P: %4.3e , Ke: %4.3e, CFL: %4.3f',
+                             self.tc, self.t, self.t / self.tmax, self.ke, self.cfl)
+            assert self.cfl < self.cflmax, self.logger.error('CFL condition violated')
+
+    def _calc_ke_qg(self):
+        return self._ctx.scalar(_lib.S_KE_QG)
+
+    def _calc_ens(self):
+        return 0.5 * self.spec_var(self.qh)
+
+    def _calc_ep_psi(self):
+        """ref: niwqg/QGModel.py:588-593"""
+        lap2psi = self.ifft(self.wv4 * self.ph)
+        lapq = self.ifft(-self.wv2 * self.qh)
+        return (self.nu4 * (self.q * lap2psi).mean() - self.nu * (self.p * lapq).mean()
+                + self.mu * (self.p * self.q).mean())
+
+    def _calc_chi_q(self):
+        return -self.nu4 * self.spec_var(self.wv2 * self.qh)
+
+    def _calc_cfl(self):
+        return np.abs(np.hstack([self.u, self.v])).max() * self.dt / self.dx
+
+    def _initialize_diagnostics(self):
+        """ref: niwqg/QGModel.py:632-722 (the passive-scalar entries report zeros, as the reference
+        does when passive_scalar=False, QGModel.py:734-737)"""
+        self.diagnostics = dict()
+        self.C2, self.gradC2, self.cvar, self.Gamma_c = 0., 0., 0., 0.
+        table = [
+            ('time', 'Time', 'seconds', lambda s: s.t),
+            ('ke_qg', 'Quasigeostrophic Kinetic Energy', r'm^2 s^{-2}', lambda s: s._calc_ke_qg()),
+            ('Ke', 'Quasigeostrophic Kinetic Energy, from energy equation', r'm^2 s^{-2}', lambda s: s.Ke),
+            ('ens', 'Quasigeostrophic Potential Enstrophy', r's^{-2}', lambda s: 0.5 * (s.q ** 2).mean()),
+            ('ep_psi', 'The hyperviscous dissipation of QG kinetic energy', r'$m^2 s^{-3}$',
+             lambda s: s._calc_ep_psi()),
+            ('chi_q', 'The hyperviscous dissipation of QG kinetic energy', r'$s^{-3}$', lambda s: s._calc_chi_q()),
+            ('C2', 'Passive tracer variance', r'[scalar]^2', lambda s: s.C2),
+            ('cvar', 'Passive tracer variance, from variance equation', r'[scalar]^2', lambda s: s.cvar),
+            ('gradC2', 'Gradient of Passive tracer variance', r'[scalar]^2 / m^2', lambda s: s.gradC2),
+            ('Gamma_c', 'Rate of generation of passive tracer gradient variance', r'[scalar]^2 / (m^2 s)',
+             lambda s: s.Gamma_c),
+        ]
+        for name, desc, units, fn in table:
+            add_diagnostic(self, name, description=desc, units=units, types='scalar', function=fn)
+
+    def _calc_derived_fields(self):
+        pass

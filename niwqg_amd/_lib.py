@@ -24,10 +24,10 @@ COUPLED, UNCOUPLED, QG = 0, 1, 2
 (F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY) = range(13)
 (S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL) = range(7)
 
-EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_phi", "nq_refresh_grad_phi",
+EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
            "nq_step", "nq_sync", "nq_get_field", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
            "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_get_coeff",
-           "nq_timer_start", "nq_timer_stop", "nq_device_bytes", "nq_stream"]
+           "nq_timer_start", "nq_timer_stop", "nq_profile_enable", "nq_profile_read", "nq_device_bytes", "nq_stream"]
 
 
 class Params(ctypes.Structure):
@@ -74,7 +74,7 @@ def lib():
     L.nq_create.argtypes = [ctypes.POINTER(Params), dp, dp, dp, dp, ctypes.c_int, ctypes.POINTER(vp)]
     L.nq_last_error.argtypes = [vp]
     L.nq_last_error.restype = ctypes.c_char_p
-    for name in ("nq_destroy", "nq_refresh_grad_phi", "nq_sync", "nq_timer_start"):
+    for name in ("nq_destroy", "nq_invert", "nq_refresh_grad_phi", "nq_sync", "nq_timer_start"):
         getattr(L, name).argtypes = [vp]
     for name in ("nq_set_q", "nq_set_phi", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi"):
         getattr(L, name).argtypes = [vp, dp]
@@ -85,6 +85,8 @@ def lib():
     L.nq_get_scalar.argtypes = [vp, ctypes.c_int, dp]
     L.nq_get_coeff.argtypes = [vp, ctypes.c_int, ctypes.c_int, dp]
     L.nq_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.nq_profile_enable.argtypes = [vp, ctypes.c_int]
+    L.nq_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)]
     L.nq_device_bytes.argtypes = [vp]
     L.nq_device_bytes.restype = ctypes.c_longlong
     L.nq_stream.argtypes = [vp]
@@ -119,6 +121,11 @@ class Context:
         if rc != 0:
             raise RuntimeError("nq_create failed (%d): %s" % (rc, self.L.nq_last_error(None).decode()))
         self.h = h
+        self.budgets_enabled = False     # set by the library once in-step budget integrals are built
+
+    def take_budget_increments(self):
+        """Ke, Pw, Kw increments accumulated on the device since the last call (Kernel.py:390-392)."""
+        return tuple(self.scalar(s) for s in (S_KE, S_PW, S_KW))
 
     def _chk(self, rc, what):
         if rc != 0:
@@ -145,6 +152,9 @@ class Context:
         phi = np.ascontiguousarray(phi, dtype=np.complex128)
         assert phi.shape == (self.nx, self.nx)
         self._chk(self.L.nq_set_phi(self.h, _dptr(phi.view(np.float64))), "nq_set_phi")
+
+    def invert(self):
+        self._chk(self.L.nq_invert(self.h), "nq_invert")
 
     def refresh_grad_phi(self):
         self._chk(self.L.nq_refresh_grad_phi(self.h), "nq_refresh_grad_phi")
@@ -226,6 +236,16 @@ class Context:
         ms = ctypes.c_float()
         self._chk(self.L.nq_timer_stop(self.h, ctypes.byref(ms)), "nq_timer_stop")
         return ms.value
+
+    KERNEL_CLASSES = {"x_products": 0, "x_wavepv": 1, "s_q": 2, "s_phi": 3, "s_invert": 4, "y_A": 5}
+
+    def profile_enable(self, kernel_class):
+        self._chk(self.L.nq_profile_enable(self.h, int(kernel_class)), "nq_profile_enable")
+
+    def profile_read(self):
+        n, ms = ctypes.c_int(), ctypes.c_float()
+        self._chk(self.L.nq_profile_read(self.h, ctypes.byref(n), ctypes.byref(ms)), "nq_profile_read")
+        return n.value, ms.value
 
     def device_bytes(self):
         return int(self.L.nq_device_bytes(self.h))

@@ -63,6 +63,9 @@ struct nq_ctx {
   cd *scr_f0 = nullptr, *scr_f1 = nullptr, *scr_h0 = nullptr, *scr_h1 = nullptr;
   double* scr_r = nullptr;
   double scal[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // Ke, Pw, Kw accumulators (host copies)
+  int prof_class = -1;
+  std::vector<hipEvent_t> prof_ev;               // pairs
+  size_t prof_used = 0;
   bool have_q = false, have_phi = false;
 };
 
@@ -219,6 +222,29 @@ static bool plan_for(int N, int* S1, int* S2) {
   return false;
 }
 
+// per-kernel event profiling ---------------------------------------------------------------------
+enum { PK_PRODUCTS = 0, PK_WAVEPV = 1, PK_SQ = 2, PK_SPHI = 3, PK_INVERT = 4, PK_A = 5 };
+struct ProfScope {
+  nq_ctx* c;
+  bool on;
+  ProfScope(nq_ctx* c_, int cls) : c(c_), on(c_->prof_class == cls) {
+    if (!on) return;
+    if (c->prof_used + 2 > c->prof_ev.size()) {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+        c->prof_ev.push_back(e);
+      }
+    }
+    (void)hipEventRecord(c->prof_ev[c->prof_used], c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(c->prof_ev[c->prof_used + 1], c->stream);
+    c->prof_used += 2;
+  }
+};
+
 // generic launches -----------------------------------------------------------------------------
 template <int N>
 static void launch_x_c2c_n(nq_ctx* c, bool inv, const cd* in, cd* out, int pin, int pout, int nrows, double scale, int mul_ik) {
@@ -258,6 +284,7 @@ static void launch_A_s(nq_ctx* c, bool inv, const ArrayList& al, int n, int maxw
 }
 // A sub-pass on a list of arrays; `half[i]` selects half-spectrum geometry
 static void launch_A(nq_ctx* c, bool inv, std::initializer_list<cd*> arrs, bool half) {
+  ProfScope ps(c, PK_A);
   ArrayList al;
   int n = 0, maxw = 0;
   for (cd* a : arrs) {
@@ -319,6 +346,7 @@ static void inv2d_half(nq_ctx* c, const cd* spec, double* phys, cd* tmp_h) {
 
 // fused-stage launches ----------------------------------------------------------------------------
 static void launch_wavepv(nq_ctx* c) {
+  ProfScope ps(c, PK_WAVEPV);
   switch (c->N) {
 #define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mphi, c->Mphiy, c->Ma, c->Mb, c->Ph, c->tw, c->kk); } break;
     NQ_FOR_SIZES(CASE_)
@@ -337,6 +365,7 @@ static void launch_products_m(nq_ctx* c) {
   }
 }
 static void launch_products(nq_ctx* c) {
+  ProfScope ps(c, PK_PRODUCTS);
   if (c->p.model == NQ_MODEL_COUPLED) launch_products_m<MODE_COUPLED>(c);
   else if (c->p.model == NQ_MODEL_UNCOUPLED) launch_products_m<MODE_UNCOUPLED>(c);
   else launch_products_m<MODE_QG>(c);
@@ -390,11 +419,13 @@ static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux) {
   }
 
 static void launch_sq(nq_ctx* c, const EtdArrays& ea, int stage) {
+  ProfScope ps(c, PK_SQ);
 #define CALL_(s) launch_sq_s<s>(c, ea, stage)
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
 static void launch_sphi(nq_ctx* c, const EtdArrays& ea, int stage) {
+  ProfScope ps(c, PK_SPHI);
 #define CALL_(s) launch_sphi_s<s>(c, ea, stage)
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
@@ -405,6 +436,7 @@ static void launch_emit_phi(nq_ctx* c, const cd* phih) {
 #undef CALL_
 }
 static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux) {
+  ProfScope ps(c, PK_INVERT);
   if (c->p.model == NQ_MODEL_COUPLED) {
 #define CALL_(s) launch_invert_sm<s, MODE_COUPLED>(c, qh, store_aux)
     NQ_S1_SWITCH(c, CALL_)
@@ -561,6 +593,7 @@ int nq_destroy(nq_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   for (void* p : c->allocs) hipFree(p);
+  for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -575,6 +608,28 @@ int nq_sync(nq_ctx* c) {
   if (!c) return -1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int nq_profile_enable(nq_ctx* c, int kernel_class) {
+  if (!c) return -1;
+  c->prof_class = kernel_class;
+  c->prof_used = 0;
+  return 0;
+}
+int nq_profile_read(nq_ctx* c, int* launches, float* total_ms) {
+  if (!c || !launches || !total_ms) return -1;
+  int rc = nq_sync(c);
+  if (rc) return rc;
+  float tot = 0.f;
+  for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]));
+    tot += ms;
+  }
+  *launches = (int)(c->prof_used / 2);
+  *total_ms = tot;
+  c->prof_used = 0;
   return 0;
 }
 
@@ -614,6 +669,13 @@ int nq_set_phi(nq_ctx* c, const double* phi_host) {
   c->have_phi = true;
   int rc = nq_refresh_grad_phi(c);
   if (rc) return rc;
+  return nq_sync(c);
+}
+
+int nq_invert(nq_ctx* c) {
+  if (!c) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  do_invert(c, c->q.y[c->q.cur], true);
   return nq_sync(c);
 }
 

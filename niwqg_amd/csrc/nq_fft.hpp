@@ -118,6 +118,44 @@ template <bool INV> struct Dft<16, INV> {
   }
 };
 
+// ---- stage twiddles ----------------------------------------------------------------------------
+// v[u] *= w^u, u = 1..R-1, with w = tw[base].  Only w^1, w^4 (and w^8 for radix 16) are fetched from the
+// table; the others are products of at most two fetched/derived values (<= 2 roundings deep), which
+// keeps 15 gathered 16-byte loads and 60 VGPRs of twiddles per butterfly out of the inner loop.
+template <int R, bool INV>
+__device__ __forceinline__ void twiddle_apply(cd (&v)[R], const cd* __restrict__ tw, int base) {
+  cd w1 = tw[base];
+  if (INV) w1.y = -w1.y;
+  v[1] = cmul(v[1], w1);
+  if constexpr (R >= 4) {
+    const cd w2 = cmul(w1, w1);
+    const cd w3 = cmul(w2, w1);
+    v[2] = cmul(v[2], w2);
+    v[3] = cmul(v[3], w3);
+    if constexpr (R >= 8) {
+      cd w4 = tw[4 * base];
+      if (INV) w4.y = -w4.y;
+      v[4] = cmul(v[4], w4);
+      v[5] = cmul(v[5], cmul(w4, w1));
+      v[6] = cmul(v[6], cmul(w4, w2));
+      v[7] = cmul(v[7], cmul(w4, w3));
+      if constexpr (R >= 16) {
+        cd w8 = tw[8 * base];
+        if (INV) w8.y = -w8.y;
+        const cd w12 = cmul(w8, w4);
+        v[8] = cmul(v[8], w8);
+        v[9] = cmul(v[9], cmul(w8, w1));
+        v[10] = cmul(v[10], cmul(w8, w2));
+        v[11] = cmul(v[11], cmul(w8, w3));
+        v[12] = cmul(v[12], w12);
+        v[13] = cmul(v[13], cmul(w12, w1));
+        v[14] = cmul(v[14], cmul(w12, w2));
+        v[15] = cmul(v[15], cmul(w12, w3));
+      }
+    }
+  }
+}
+
 // ---- radix plan -----------------------------------------------------------------------------
 __host__ __device__ constexpr int nq_min(int a, int b) { return a < b ? a : b; }
 __host__ __device__ constexpr int plan_radix(int N, int P, int stage) {
@@ -171,14 +209,7 @@ struct WgFft {
       for (int u = 0; u < R; ++u) v[u] = r[b + u * NB];
       const int jj = j + b * T;
       const int jr = jj % NS;
-      if (NS > 1) {
-        const int base = jr * (N / (NS * R)) * tw_step;
-#pragma unroll
-        for (int u = 1; u < R; ++u) {
-          cd w = tw[u * base];
-          v[u] = INV ? cmulc(v[u], w) : cmul(v[u], w);
-        }
-      }
+      if (NS > 1) twiddle_apply<R, INV>(v, tw, jr * (N / (NS * R)) * tw_step);
       Dft<R, INV>::run(v);
       if (LAST) {
 #pragma unroll

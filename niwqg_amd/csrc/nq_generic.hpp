@@ -24,11 +24,19 @@ template <int S> struct YPlan {
   static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cd);
 };
 
+#ifndef NQ_XP
+#define NQ_XP 16
+#endif
 template <int N> struct XPlan {
-  static constexpr int P = (N >= 128) ? 16 : 8;
+  static constexpr int P = (N >= 128) ? NQ_XP : 8;
   static constexpr int T = N / P;
   static constexpr int C = (T >= 64) ? 1 : 64 / T;     // rows per workgroup (>= one wave)
   static constexpr int THREADS = C * T;
+#ifndef NQ_XWG
+#define NQ_XWG 2
+#endif
+  // workgroups per CU the fused row kernels are compiled for (LDS allows 2 at N = 4096)
+  static constexpr int MIN_WAVES = (THREADS * NQ_XWG + 255) / 256;
   typedef WgFft<N, P, C, true> F;
   static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cd) + 16 * C;   // + per-row scratch words
 };

@@ -19,6 +19,15 @@ namespace nq {
 
 enum { MODE_COUPLED = 0, MODE_UNCOUPLED = 1, MODE_QG = 2 };
 
+// Keeps hipcc from hoisting the next phase's global loads (and interleaving independent FFTs) across a
+// phase boundary of the fused row kernels: that inflates the live set past 256 VGPRs and spills.
+#define NQ_PHASE_FENCE()                      \
+  do {                                        \
+    __builtin_amdgcn_sched_barrier(0);        \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+
 // ---- helpers for the row kernels ----------------------------------------------------------
 // Build Z = A + i*B at full-row position kx from two half-spectrum rows (Hermitian completion);
 // `a_mul_ik` multiplies B by i*kk first (for v = ifft(ik psi)).  Self-mirrored entries kx = 0, N/2
@@ -66,35 +75,48 @@ __device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* 
 }
 
 // ---- X1: wave potential-vorticity sources (CoupledModel._invert, ref CoupledModel.py:59-88) ------
+// Register plan (P = 16: a complex row slice is 64 VGPRs, a real one 32): the peak is
+// a(32) + phix(64) + working(64); everything is ordered so that this stays below the 256-VGPR budget
+// of two workgroups per CU.
 template <int N>
-__global__ void __launch_bounds__(XPlan<N>::THREADS)
+__global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
 k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __restrict__ Ma, cd* __restrict__ Mb,
            int Ph, const cd* __restrict__ tw, const double* __restrict__ kk) {
   typedef XPlan<N> X;
   constexpr int P = X::P, T = X::T;
   const int j = threadIdx.x % T, c = threadIdx.x / T;
   const size_t row = (size_t)blockIdx.x * X::C + c;
+  const cd* __restrict__ rphi = Mphi + row * N;
+  const cd* __restrict__ rphiy = Mphiy + row * N;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
-  cd phi[P], gx[P], z[P];
+  cd w[P], gx[P];
+  double a[P];
 #pragma unroll
-  for (int t = 0; t < P; ++t) {
-    const int kx = j + t * T;
-    phi[t] = Mphi[row * N + kx];
-    gx[t] = cscale(cmul_i(phi[t]), kk[kx]);
-  }
-  X::F::template run<true>(phi, j, c, lds, tw, 1);
-  X::F::template run<true>(gx, j, c, lds, tw, 1);
-#pragma unroll
-  for (int t = 0; t < P; ++t) z[t].x = phi[t].x * phi[t].x + phi[t].y * phi[t].y;
-#pragma unroll
-  for (int t = 0; t < P; ++t) phi[t] = Mphiy[row * N + j + t * T];        // reuse registers for phiy
-  X::F::template run<true>(phi, j, c, lds, tw, 1);
+  for (int t = 0; t < P; ++t) w[t] = rphi[j + t * T];
+  NQ_PHASE_FENCE();
+  X::F::template run<true>(w, j, c, lds, tw, 1);
   double ma = 0.0, mb = 0.0;
 #pragma unroll
   for (int t = 0; t < P; ++t) {
-    z[t].y = -2.0 * (gx[t].x * phi[t].y - gx[t].y * phi[t].x);
-    ma = fmax(ma, z[t].x);
-    mb = fmax(mb, fabs(z[t].y));
+    a[t] = w[t].x * w[t].x + w[t].y * w[t].y;
+    ma = fmax(ma, a[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int kx = j + t * T;
+    gx[t] = cscale(cmul_i(rphi[kx]), kk[kx]);
+  }
+  NQ_PHASE_FENCE();
+  X::F::template run<true>(gx, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) w[t] = rphiy[j + t * T];
+  NQ_PHASE_FENCE();
+  X::F::template run<true>(w, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const double b = -2.0 * (gx[t].x * w[t].y - gx[t].y * w[t].x);
+    mb = fmax(mb, fabs(b));
+    w[t] = cmake(a[t], b);
   }
   // The two real fields share one complex transform; |phi|^2 is typically 1e8 times larger than
   // J(phi*,phi), so the second is rescaled per row by a power of two (exactly undone after the
@@ -115,16 +137,19 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
   e = e > 900 ? 900 : (e < -900 ? -900 : e);
   const double sb = ldexp(1.0, e), isb = ldexp(1.0, -e);
 #pragma unroll
-  for (int t = 0; t < P; ++t) z[t].y *= sb;
-  X::F::template run<false>(z, j, c, lds, tw, 1);
-  unpack_pair_store<N, P, T, typename X::F>(z, j, c, lds, Ma + row * Ph, Mb + row * Ph, isb);
+  for (int t = 0; t < P; ++t) w[t].y *= sb;
+  NQ_PHASE_FENCE();
+  X::F::template run<false>(w, j, c, lds, tw, 1);
+  NQ_PHASE_FENCE();
+  unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, Ma + row * Ph, Mb + row * Ph, isb);
 }
 
 // ---- X2: all nonlinear products of one stage ------------------------------------------------
 // ref Kernel.py:471-486 (jacobian_psi_q), :457-469 (jacobian_psi_phi), :332 (refraction).
 // MODE_QG: only Muq, Mvq.  MODE_UNCOUPLED: q_psi = q, phix/phiy from the (possibly stale) Mgx/Mgy.
+// Register plan: u, v, q_psi are kept as reals (32 VGPRs each); peak = u+v+q_psi+working = 160.
 template <int N, int MODE>
-__global__ void __launch_bounds__(XPlan<N>::THREADS)
+__global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
 k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __restrict__ Mq,
              const cd* __restrict__ Mqw, const cd* __restrict__ Mphi, const cd* __restrict__ Mgx,
              const cd* __restrict__ Mgy, cd* __restrict__ Muq, cd* __restrict__ Mvq, cd* __restrict__ Mj,
@@ -134,12 +159,18 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
   const int j = threadIdx.x % T, c = threadIdx.x / T;
   const size_t row = (size_t)blockIdx.x * X::C + c;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
-  cd uv[P], w[P];
-  double qpsi[P];
+  cd w[P];
+  double u[P], v[P], qpsi[P];
   // (u, v) = ifft of (-il psi, ik psi): Mu already holds T_y^-1[-il psi], Mp holds T_y^-1[psi]
 #pragma unroll
-  for (int t = 0; t < P; ++t) uv[t] = pack_pair<N>(Mu + row * Ph, Mp + row * Ph, j + t * T, kk, true, v_zero_nyq);
-  X::F::template run<true>(uv, j, c, lds, tw, 1);
+  for (int t = 0; t < P; ++t) w[t] = pack_pair<N>(Mu + row * Ph, Mp + row * Ph, j + t * T, kk, true, v_zero_nyq);
+  NQ_PHASE_FENCE();
+  X::F::template run<true>(w, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    u[t] = w[t].x;
+    v[t] = w[t].y;
+  }
   // (q, qw)
 #pragma unroll
   for (int t = 0; t < P; ++t) {
@@ -155,43 +186,66 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
       w[t] = a;
     }
   }
+  NQ_PHASE_FENCE();
   X::F::template run<true>(w, j, c, lds, tw, 1);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const double q = w[t].x;
     qpsi[t] = (MODE == MODE_COUPLED) ? q - w[t].y : q;
-    w[t] = cmake(uv[t].x * q, uv[t].y * q);                  // u q + i v q
+    w[t] = cmake(u[t] * q, v[t] * q);                        // u q + i v q
   }
+  NQ_PHASE_FENCE();
   X::F::template run<false>(w, j, c, lds, tw, 1);
+  NQ_PHASE_FENCE();
   unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, Muq + row * Ph, Mvq + row * Ph);
   if (MODE == MODE_QG) return;
   // refraction source phi * q_psi
+  {
+    const cd* __restrict__ rp = Mphi + row * N;
 #pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = Mphi[row * N + j + t * T];
+    for (int t = 0; t < P; ++t) w[t] = rp[j + t * T];
+  }
+  NQ_PHASE_FENCE();
   X::F::template run<true>(w, j, c, lds, tw, 1);
 #pragma unroll
   for (int t = 0; t < P; ++t) w[t] = cscale(w[t], qpsi[t]);
+  NQ_PHASE_FENCE();
   X::F::template run<false>(w, j, c, lds, tw, 1);
+  {
+    cd* __restrict__ rp = Mr + row * N;
 #pragma unroll
-  for (int t = 0; t < P; ++t) Mr[row * N + j + t * T] = w[t];
-  // advection u phix + v phiy
-  cd acc[P];
-#pragma unroll
-  for (int t = 0; t < P; ++t) {
-    const int kx = j + t * T;
-    w[t] = cscale(cmul_i(Mgx[row * N + kx]), kk[kx]);
+    for (int t = 0; t < P; ++t) rp[j + t * T] = w[t];
   }
+  // advection u phix + v phiy: w <- u*phix, then w += v*phiy with phiy in w2
+  {
+    const cd* __restrict__ rp = Mgx + row * N;
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const int kx = j + t * T;
+      w[t] = cscale(cmul_i(rp[kx]), kk[kx]);
+    }
+  }
+  NQ_PHASE_FENCE();
   X::F::template run<true>(w, j, c, lds, tw, 1);
 #pragma unroll
-  for (int t = 0; t < P; ++t) acc[t] = cscale(w[t], uv[t].x);
+  for (int t = 0; t < P; ++t) w[t] = cscale(w[t], u[t]);
+  cd w2[P];
+  {
+    const cd* __restrict__ rp = Mgy + row * N;
 #pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = Mgy[row * N + j + t * T];
-  X::F::template run<true>(w, j, c, lds, tw, 1);
+    for (int t = 0; t < P; ++t) w2[t] = rp[j + t * T];
+  }
+  NQ_PHASE_FENCE();
+  X::F::template run<true>(w2, j, c, lds, tw, 1);
 #pragma unroll
-  for (int t = 0; t < P; ++t) acc[t] = cmake(acc[t].x + w[t].x * uv[t].y, acc[t].y + w[t].y * uv[t].y);
-  X::F::template run<false>(acc, j, c, lds, tw, 1);
+  for (int t = 0; t < P; ++t) w[t] = cmake(w[t].x + w2[t].x * v[t], w[t].y + w2[t].y * v[t]);
+  NQ_PHASE_FENCE();
+  X::F::template run<false>(w, j, c, lds, tw, 1);
+  {
+    cd* __restrict__ rp = Mj + row * N;
 #pragma unroll
-  for (int t = 0; t < P; ++t) Mj[row * N + j + t * T] = acc[t];
+    for (int t = 0; t < P; ++t) rp[j + t * T] = w[t];
+  }
 }
 
 // ---- ETDRK4 stage update of one spectral element -----------------------------------------------

@@ -43,7 +43,8 @@ enum {
 
 /* scalar ids for nq_get_scalar */
 enum {
-  NQ_S_KE = 0, NQ_S_PW = 1, NQ_S_KW = 2,   /* budget accumulators Ke, Pw, Kw       Kernel.py:390-392 */
+  NQ_S_KE = 0, NQ_S_PW = 1, NQ_S_KW = 2,   /* INCREMENT of the budget accumulators Ke, Pw, Kw since the last
+                                              read (reading resets it)             Kernel.py:390-392 */
   NQ_S_KE_QG = 3,                          /* _calc_ke_qg()                        Kernel.py:600-602 */
   NQ_S_KE_NIW = 4,                         /* _calc_ke_niw()                       Kernel.py:604-606 */
   NQ_S_PE_NIW = 5,                         /* _calc_pe_niw() (no side effect here) Kernel.py:608-611 */

@@ -190,6 +190,8 @@ class Kernel(object):
         self._ctx.set_q(q)
         self._dirty()
         self._user["q"] = q
+        if self._ctx.budgets_enabled:
+            self._ctx.take_budget_increments()      # drop increments that belong to the old state
         self.Ke = self.ke = self._calc_ke_qg()
 
     def set_phi(self, phi):

@@ -126,6 +126,8 @@ class Model(object):
         self._ctx.set_q(q)
         self._dirty()
         self._user["q"] = q
+        if self._ctx.budgets_enabled:
+            self._ctx.scalar(_lib.S_KE)             # drop increments that belong to the old state
         self.Ke = self._calc_ke_qg()
 
     def _invert(self):

@@ -121,7 +121,7 @@ class Context:
         if rc != 0:
             raise RuntimeError("nq_create failed (%d): %s" % (rc, self.L.nq_last_error(None).decode()))
         self.h = h
-        self.budgets_enabled = False     # set by the library once in-step budget integrals are built
+        self.budgets_enabled = bool(budgets)
 
     def take_budget_increments(self):
         """Ke, Pw, Kw increments accumulated on the device since the last call (Kernel.py:390-392)."""

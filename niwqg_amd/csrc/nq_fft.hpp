@@ -216,14 +216,31 @@ struct WgFft {
         for (int u = 0; u < R; ++u) r[b + u * NB] = v[u];
       } else {
         const int pos = (jj / NS) * (NS * R) + jr;
+        // padded index of pos + u*NS is affine in u whenever NS % 16 == 0, or NS == 1 with R == 16
+        // (pos is then a multiple of 16); saying so lets the compiler use one address register plus
+        // immediate offsets instead of R separately computed addresses.
+        constexpr bool AFFINE = (NS % 16 == 0) || (NS == 1 && R == 16);
+        if constexpr (AFFINE) {
+          constexpr int STRIDE = (NS == 1) ? 1 : NS + NS / 16;
+          cd* dst = lds + lds_index(pos, c);
 #pragma unroll
-        for (int u = 0; u < R; ++u) lds[lds_index(pos + u * NS, c)] = v[u];
+          for (int u = 0; u < R; ++u) dst[(LINE_MAJOR ? 1 : C) * u * STRIDE] = v[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < R; ++u) lds[lds_index(pos + u * NS, c)] = v[u];
+        }
       }
     }
     if (!LAST) {
       __syncthreads();
+      if constexpr (T % 16 == 0) {
+        const cd* src = lds + lds_index(j, c);
 #pragma unroll
-      for (int t = 0; t < P; ++t) r[t] = lds[lds_index(j + t * T, c)];
+        for (int t = 0; t < P; ++t) r[t] = src[(LINE_MAJOR ? 1 : C) * t * (T + T / 16)];
+      } else {
+#pragma unroll
+        for (int t = 0; t < P; ++t) r[t] = lds[lds_index(j + t * T, c)];
+      }
       __syncthreads();
     }
   }

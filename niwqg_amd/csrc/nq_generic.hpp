@@ -21,7 +21,7 @@ template <int S> struct YPlan {
   static constexpr int T = S / P;
   static constexpr int THREADS = CL * T;
   typedef WgFft<S, P, CL, false> F;
-  static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cd);
+  static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cd) + 512;   // + reduction scratch
 };
 
 #ifndef NQ_XP
@@ -38,10 +38,43 @@ template <int N> struct XPlan {
   // workgroups per CU the fused row kernels are compiled for (LDS allows 2 at N = 4096)
   static constexpr int MIN_WAVES = (THREADS * NQ_XWG + 255) / 256;
   typedef WgFft<N, P, C, true> F;
-  static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cd) + 16 * C;   // + per-row scratch words
+  static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cd) + 16 * C + 512;   // + per-row words + reduction scratch
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char nq_smem[];
+
+// Sum NV per-thread values over the workgroup and let thread 0 store them at dst[0..NV) (one slot per
+// workgroup: deterministic, no atomics; a later kernel adds the slots up).  `scratch` = 512 B of LDS.
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&vals)[NV], double* scratch, double* __restrict__ dst) {
+  static_assert(NV <= 4, "scratch holds 16 waves x 4 values");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int live = (int)blockDim.x - (wave << 6);        // lanes of this wave that exist (blocks of 32)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double x = vals[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double y = __shfl_down(x, off, 64);
+      if (lane + off < live) x += y;
+    }
+    vals[i] = x;
+  }
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = vals[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double x = 0.0;
+      for (int w = 0; w < nw; ++w) x += scratch[w * NV + i];
+      dst[i] = x;
+    }
+  }
+}
 
 // ---------------------------------------------------------------- x direction, generic
 // mode 0: complex in (pitch_in) -> complex out; mode 1: multiply input by i*kk[kx] first

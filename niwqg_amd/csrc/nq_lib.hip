@@ -62,7 +62,14 @@ struct nq_ctx {
   // scratch for the generic transforms / downloads
   cd *scr_f0 = nullptr, *scr_f1 = nullptr, *scr_h0 = nullptr, *scr_h1 = nullptr;
   double* scr_r = nullptr;
-  double scal[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // Ke, Pw, Kw accumulators (host copies)
+  // in-step budget integrals (ref Kernel.py:319-322, :390-392)
+  bool bud = false, need_diss = false;
+  cd *Mlap = nullptr, *Mdiss = nullptr;
+  int nwx = 0, nww = 0, nwq = 0;                  // workgroups of the three kernels that emit partial sums
+  double *partX = nullptr, *partW = nullptr, *partQ = nullptr;   // [4 stages][workgroups][2 | 6 | 3]
+  double *part0W = nullptr, *part0Q = nullptr;    // partials of set_phi / set_q / nq_invert
+  double *carryW = nullptr, *carryQ = nullptr;    // spectral sums of the state at the start of the next step
+  double *gradS1 = nullptr, *acc = nullptr;       // stale-aware sum wv2|phih_grad|^2 ; Ke,Pw,Kw increments
   int prof_class = -1;
   std::vector<hipEvent_t> prof_ev;               // pairs
   size_t prof_used = 0;
@@ -211,6 +218,98 @@ __global__ void k_reduce_real_max(const double* __restrict__ a, size_t n, double
   if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(sh[0]));
 }
 
+// budget bookkeeping ----------------------------------------------------------------------------
+struct BudgetAcc {
+  int model, nwx, nww, nwq;
+  const double *partX, *partW, *partQ;
+  double *carryW, *carryQ, *gradS1, *acc;
+  double dt, f, hslash, kappa2, nu, nu4, mu, nuw, nu4w, muw, M;
+};
+
+__device__ double block_total(const double* __restrict__ part, int n, int stride, double* sh) {
+  double x = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) x += part[(size_t)i * stride];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+  __syncthreads();
+  double tot = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += sh[w];
+  return tot;
+}
+
+// sums workgroup partials of one emitter into dst[0..nq)
+__global__ void k_reduce_partials(const double* __restrict__ part, int nwg, int stride, int nq, double* dst) {
+  __shared__ double sh[16];
+  for (int q = 0; q < nq; ++q) {
+    const double t = block_total(part + q, nwg, stride, sh);
+    if (threadIdx.x == 0) dst[q] = t;
+  }
+}
+
+// One ETDRK4 step's worth of budget rates -> Ke, Pw, Kw increments (ref Kernel.py:319-322, :390-392;
+// QGModel.py:355-407).  Slot s of the spectral sums = state at the start of stage s.
+__global__ void k_budget_accumulate(BudgetAcc b) {
+  __shared__ double sh[16];
+  __shared__ double sw[5][4], sj[4][2], sq[5][3], sx[4][2];
+  const bool qg = b.model == NQ_MODEL_QG;
+  for (int s = 0; s < 4; ++s) {
+    for (int q = 0; q < 3; ++q) {
+      const double t = block_total(b.partQ + (size_t)s * b.nwq * 3 + q, b.nwq, 3, sh);
+      if (threadIdx.x == 0) sq[qg ? s : s + 1][q] = t;
+    }
+    if (!qg) {
+      for (int q = 0; q < 6; ++q) {
+        const double t = block_total(b.partW + (size_t)s * b.nww * 6 + q, b.nww, 6, sh);
+        if (threadIdx.x == 0) {
+          if (q < 4) sw[s + 1][q] = t;
+          else sj[s][q - 4] = t;
+        }
+      }
+      for (int q = 0; q < 2; ++q) {
+        const double t = block_total(b.partX + (size_t)s * b.nwx * 2 + q, b.nwx, 2, sh);
+        if (threadIdx.x == 0) sx[s][q] = t;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double M = b.M, M2 = b.M * b.M;
+  if (!qg) {
+    for (int q = 0; q < 3; ++q) sq[0][q] = b.carryQ[q];
+    for (int q = 0; q < 4; ++q) sw[0][q] = b.carryW[q];
+  }
+  double K = 0.0, Pw = 0.0, A = 0.0;
+  const double wgt[4] = {1.0, 2.0, 2.0, 1.0};
+  for (int s = 0; s < 4; ++s) {
+    const double ep_psi = (b.nu4 * sq[s][0] + b.nu * sq[s][1] + b.mu * sq[s][2]) / M2;
+    double k = ep_psi, p = 0.0, a = 0.0;
+    if (!qg) {
+      const double lap2 = sw[s][2] / M2, glap2 = sw[s][3] / M2, phi2 = sw[s][0] / M2;
+      const double grad2 = ((b.model == NQ_MODEL_COUPLED) ? sw[s][1] : b.gradS1[0]) / M2;
+      const double g1 = 0.25 * b.hslash * (sx[s][0] / M) / b.f;
+      const double g2 = 0.5 * b.hslash * (sj[s][0] / M2) / b.f;
+      const double x1 = -(sj[s][1] / M2) / b.f;
+      const double x2 = 0.5 * (sx[s][1] / M) / b.f;
+      const double chi = (-0.5 * b.nu4w * glap2 - 0.5 * b.nuw * lap2 - 0.5 * b.muw * grad2) / b.kappa2;
+      a = -b.nu4w * lap2 - b.nuw * grad2 - b.muw * phi2;
+      k = -(g1 + g2) + (x1 + x2) + ep_psi;
+      p = g1 + g2 + chi;
+    }
+    K += wgt[s] * k;
+    Pw += wgt[s] * p;
+    A += wgt[s] * a;
+  }
+  b.acc[0] += b.dt * K / 6.0;
+  b.acc[1] += b.dt * Pw / 6.0;
+  b.acc[2] += b.dt * A / 6.0;
+  if (!qg) {
+    for (int q = 0; q < 3; ++q) b.carryQ[q] = sq[4][q];
+    for (int q = 0; q < 4; ++q) b.carryW[q] = sw[4][q];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // size dispatch
 #define NQ_FOR_SIZES(M) M(64, 8, 8) M(128, 8, 16) M(256, 16, 16) M(512, 16, 32) M(1024, 32, 32) M(2048, 32, 64) M(4096, 64, 64) M(8192, 64, 128)
@@ -353,22 +452,30 @@ static void launch_wavepv(nq_ctx* c) {
 #undef CASE_
   }
 }
-template <int MODE>
-static void launch_products_m(nq_ctx* c) {
+template <int MODE, bool BUD>
+static void launch_products_mb(nq_ctx* c, int stage) {
   const cd* gx = (MODE == MODE_UNCOUPLED) ? c->Mgx : c->Mphi;
   const cd* gy = (MODE == MODE_UNCOUPLED) ? c->Mgy : c->Mphiy;
   const int vz = c->kernel_family ? 1 : 0;
+  BudgetX bx;
+  bx.Mlap = c->Mlap;
+  bx.Mdiss = c->need_diss ? c->Mdiss : nullptr;
+  bx.nuw = c->p.nuw;
+  bx.muw = c->p.muw;
+  bx.part = BUD ? c->partX + (size_t)stage * c->nwx * 2 : nullptr;
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mu, c->Mp, c->Mq, c->Mqw, c->Mphi, gx, gy, c->Muq, c->Mvq, c->Mj, c->Mr, c->Ph, c->tw, c->kk, vz); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE, BUD>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mu, c->Mp, c->Mq, c->Mqw, c->Mphi, gx, gy, c->Muq, c->Mvq, c->Mj, c->Mr, c->Ph, c->tw, c->kk, vz, bx); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
 }
-static void launch_products(nq_ctx* c) {
+// stage < 0: no budget sums (API calls outside a step)
+static void launch_products(nq_ctx* c, int stage = -1) {
   ProfScope ps(c, PK_PRODUCTS);
-  if (c->p.model == NQ_MODEL_COUPLED) launch_products_m<MODE_COUPLED>(c);
-  else if (c->p.model == NQ_MODEL_UNCOUPLED) launch_products_m<MODE_UNCOUPLED>(c);
-  else launch_products_m<MODE_QG>(c);
+  const bool b = c->bud && stage >= 0;
+  if (c->p.model == NQ_MODEL_COUPLED) { if (b) launch_products_mb<MODE_COUPLED, true>(c, stage); else launch_products_mb<MODE_COUPLED, false>(c, stage); }
+  else if (c->p.model == NQ_MODEL_UNCOUPLED) { if (b) launch_products_mb<MODE_UNCOUPLED, true>(c, stage); else launch_products_mb<MODE_UNCOUPLED, false>(c, stage); }
+  else launch_products_mb<MODE_QG, false>(c, stage);
 }
 
 static EtdArrays etd_arrays(EqState& e, int stage, int* out_slot) {
@@ -395,20 +502,33 @@ static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage) {
   typedef YPlan<S> Y;
   hipLaunchKernelGGL((k_s_q<S>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Muq, c->Mvq, ea, stage, c->Wh, c->Ph, c->S2, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1);
 }
+static BudgetW budget_w(nq_ctx* c, double* part, const cd* y_start) {
+  BudgetW bw;
+  bw.part = c->bud ? part : nullptr;
+  bw.y_start = y_start;
+  bw.Hlap = c->Mlap;
+  bw.Hdiss = c->need_diss ? c->Mdiss : nullptr;
+  bw.nu4w = c->p.nu4w;
+  bw.nuw = c->p.nuw;
+  bw.muw = c->p.muw;
+  return bw;
+}
 template <int S>
-static void launch_sphi_s(nq_ctx* c, const EtdArrays& ea, int stage) {
+static void launch_sphi_s(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_start) {
   typedef YPlan<S> Y;
-  hipLaunchKernelGGL((k_s_phi<S>), dim3(c->N / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Mj, c->Mr, ea, stage, c->S2, c->Mphi, c->Mphiy, 1.0 / ((double)c->N * c->N), c->ll, c->tw, 1);
+  BudgetW bw = budget_w(c, c->partW + (size_t)stage * c->nww * 6, y_start);
+  hipLaunchKernelGGL((k_s_phi<S>), dim3(c->N / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Mj, c->Mr, ea, stage, c->S2, c->Mphi, c->Mphiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
 template <int S>
 static void launch_emit_phi_s(nq_ctx* c, const cd* phih) {
   typedef YPlan<S> Y;
-  hipLaunchKernelGGL((k_s_emit_phi<S>), dim3(c->N / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, phih, c->S2, c->Mphi, c->Mphiy, 1.0 / ((double)c->N * c->N), c->ll, c->tw, 1);
+  BudgetW bw = budget_w(c, c->part0W, phih);
+  hipLaunchKernelGGL((k_s_emit_phi<S>), dim3(c->N / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, phih, c->S2, c->Mphi, c->Mphiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
 template <int S, int MODE>
-static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux) {
+static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud) {
   typedef YPlan<S> Y;
-  hipLaunchKernelGGL((k_s_invert<S, MODE>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Ma, c->Mb, qh, c->filt_h, c->Mu, c->Mp, c->Mq, c->Mqw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, c->Wh, c->Ph, c->S2, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1);
+  hipLaunchKernelGGL((k_s_invert<S, MODE>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Ma, c->Mb, qh, c->filt_h, c->Mu, c->Mp, c->Mq, c->Mqw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, c->Wh, c->Ph, c->S2, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1, c->bud ? part : nullptr, q_bud);
 }
 #define NQ_S1_SWITCH(c, CALL)         \
   switch ((c)->S1) {                  \
@@ -424,9 +544,9 @@ static void launch_sq(nq_ctx* c, const EtdArrays& ea, int stage) {
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
-static void launch_sphi(nq_ctx* c, const EtdArrays& ea, int stage) {
+static void launch_sphi(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_start) {
   ProfScope ps(c, PK_SPHI);
-#define CALL_(s) launch_sphi_s<s>(c, ea, stage)
+#define CALL_(s) launch_sphi_s<s>(c, ea, stage, y_start)
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
@@ -435,46 +555,76 @@ static void launch_emit_phi(nq_ctx* c, const cd* phih) {
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
-static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux) {
+static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud) {
   ProfScope ps(c, PK_INVERT);
   if (c->p.model == NQ_MODEL_COUPLED) {
-#define CALL_(s) launch_invert_sm<s, MODE_COUPLED>(c, qh, store_aux)
+#define CALL_(s) launch_invert_sm<s, MODE_COUPLED>(c, qh, store_aux, part, q_bud)
     NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
   } else {
-#define CALL_(s) launch_invert_sm<s, MODE_UNCOUPLED>(c, qh, store_aux)
+#define CALL_(s) launch_invert_sm<s, MODE_UNCOUPLED>(c, qh, store_aux, part, q_bud)
     NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
   }
 }
 
 // the inversion of the current qh (and, Coupled, current Mphi/Mphiy) into Mu, Mp, Mq, Mqw
-static void do_invert(nq_ctx* c, const cd* qh, bool store_aux) {
+// part: where the ep_psi Parseval partials go; q_bud: QGModel's stale q (or null)
+static void do_invert(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud) {
   if (c->p.model == NQ_MODEL_COUPLED) {
     launch_wavepv(c);
     launch_A(c, false, {c->Ma, c->Mb}, true);
   }
-  launch_invert(c, qh, store_aux);
+  launch_invert(c, qh, store_aux, part, q_bud);
   if (c->p.model == NQ_MODEL_COUPLED) launch_A(c, true, {c->Mu, c->Mp, c->Mq, c->Mqw}, true);
   else launch_A(c, true, {c->Mu, c->Mp, c->Mq}, true);
+}
+// inversion outside a step (set_q, nq_invert): its spectral sums become the next step's slot 0
+static void do_invert_now(nq_ctx* c) {
+  do_invert(c, c->q.y[c->q.cur], true, c->part0Q, nullptr);
+  if (c->bud && c->kernel_family)
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0Q, c->nwq, 3, 3, c->carryQ);
+}
+
+static BudgetAcc budget_acc(nq_ctx* c) {
+  BudgetAcc b;
+  b.model = c->p.model;
+  b.nwx = c->nwx; b.nww = c->nww; b.nwq = c->nwq;
+  b.partX = c->partX; b.partW = c->partW; b.partQ = c->partQ;
+  b.carryW = c->carryW; b.carryQ = c->carryQ; b.gradS1 = c->gradS1; b.acc = c->acc;
+  b.dt = c->p.dt; b.f = c->p.f; b.kappa2 = c->p.kappa2; b.hslash = c->p.f / c->p.kappa2;
+  b.nu = c->p.nu; b.nu4 = c->p.nu4; b.mu = c->p.mu; b.nuw = c->p.nuw; b.nu4w = c->p.nu4w; b.muw = c->p.muw;
+  b.M = (double)c->N * c->N;
+  return b;
 }
 
 static void do_step(nq_ctx* c) {
   const bool waves = c->p.model != NQ_MODEL_QG;
   for (int s = 0; s < 4; ++s) {
-    launch_products(c);
+    launch_products(c, s);
     int qslot = 0, wslot = 0;
     if (waves) launch_A(c, false, {c->Mj, c->Mr}, false);
     launch_A(c, false, {c->Muq, c->Mvq}, true);
     EtdArrays eq = etd_arrays(c->q, s, &qslot);
     launch_sq(c, eq, s);
     if (waves) {
+      // phih at the start of this stage: y(t_n), stage-0 result, stage-1 result, stage-2 result
+      const int cur = c->w.cur;
+      const cd* y_start = (s == 0) ? c->w.y[cur] : (s == 1 ? c->w.y[(cur + 1) % 3] : c->w.y[(cur + 2) % 3]);
       EtdArrays ew = etd_arrays(c->w, s, &wslot);
-      launch_sphi(c, ew, s);
-      launch_A(c, true, {c->Mphi, c->Mphiy}, false);
+      launch_sphi(c, ew, s, y_start);
+      if (c->bud) {
+        if (c->need_diss) launch_A(c, true, {c->Mphi, c->Mphiy, c->Mlap, c->Mdiss}, false);
+        else launch_A(c, true, {c->Mphi, c->Mphiy, c->Mlap}, false);
+      } else {
+        launch_A(c, true, {c->Mphi, c->Mphiy}, false);
+      }
     }
-    do_invert(c, c->q.y[qslot], s == 3);
+    // QGModel evaluates ep_psi after each stage's inversion with the start-of-step q (QGModel.py:355,:401)
+    const cd* q_bud = (!c->kernel_family && s < 3) ? c->q.y[c->q.cur] : nullptr;
+    do_invert(c, c->q.y[qslot], s == 3, c->partQ + (size_t)s * c->nwq * 3, q_bud);
   }
+  if (c->bud) hipLaunchKernelGGL(k_budget_accumulate, dim3(1), dim3(1024), 0, c->stream, budget_acc(c));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -579,6 +729,32 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
         ALLOC(c, c->Mgy, full);
       }
     }
+    c->bud = p->budgets != 0;
+    if (c->bud) {
+      int xc = 1;
+      switch (N) {
+#define CASE_(n, a, b) case n: xc = XPlan<n>::C; break;
+        NQ_FOR_SIZES(CASE_)
+#undef CASE_
+      }
+      c->nwx = N / xc;
+      c->nww = (N / CL) * c->S2;
+      c->nwq = ((c->Wh + CL - 1) / CL) * c->S2;
+      ALLOC(c, c->partQ, (size_t)4 * c->nwq * 3);
+      ALLOC(c, c->part0Q, (size_t)c->nwq * 3);
+      ALLOC(c, c->carryQ, (size_t)4);
+      ALLOC(c, c->acc, (size_t)4);
+      if (c->kernel_family) {
+        c->need_diss = p->nu4w != 0.0;
+        ALLOC(c, c->partX, (size_t)4 * c->nwx * 2);
+        ALLOC(c, c->partW, (size_t)4 * c->nww * 6);
+        ALLOC(c, c->part0W, (size_t)c->nww * 6);
+        ALLOC(c, c->carryW, (size_t)4);
+        ALLOC(c, c->gradS1, (size_t)1);
+        ALLOC(c, c->Mlap, full);
+        if (c->need_diss) ALLOC(c, c->Mdiss, full);
+      }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -652,7 +828,7 @@ int nq_set_q(nq_ctx* c, const double* q_host) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(c->scr_r, q_host, sizeof(double) * full, hipMemcpyHostToDevice, c->stream));
   fwd2d_half(c, c->scr_r, c->q.y[c->q.cur], c->scr_h0);
-  do_invert(c, c->q.y[c->q.cur], true);
+  do_invert_now(c);
   c->have_q = true;
   return nq_sync(c);
 }
@@ -665,7 +841,13 @@ int nq_set_phi(nq_ctx* c, const double* phi_host) {
   HIPCHK(c, hipMemcpyAsync(c->scr_f0, phi_host, sizeof(cd) * full, hipMemcpyHostToDevice, c->stream));
   fwd2d_full(c, c->scr_f0, c->w.y[c->w.cur], c->scr_f1);
   launch_emit_phi(c, c->w.y[c->w.cur]);
-  launch_A(c, true, {c->Mphi, c->Mphiy}, false);
+  if (c->bud) {
+    if (c->need_diss) launch_A(c, true, {c->Mphi, c->Mphiy, c->Mlap, c->Mdiss}, false);
+    else launch_A(c, true, {c->Mphi, c->Mphiy, c->Mlap}, false);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0W, c->nww, 6, 4, c->carryW);
+  } else {
+    launch_A(c, true, {c->Mphi, c->Mphiy}, false);
+  }
   c->have_phi = true;
   int rc = nq_refresh_grad_phi(c);
   if (rc) return rc;
@@ -675,7 +857,7 @@ int nq_set_phi(nq_ctx* c, const double* phi_host) {
 int nq_invert(nq_ctx* c) {
   if (!c) return -1;
   HIPCHK(c, hipSetDevice(c->device));
-  do_invert(c, c->q.y[c->q.cur], true);
+  do_invert_now(c);
   return nq_sync(c);
 }
 
@@ -685,6 +867,7 @@ int nq_refresh_grad_phi(nq_ctx* c) {
     const size_t full = (size_t)c->N * c->N;
     HIPCHK(c, hipMemcpyAsync(c->Mgx, c->Mphi, sizeof(cd) * full, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->Mgy, c->Mphiy, sizeof(cd) * full, hipMemcpyDeviceToDevice, c->stream));
+    if (c->bud) HIPCHK(c, hipMemcpyAsync(c->gradS1, c->carryW + 1, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   }
   return 0;
 }
@@ -807,8 +990,13 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
   double h[2] = {0, 0};
   HIPCHK(c, hipMemsetAsync(d, 0, sizeof(double) * 2, c->stream));
   if (id == NQ_S_KE || id == NQ_S_PW || id == NQ_S_KW) {
-    *out = c->scal[id];
-    return 0;
+    // increment accumulated by nq_step since the last read; reading resets it
+    if (!c->bud) NQ_FAIL(c, -4, "budgets are disabled in this context");
+    HIPCHK(c, hipMemcpyAsync(h, c->acc + id, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->acc + id, 0, sizeof(double), c->stream));
+    int rc = nq_sync(c);
+    *out = h[0];
+    return rc;
   }
   if (id == NQ_S_KE_QG) {
     hipLaunchKernelGGL(k_reduce, dim3((c->Wh + 255) / 256, N), dim3(256), 0, c->stream, c->ph, c->Wh, c->Ph, N, 1, c->kk, c->ll, d);

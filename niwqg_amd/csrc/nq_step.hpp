@@ -57,8 +57,14 @@ template <int N, int P, int T, typename F>
 __device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* lds, cd* __restrict__ rowA,
                                                   cd* __restrict__ rowB, double scaleB = 1.0) {
   __syncthreads();
+  if constexpr (T % 16 == 0) {
+    cd* dst = lds + F::lds_index(j, c);
 #pragma unroll
-  for (int t = 0; t < P; ++t) lds[F::lds_index(j + t * T, c)] = r[t];
+    for (int t = 0; t < P; ++t) dst[t * (T + T / 16)] = r[t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < P; ++t) lds[F::lds_index(j + t * T, c)] = r[t];
+  }
   __syncthreads();
 #pragma unroll
   for (int t = 0; t <= P / 2; ++t) {
@@ -145,32 +151,32 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
 }
 
 // ---- X2: all nonlinear products of one stage ------------------------------------------------
-// ref Kernel.py:471-486 (jacobian_psi_q), :457-469 (jacobian_psi_phi), :332 (refraction).
+// ref Kernel.py:471-486 (jacobian_psi_q), :457-469 (jacobian_psi_phi), :332 (refraction) and, with
+// BUD, the two budget terms that are triple products in physical space (gamma1, xi2; Kernel.py:691-700).
 // MODE_QG: only Muq, Mvq.  MODE_UNCOUPLED: q_psi = q, phix/phiy from the (possibly stale) Mgx/Mgy.
-// Register plan: u, v, q_psi are kept as reals (32 VGPRs each); peak = u+v+q_psi+working = 160.
-template <int N, int MODE>
+// Register plan: q, q_psi, u, v are reals (32 VGPRs each); complex working sets are 64.
+struct BudgetX {
+  const cd* Mlap;     // T_y^-1[-wv2 phih] / M
+  const cd* Mdiss;    // T_y^-1[-(nu4w wv4 + nuw wv2 + muw) phih] / M, or null: diss = nuw lap(phi) - muw phi
+  double nuw, muw;
+  double* part;       // [workgroup][2]: sum q_psi Im(conj(phi) lap(phi)), sum q_psi Re(diss conj(phi))
+};
+
+template <int N, int MODE, bool BUD>
 __global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
 k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __restrict__ Mq,
              const cd* __restrict__ Mqw, const cd* __restrict__ Mphi, const cd* __restrict__ Mgx,
              const cd* __restrict__ Mgy, cd* __restrict__ Muq, cd* __restrict__ Mvq, cd* __restrict__ Mj,
-             cd* __restrict__ Mr, int Ph, const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq) {
+             cd* __restrict__ Mr, int Ph, const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq,
+             BudgetX bx) {
   typedef XPlan<N> X;
   constexpr int P = X::P, T = X::T;
   const int j = threadIdx.x % T, c = threadIdx.x / T;
   const size_t row = (size_t)blockIdx.x * X::C + c;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  double* red = reinterpret_cast<double*>(nq_smem + X::LDS_BYTES - 512);
   cd w[P];
-  double u[P], v[P], qpsi[P];
-  // (u, v) = ifft of (-il psi, ik psi): Mu already holds T_y^-1[-il psi], Mp holds T_y^-1[psi]
-#pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = pack_pair<N>(Mu + row * Ph, Mp + row * Ph, j + t * T, kk, true, v_zero_nyq);
-  NQ_PHASE_FENCE();
-  X::F::template run<true>(w, j, c, lds, tw, 1);
-#pragma unroll
-  for (int t = 0; t < P; ++t) {
-    u[t] = w[t].x;
-    v[t] = w[t].y;
-  }
+  double q[P], qpsi[P];
   // (q, qw)
 #pragma unroll
   for (int t = 0; t < P; ++t) {
@@ -190,32 +196,74 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
   X::F::template run<true>(w, j, c, lds, tw, 1);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
-    const double q = w[t].x;
-    qpsi[t] = (MODE == MODE_COUPLED) ? q - w[t].y : q;
-    w[t] = cmake(u[t] * q, v[t] * q);                        // u q + i v q
+    q[t] = w[t].x;
+    qpsi[t] = (MODE == MODE_COUPLED) ? w[t].x - w[t].y : w[t].x;
+  }
+  if (MODE != MODE_QG) {
+    // phi (physical), budget triple products, refraction source phi * q_psi
+    {
+      const cd* __restrict__ rp = Mphi + row * N;
+#pragma unroll
+      for (int t = 0; t < P; ++t) w[t] = rp[j + t * T];
+    }
+    NQ_PHASE_FENCE();
+    X::F::template run<true>(w, j, c, lds, tw, 1);
+    if (BUD) {
+      cd w2[P];
+      double acc[2] = {0.0, 0.0};
+      {
+        const cd* __restrict__ rp = bx.Mlap + row * N;
+#pragma unroll
+        for (int t = 0; t < P; ++t) w2[t] = rp[j + t * T];
+      }
+      NQ_PHASE_FENCE();
+      X::F::template run<true>(w2, j, c, lds, tw, 1);
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        acc[0] += qpsi[t] * (w[t].x * w2[t].y - w[t].y * w2[t].x);
+        if (!bx.Mdiss)
+          acc[1] += qpsi[t] * (bx.nuw * (w2[t].x * w[t].x + w2[t].y * w[t].y) -
+                               bx.muw * (w[t].x * w[t].x + w[t].y * w[t].y));
+      }
+      if (bx.Mdiss) {
+        const cd* __restrict__ rp = bx.Mdiss + row * N;
+#pragma unroll
+        for (int t = 0; t < P; ++t) w2[t] = rp[j + t * T];
+        NQ_PHASE_FENCE();
+        X::F::template run<true>(w2, j, c, lds, tw, 1);
+#pragma unroll
+        for (int t = 0; t < P; ++t) acc[1] += qpsi[t] * (w2[t].x * w[t].x + w2[t].y * w[t].y);
+      }
+      NQ_PHASE_FENCE();
+      block_sum_store<2>(acc, red, bx.part + 2 * (size_t)blockIdx.x);
+    }
+#pragma unroll
+    for (int t = 0; t < P; ++t) w[t] = cscale(w[t], qpsi[t]);
+    NQ_PHASE_FENCE();
+    X::F::template run<false>(w, j, c, lds, tw, 1);
+    {
+      cd* __restrict__ rp = Mr + row * N;
+#pragma unroll
+      for (int t = 0; t < P; ++t) rp[j + t * T] = w[t];
+    }
+  }
+  // (u, v) = ifft of (-il psi, ik psi): Mu already holds T_y^-1[-il psi], Mp holds T_y^-1[psi]
+  double u[P], v[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) w[t] = pack_pair<N>(Mu + row * Ph, Mp + row * Ph, j + t * T, kk, true, v_zero_nyq);
+  NQ_PHASE_FENCE();
+  X::F::template run<true>(w, j, c, lds, tw, 1);
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    u[t] = w[t].x;
+    v[t] = w[t].y;
+    w[t] = cmake(u[t] * q[t], v[t] * q[t]);                  // u q + i v q
   }
   NQ_PHASE_FENCE();
   X::F::template run<false>(w, j, c, lds, tw, 1);
   NQ_PHASE_FENCE();
   unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, Muq + row * Ph, Mvq + row * Ph);
   if (MODE == MODE_QG) return;
-  // refraction source phi * q_psi
-  {
-    const cd* __restrict__ rp = Mphi + row * N;
-#pragma unroll
-    for (int t = 0; t < P; ++t) w[t] = rp[j + t * T];
-  }
-  NQ_PHASE_FENCE();
-  X::F::template run<true>(w, j, c, lds, tw, 1);
-#pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = cscale(w[t], qpsi[t]);
-  NQ_PHASE_FENCE();
-  X::F::template run<false>(w, j, c, lds, tw, 1);
-  {
-    cd* __restrict__ rp = Mr + row * N;
-#pragma unroll
-    for (int t = 0; t < P; ++t) rp[j + t * T] = w[t];
-  }
   // advection u phix + v phiy: w <- u*phix, then w += v*phiy with phiy in w2
   {
     const cd* __restrict__ rp = Mgx + row * N;
@@ -325,18 +373,55 @@ k_s_q(const cd* __restrict__ Huq, const cd* __restrict__ Hvq, EtdArrays ea, int 
 }
 
 // ---- Sw: nonlinear term + stage update of phi-hat, then first half of the inverse y transform -----
+// With budgets (bw.part != null) it also emits the y-half-transformed -wv2*phih (for lap(phi)) and the
+// Parseval sums of ref Kernel.py:629-633, :646-652, :698-699 (see oracle/reduced_pipeline.py).
+struct BudgetW {
+  double* part;        // [workgroup][6]: S0..S3 of the NEW phih, then GJ, XJ of this stage; null = off
+  const cd* y_start;   // phih at the start of this stage (what J was computed from)
+  cd* Hlap;
+  cd* Hdiss;           // null unless nu4w != 0
+  double nu4w, nuw, muw;
+};
+
+// a[], b[] hold y/M and i*l*y/M on return; budgets: sums over the new y and emission of lap / diss
+template <int P, int T>
+__device__ __forceinline__ void phi_outputs(const cd (&y)[P], cd (&a)[P], cd (&b)[P], cd (&lap)[P], int l1, int S2,
+                                            int j, int k, double invM, const double* __restrict__ kk,
+                                            const double* __restrict__ ll, bool bud, double (&s)[4]) {
+  const double kx = kk[k];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int l = l1 + S2 * (j + t * T);
+    const double ly = ll[l];
+    a[t] = cscale(y[t], invM);
+    b[t] = cscale(cmul_i(y[t]), ly * invM);
+    if (bud) {
+      const double wv2 = kx * kx + ly * ly;
+      const double m2 = y[t].x * y[t].x + y[t].y * y[t].y;
+      s[0] += m2;
+      s[1] += wv2 * m2;
+      s[2] += wv2 * wv2 * m2;
+      s[3] += wv2 * wv2 * wv2 * m2;
+      lap[t] = cscale(y[t], -wv2 * invM);
+    }
+  }
+}
+
 template <int S1>
 __global__ void __launch_bounds__(YPlan<S1>::THREADS)
 k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int stage, int S2,
-        cd* __restrict__ Hphi, cd* __restrict__ Hphiy, double invM, const double* __restrict__ ll,
-        const cd* __restrict__ tw, int tw_step_N) {
+        cd* __restrict__ Hphi, cd* __restrict__ Hphiy, double invM, const double* __restrict__ kk,
+        const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N, BudgetW bw) {
   typedef YPlan<S1> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
   const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
   const int N = S1 * S2;
+  const bool bud = bw.part != nullptr;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
-  cd a[P], b[P];
+  double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
+  double* part = bud ? bw.part + 6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+  cd a[P], b[P], y[P];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const size_t at = (size_t)(l1 * S1 + j + t * T) * N + k;
@@ -345,17 +430,30 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
   }
   Y::F::template run<false>(a, j, c, lds, tw, tw_step_N * (N / S1));
   Y::F::template run<false>(b, j, c, lds, tw, tw_step_N * (N / S1));
+  double sj[2] = {0.0, 0.0};
+  const double kx = kk[k];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int l = l1 + S2 * (j + t * T);
+    const size_t idx = (size_t)l * N + k;
+    if (bud) {
+      // gamma2 ~ sum Re(conj(lap_h) J), xi1 ~ -sum Im(diss_h conj(J)) with lap_h = -wv2 ys, diss_h = -d ys
+      const cd ys = bw.y_start[idx];
+      const double ly = ll[l];
+      const double wv2 = kx * kx + ly * ly;
+      const double d = bw.nu4w * wv2 * wv2 + bw.nuw * wv2 + bw.muw;
+      sj[0] += -wv2 * (ys.x * a[t].x + ys.y * a[t].y);
+      sj[1] += -d * (ys.y * a[t].x - ys.x * a[t].y);
+    }
     cd J = a[t];
     if (l == 0 && k == 0) J = cmake(0, 0);
     // N_phi = -J - 0.5 i R
     const cd Nl = cmake(-J.x + 0.5 * b[t].y, -J.y - 0.5 * b[t].x);
-    const cd y = etd_update(ea, (size_t)l * N + k, Nl, stage);
-    a[t] = cscale(y, invM);
-    b[t] = cscale(cmul_i(y), ll[l] * invM);
+    y[t] = etd_update(ea, idx, Nl, stage);
   }
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
+  cd lap[P];
+  phi_outputs<P, T>(y, a, b, lap, l1, S2, j, k, invM, kk, ll, bud, s4);
   Y::F::template run<true>(a, j, c, lds, tw, tw_step_N * (N / S1));
   Y::F::template run<true>(b, j, c, lds, tw, tw_step_N * (N / S1));
 #pragma unroll
@@ -364,27 +462,45 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
     Hphi[at] = a[t];
     Hphiy[at] = b[t];
   }
+  if (bud) {
+    Y::F::template run<true>(lap, j, c, lds, tw, tw_step_N * (N / S1));
+#pragma unroll
+    for (int t = 0; t < P; ++t) bw.Hlap[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
+    if (bw.Hdiss) {
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        const double ly = ll[l1 + S2 * (j + t * T)];
+        const double wv2 = kx * kx + ly * ly;
+        lap[t] = cscale(y[t], -(bw.nu4w * wv2 * wv2 + bw.nuw * wv2 + bw.muw) * invM);
+      }
+      Y::F::template run<true>(lap, j, c, lds, tw, tw_step_N * (N / S1));
+#pragma unroll
+      for (int t = 0; t < P; ++t) bw.Hdiss[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
+    }
+    block_sum_store<4>(s4, red, part);
+    block_sum_store<2>(sj, red, part + 4);
+  }
 }
 
-// emit-only variant (set_phi): phih -> Hphi, Hphiy
+// emit-only variant (set_phi): phih -> Hphi, Hphiy (+ lap, diss, sums with budgets)
 template <int S1>
 __global__ void __launch_bounds__(YPlan<S1>::THREADS)
 k_s_emit_phi(const cd* __restrict__ phih, int S2, cd* __restrict__ Hphi, cd* __restrict__ Hphiy, double invM,
-             const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N) {
+             const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N,
+             BudgetW bw) {
   typedef YPlan<S1> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
   const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
   const int N = S1 * S2;
+  const bool bud = bw.part != nullptr;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
-  cd a[P], b[P];
+  double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
+  cd a[P], b[P], y[P], lap[P];
 #pragma unroll
-  for (int t = 0; t < P; ++t) {
-    const int l = l1 + S2 * (j + t * T);
-    const cd y = phih[(size_t)l * N + k];
-    a[t] = cscale(y, invM);
-    b[t] = cscale(cmul_i(y), ll[l] * invM);
-  }
+  for (int t = 0; t < P; ++t) y[t] = phih[(size_t)(l1 + S2 * (j + t * T)) * N + k];
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
+  phi_outputs<P, T>(y, a, b, lap, l1, S2, j, k, invM, kk, ll, bud, s4);
   Y::F::template run<true>(a, j, c, lds, tw, tw_step_N * (N / S1));
   Y::F::template run<true>(b, j, c, lds, tw, tw_step_N * (N / S1));
 #pragma unroll
@@ -392,6 +508,27 @@ k_s_emit_phi(const cd* __restrict__ phih, int S2, cd* __restrict__ Hphi, cd* __r
     const size_t at = (size_t)(l1 * S1 + j + t * T) * N + k;
     Hphi[at] = a[t];
     Hphiy[at] = b[t];
+  }
+  if (bud) {
+    const double kx = kk[k];
+    Y::F::template run<true>(lap, j, c, lds, tw, tw_step_N * (N / S1));
+#pragma unroll
+    for (int t = 0; t < P; ++t) bw.Hlap[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
+    if (bw.Hdiss) {
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        const double ly = ll[l1 + S2 * (j + t * T)];
+        const double wv2 = kx * kx + ly * ly;
+        lap[t] = cscale(y[t], -(bw.nu4w * wv2 * wv2 + bw.nuw * wv2 + bw.muw) * invM);
+      }
+      Y::F::template run<true>(lap, j, c, lds, tw, tw_step_N * (N / S1));
+#pragma unroll
+      for (int t = 0; t < P; ++t) bw.Hdiss[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
+    }
+    double* part = bw.part + 6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    double z2[2] = {0.0, 0.0};
+    block_sum_store<4>(s4, red, part);
+    block_sum_store<2>(z2, red, part + 4);
   }
 }
 
@@ -404,7 +541,10 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
            const double* __restrict__ filt, cd* __restrict__ Hu, cd* __restrict__ Hp, cd* __restrict__ Hq,
            cd* __restrict__ Hqw, cd* __restrict__ qwh_out, cd* __restrict__ ph_out, int Wh, int Ph, int S2,
            double invM, double f, const double* __restrict__ kk, const double* __restrict__ ll, int kernel_family,
-           const cd* __restrict__ tw, int tw_step_N) {
+           const cd* __restrict__ tw, int tw_step_N, double* __restrict__ bud_part, const cd* __restrict__ q_bud) {
+  // bud_part: [workgroup][3] Parseval sums for ep_psi (ref Kernel.py:635-640 / QGModel.py:588-593):
+  //   sum w*wv4*Re(qb conj psi), sum w*wv2*Re(q conj psi), sum w*Re(qb conj psi); qb = q_bud (QGModel's
+  //   stale q, QGModel.py:401) or q; w = 1 on the self-mirrored columns, 2 elsewhere.
   typedef YPlan<S1> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
@@ -412,6 +552,8 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
   const bool ok = k < Wh;
   const int N = S1 * S2;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
+  double s3[3] = {0.0, 0.0, 0.0};
   cd a[P], b[P], u[P], q[P];
   if (MODE == MODE_COUPLED) {
 #pragma unroll
@@ -447,6 +589,28 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
       ph_out[idx] = psi;
       if (MODE == MODE_COUPLED) qwh_out[idx] = qw;
     }
+    if (bud_part && ok) {
+      const bool special = (k == 0 || k == N / 2);
+      cd qB = q_bud ? q_bud[idx] : qv, qQ = qv, ps = psi;
+      if (special) {
+        // mean(a*b) of REAL fields uses the Hermitian part (in l) of the self-mirrored columns -- what
+        // irfft2 / `.real` keep.  q-hat(-l) comes from memory; psi(-l) follows from it because qwh is
+        // Hermitian there: psi(-l) = wv2i (conj(qwh(l)) - q(-l)).
+        const size_t im = (size_t)((N - l) % N) * Ph + k;
+        const cd qm = qh[im];
+        const cd qbm = q_bud ? q_bud[im] : qm;
+        const cd psm = (MODE == MODE_COUPLED) ? cmake(wv2i * (qw.x - qm.x), wv2i * (-qw.y - qm.y))
+                                              : cmake(-wv2i * qm.x, -wv2i * qm.y);
+        qQ = cmake(0.5 * (qv.x + qm.x), 0.5 * (qv.y - qm.y));
+        qB = cmake(0.5 * (qB.x + qbm.x), 0.5 * (qB.y - qbm.y));
+        ps = cmake(0.5 * (psi.x + psm.x), 0.5 * (psi.y - psm.y));
+      }
+      const double wgt = special ? 1.0 : 2.0;
+      const double rb = wgt * (qB.x * ps.x + qB.y * ps.y), rq = wgt * (qQ.x * ps.x + qQ.y * ps.y);
+      s3[0] += wv2 * wv2 * rb;
+      s3[1] += wv2 * rq;
+      s3[2] += rb;
+    }
     // u = Re ifft(-il psi) with psi Hermitian (ref Kernel.py:481): the whole Nyquist row drops out.
     // On the two self-mirrored columns psi is kept un-projected here and the row kernels take the
     // real part after the y transform; that commutes with -il everywhere except at l = N/2, where
@@ -471,6 +635,7 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
       if (MODE == MODE_COUPLED) Hqw[at] = b[t];
     }
   }
+  if (bud_part) block_sum_store<3>(s3, red, bud_part + 3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
 }
 
 }  // namespace nq

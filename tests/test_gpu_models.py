@@ -1,0 +1,321 @@
+"""GPU parity of the drop-in model classes (niwqg_amd.CoupledModel / UnCoupledModel / QGModel).
+
+Expected values are (a) the golden vectors generated from the reference (tests/golden/*.npz,
+make_golden.py), (b) the logged lines of the reference's notebook, (c) the numpy oracle pinned to the
+reference by test_oracle_golden.py.  Tolerances are RELATIVE L2 errors; the acceptance bar of
+BASELINE.json is 1e-10 over 100 steps -- these tests ask for much less.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import niwqg_oracle as O
+from test_oracle_golden import notebook_kwargs, rel, L, K0, U0, TE, F0, NB, MZ
+
+pytestmark = pytest.mark.gpu
+
+
+def models():
+    import niwqg_amd
+    return niwqg_amd
+
+
+def steps(m, n):
+    while m.tc < n:
+        m._step_forward()
+
+
+def rel_no_passenger(qh, ref):
+    """q-hat comparison without the Nyquist row of the interior columns: the reference carries an
+    anti-Hermitian passenger there that never reaches physical space (known gaps)."""
+    n = ref.shape[0]
+    a, b = qh.copy(), ref.copy()
+    for x in (a, b):
+        x[n // 2, 1:n // 2] = 0
+        x[n // 2, n // 2 + 1:] = 0
+    return rel(a, b)
+
+
+@pytest.mark.parametrize("use_filter", [False, True])
+def test_coupled_golden_trajectory_64(golden, use_filter):
+    g = golden("g2_coupled_64_%s.npz" % ("filter" if use_filter else "nofilter"))
+    m = models().CoupledModel.Model(**notebook_kwargs(64, use_filter))
+    m.set_q(g["q0"])
+    m.set_phi(g["phi0"])
+    for n in g["snaps"]:
+        m.tmax = (int(n) - 0.5) * m.dt      # the reference's tests mutate tmax after construction too
+        m.run()
+        assert m.tc == n
+        assert rel(m.q, g["q_%d" % n]) < 1e-12
+        assert rel(m.phi, g["phi_%d" % n]) < 1e-12
+        assert rel(m.phih, g["phih_%d" % n]) < 1e-12
+        assert rel(m.ph, g["ph_%d" % n]) < 1e-12
+        assert rel_no_passenger(m.qh, g["qh_%d" % n]) < 1e-12
+        assert np.allclose([m.Ke, m.Pw, m.Kw], g["budgets_%d" % n], rtol=1e-9)
+
+
+@pytest.mark.parametrize("use_filter", [False, True])
+def test_coupled_golden_100_steps_128(golden, use_filter):
+    g = golden("g2_coupled_128_%s.npz" % ("filter" if use_filter else "nofilter"))
+    m = models().CoupledModel.Model(**notebook_kwargs(128, use_filter))
+    m.set_q(g["q0"])
+    m.set_phi(g["phi0"])
+    m.tmax = 99.5 * m.dt
+    m.run()
+    assert m.tc == 100
+    eq, ep = rel(m.q, g["q_100"]), rel(m.phi, g["phi_100"])
+    print("128^2, 100 steps, filter=%s: rel err q %.2e phi %.2e" % (use_filter, eq, ep))
+    assert eq < 1e-12 and ep < 1e-12          # BASELINE bar: 1e-10
+    assert np.allclose([m.Ke, m.Pw, m.Kw], g["budgets_100"], rtol=1e-9)
+
+
+def test_qg_golden_trajectories(golden):
+    QG = models().QGModel
+    g = golden("g3_qg_64.npz")
+    m = QG.Model(L=L, nx=64, tmax=1e30, dt=float(g["dt"]), twrite=10 ** 9, nu4=7.5e8, use_filter=False,
+                 U=-U0, tdiags=10 ** 9, beta=0.0)
+    m.set_q(g["q0"])
+    for n in g["snaps"]:
+        steps(m, n)
+        assert rel(m.q, g["q_%d" % n]) < 1e-11
+        assert rel(m.qh, g["qh_%d" % n]) < 1e-11
+        assert np.isclose(m.Ke, float(g["Ke_%d" % n]), rtol=1e-10)
+    g = golden("g3_qg_256.npz")
+    m = QG.Model(L=L, nx=256, tmax=199.5 * float(g["dt"]), dt=float(g["dt"]), twrite=10 ** 9, nu4=7.5e8,
+                 use_filter=False, U=-U0, tdiags=10 ** 9, beta=0.0)
+    m.set_q(g["q0"])
+    m.run()                                   # BASELINE configs[0]: QGModel LambDipole 256^2, 200 steps
+    assert m.tc == 200
+    assert rel(m.q, g["q_200"]) < 1e-11 and rel(m.qh, g["qh_200"]) < 1e-11
+    assert np.isclose(m.Ke, float(g["Ke_200"]), rtol=1e-10)
+    g = golden("g3_qg_64_beta.npz")
+    m = QG.Model(L=L, nx=64, tmax=1e30, dt=float(g["dt"]), twrite=10 ** 9, nu4=7.5e8, nu=5.0, mu=1e-8,
+                 use_filter=True, U=-U0, tdiags=10 ** 9, beta=2e-11)
+    m.set_q(g["q0"])
+    steps(m, 20)
+    assert rel(m.q, g["q_20"]) < 1e-12 and rel(m.qh, g["qh_20"]) < 1e-12
+    assert np.isclose(m.Ke, float(g["Ke_20"]), rtol=1e-10)
+
+
+def test_uncoupled_quirk_q1_golden(golden):
+    g = golden("g4_quirks_64.npz")
+    res = {}
+    for tag, td in (("td1", 1), ("tdinf", 10 ** 9)):
+        m = models().UnCoupledModel.Model(**notebook_kwargs(64, True, tdiags=td))
+        m.set_q(g["unc_q0"])
+        m.set_phi(g["unc_phi0"])
+        m.tmax = 19.5 * m.dt
+        m.run()
+        assert m.tc == 20
+        assert rel(m.phi, g["unc_phi_" + tag]) < 1e-12
+        assert rel(m.q, g["unc_q_" + tag]) < 1e-12
+        assert np.allclose([m.Ke, m.Pw, m.Kw], g["unc_budgets_" + tag], rtol=1e-9)
+        res[tag] = m.phi
+    assert rel(res["td1"], res["tdinf"]) > 1e-3
+
+
+def test_set_order_quirk_q2_golden(golden):
+    g = golden("g4_quirks_64.npz")
+    for tag in ("q_then_phi", "phi_then_q"):
+        m = models().CoupledModel.Model(**notebook_kwargs(64, True))
+        if tag == "q_then_phi":
+            m.set_q(g["order_q0"]); m.set_phi(g["order_phi0"])
+        else:
+            m.set_phi(g["order_phi0"]); m.set_q(g["order_q0"])
+        assert rel(m.ph, g["order_ph0_" + tag]) < 1e-13
+        steps(m, 1)
+        assert rel(m.q, g["order_q_" + tag]) < 1e-13
+        assert rel(m.phi, g["order_phi_" + tag]) < 1e-12      # phi ~ 1e-8 here: the filter removes the packet
+
+
+def test_rough_fields_every_budget_term_vs_oracle():
+    kw = notebook_kwargs(64, False)
+    kw.update(nu4w=1e10, mu=1e-8, muw=2e-8)
+    rng = np.random.default_rng(1)
+    q0 = 1e-5 * rng.standard_normal((64, 64))
+    phi0 = 0.05 * (rng.standard_normal((64, 64)) + 1j * rng.standard_normal((64, 64)))
+    o = O.NIWQGOracle("coupled", **kw)
+    m = models().CoupledModel.Model(**kw)
+    for x in (o, m):
+        x.set_q(q0)
+        x.set_phi(phi0)
+    for _ in range(5):
+        o._step_forward()
+    steps(m, 5)
+    assert rel(m.q, o.q) < 1e-11 and rel(m.phi, o.phi) < 1e-11
+    assert np.allclose([m.Ke, m.Pw, m.Kw], [o.Ke, o.Pw, o.Kw], rtol=1e-8)
+
+
+# ---- the reference's own test files, restated against the new backend -------------------------------
+def test_ref_test_fft():
+    """niwqg/tests/test_fft.py: round trip and Parseval, CoupledModel (c2c) and QGModel (r2c)."""
+    rng = np.random.default_rng(0)
+    m = models().CoupledModel.Model(use_filter=False)
+    qi = rng.standard_normal((m.ny, m.nx))
+    phii = rng.standard_normal((m.ny, m.nx)) + 1j * rng.standard_normal((m.ny, m.nx))
+    assert np.allclose(m.ifft(m.fft(qi)).real, qi, rtol=1e-15)
+    assert np.allclose(m.ifft(m.fft(phii)), phii, rtol=1e-15)
+    m.set_q(qi)
+    assert abs(m.spec_var(m.qh) - qi.var()) / qi.var() < 1e-14
+    m.set_phi(phii)
+    assert abs(m.spec_var(m.phih) - phii.var()) / phii.var() < 1e-14
+    g = models().QGModel.Model(use_filter=False)
+    assert np.allclose(g.ifft(g.fft(qi)), qi, rtol=1e-15)
+    g.set_q(qi)
+    assert abs(g.spec_var(g.qh) - qi.var()) / qi.var() < 1e-14
+
+
+def test_ref_test_advection():
+    """niwqg/tests/test_advection.py: Jacobians of a slanted plane wave vanish."""
+    m = models().CoupledModel.Model(use_filter=False)
+    k, l = 2 * np.pi * 5 / m.L, 2 * np.pi * 9 / m.L
+    m.set_q(np.sin(k * m.x + l * m.y))
+    m.set_phi(np.sin(k * m.x + l * m.y))
+    assert m.jacobian_psi_q().std() < 1e-12
+    assert m.jacobian_phic_phi().std() < 1e-12
+    assert m.jacobian_psi_phi().std() < 1e-12
+    g = models().QGModel.Model(use_filter=False)
+    g.set_q(np.sin(k * g.x + l * g.y))
+    assert g.jacobian_psi_q().std() < 1e-12
+
+
+def test_ref_test_diffusion():
+    """niwqg/tests/test_diffusion.py: ETDRK4 is exact for the linear hyperviscous decay.  With the
+    reference's parameters (q amplitude 1 1/s, nu4=1e14) the wave decays by exp(-2800), so its assertion
+    only sees atol=1e-8; the check is repeated with a physical amplitude (1e-6 1/s) and nu4=1e11 (decay to
+    6 %) under a relative tolerance."""
+    k, l = 2 * np.pi * 5 / 5e5, 2 * np.pi * 9 / 5e5
+    for nu4, amp, strict in ((1e14, 1.0, False), (1e11, 1e-6, True)):
+        m = models().CoupledModel.Model(use_filter=False, nu4=nu4, nu4w=0.)
+        m.tmax = 10 * m.dt
+        qi = amp * np.sin(k * m.x + l * m.y)
+        m.set_q(qi)
+        m.set_phi(qi * 0)
+        m.run()
+        assert m.tc == 10
+        qfh = m.fft(qi) * np.exp((-m.nu4 * m.wv4 - (m.nu * m.wv2 if strict else 0)) * m.tmax)
+        assert np.allclose(qfh, m.qh, rtol=1e-15)
+        if strict:
+            assert rel(m.qh, qfh) < 1e-12
+        g = models().QGModel.Model(use_filter=False, nu4=nu4)
+        g.tmax = (100 if not strict else 10) * g.dt
+        qi = amp * np.sin(k * g.x + l * g.x)
+        g.set_q(qi)
+        g.run()
+        qfh = g.fft(qi) * np.exp(-g.nu4 * g.wv4 * g.tmax)
+        assert np.allclose(qfh, g.qh, rtol=1e-15)
+        if strict:
+            assert rel(g.qh, qfh) < 1e-12
+
+
+def test_ref_test_diagnostics_energy():
+    """niwqg/tests/test_diagnostics.py::QGNIWTester: diagnosed energies equal the budget accumulators."""
+    from niwqg_amd import InitialConditions as ic
+    m = models().CoupledModel.Model(use_filter=False, U=-0.05, tdiags=1)
+    k0 = 10 * (2 * np.pi / m.L)
+    q = ic.LambDipole(m, U=0.05, R=2 * np.pi / k0)
+    phi = (np.ones_like(q) + 1j) * 5 * 0.05 / np.sqrt(2)
+    m.set_q(q)
+    m.set_phi(phi)
+    m.run()
+    d = m.diagnostics
+    assert np.allclose(d['ke_qg']['value'], d['Ke']['value'], rtol=1e-15)
+    assert np.allclose(d['ke_niw']['value'], d['Kw']['value'], rtol=1e-15)
+    assert np.allclose(d['pe_niw']['value'], d['Pw']['value'], rtol=1e-15)
+    assert len(d['time']['value']) == 25
+    # tighter than the reference's (atol-dominated) check
+    assert np.allclose(d['ke_qg']['value'], d['Ke']['value'], rtol=1e-7, atol=0)
+
+
+def test_notebook_status_lines_and_diagnostics(golden):
+    """The 33 status lines logged in examples/LambDipole_CoupledModel.ipynb (cell 9) and the reference's
+    diagnostics series for that run (g6), through CoupledModel.Model.run() on the device."""
+    from niwqg_amd import InitialConditions as ic
+    g = golden("g6_notebook_diags.npz")
+    dt = 0.025 * TE
+    m = models().CoupledModel.Model(L=L, nx=128, tmax=10 * TE, dt=dt, m=MZ, N=NB, f=F0,
+                                    twrite=int((2 * np.pi / F0) / dt), nu4=5e11, nu4w=0e10, nu=20, nuw=50e0,
+                                    mu=0.e-7, muw=0e-7, use_filter=False, U=-U0, tdiags=1,
+                                    save_to_disk=False, dealias=False)
+    lines = []
+
+    class Grab(object):
+        def info(self, fmt, *a):
+            lines.append("INFO: " + fmt % a)
+
+        def error(self, *a):
+            return "error"
+
+    m.logger = Grab()
+    m.set_q(ic.LambDipole(m, U=U0, R=2 * np.pi / K0))
+    m.set_phi((np.ones((128, 128)) + 1j) * (2 * U0) / np.sqrt(2))
+    m.run()
+    logged = open(os.path.join(os.path.dirname(__file__), "golden", "g5_notebook_cell9_log.txt")).read()
+    logged = [re.sub(r"\s+$", "", s) for s in logged.splitlines() if s.strip()]
+    assert lines == logged
+    for name in ("time", "Ke", "Pw", "Kw", "ke_qg", "ke_niw", "pe_niw", "gamma_r", "gamma_a", "xi_r", "xi_a",
+                 "ep_psi", "chi_phi", "ep_phi", "pi", "ens", "ke_qg_q", "ke_qg_w", "ke_qg_qw", "chi_q"):
+        assert np.allclose(m.diagnostics[name]['value'], g[name], rtol=1e-8, atol=1e-22), name
+    assert rel(m.q, g["final_q"]) < 1e-11 and rel(m.phi, g["final_phi"]) < 1e-11
+
+
+def test_unsupported_options_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        models().CoupledModel.Model(nx=64, use_filter=False, dealias=True)
+    with pytest.raises(NotImplementedError):
+        models().QGModel.Model(nx=64, passive_scalar=True)
+    with pytest.raises(RuntimeError):
+        models().CoupledModel.Model(nx=96)
+
+
+# ---- larger sizes ------------------------------------------------------------------------------------
+def test_parity_1024_vs_oracle():
+    nx = 1024
+    kw = notebook_kwargs(nx, True)
+    o = O.NIWQGOracle("coupled", coeff_chunk=8, **kw)
+    m = models().CoupledModel.Model(**kw)
+    q0 = O.lamb_dipole(o.grid, U=U0, R=2 * np.pi / K0)
+    phi0 = (np.ones((nx, nx)) + 1j) * (2 * U0) / np.sqrt(2)
+    for x in (o, m):
+        x.set_q(q0)
+        x.set_phi(phi0)
+    for _ in range(2):
+        o._step_forward()
+    steps(m, 2)
+    assert rel(m.q, o.q) < 1e-12 and rel(m.phi, o.phi) < 1e-12
+    assert np.allclose([m.Ke, m.Pw, m.Kw], [o.Ke, o.Pw, o.Kw], rtol=1e-9)
+
+
+def test_full_size_4096_properties():
+    """BASELINE's 4096^2 CoupledModel: properties that need no oracle at that size."""
+    from niwqg_amd import InitialConditions as ic
+    nx = 4096
+    m = models().CoupledModel.Model(**notebook_kwargs(nx, True))
+    rng = np.random.default_rng(7)
+    a = rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx))
+    fa = m.fft(a)
+    assert rel(m.ifft(fa), a) < 1e-14                                     # round trip
+    assert abs((np.abs(fa) ** 2).sum() / nx ** 2 - (np.abs(a) ** 2).sum()) / (np.abs(a) ** 2).sum() < 1e-13
+    row = np.fft.fft(a[17])                                               # one row/column against numpy
+    assert rel(m.fft(np.tile(a[17], (nx, 1)))[0] / nx, row) < 1e-14
+    # linear decay is exact: plane-wave q (zero Jacobian), phi = 0
+    k, l = 2 * np.pi * 5 / m.L, 2 * np.pi * 9 / m.L
+    qi = 1e-5 * np.sin(k * m.x + l * m.y)
+    m.set_q(qi)
+    m.set_phi(np.zeros((nx, nx), complex))
+    steps(m, 3)
+    wv2 = k * k + l * l
+    expect = qi * np.exp((-m.nu4 * wv2 ** 2 - m.nu * wv2) * 3 * m.dt)
+    # the plane wave is advected by U: compare amplitudes through the spectrum norm
+    assert abs(np.linalg.norm(m.q) / np.linalg.norm(expect) - 1) < 1e-12
+    # LambDipole + uniform wave: wave-action-like invariant and finite fields after a few steps
+    m2 = models().CoupledModel.Model(**notebook_kwargs(nx, True))
+    m2.set_q(ic.LambDipole(m2, U=U0, R=2 * np.pi / K0))
+    m2.set_phi((np.ones((nx, nx)) + 1j) * (2 * U0) / np.sqrt(2))
+    kw0 = m2.Kw
+    steps(m2, 4)
+    assert np.isfinite(m2.q).all() and np.isfinite(m2.phi).all()
+    assert abs(m2._calc_ke_niw() - m2.Kw) < 1e-9 * kw0                   # budget closes (Kernel.py:392)
+    assert abs(m2._calc_ke_qg() - m2.Ke) < 1e-6 * m2.Ke

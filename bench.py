@@ -106,14 +106,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from niwqg_amd.distributed import Group, aggregate_throughput
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    grp = Group()                      # nccl (= RCCL) when launched with WORLD_SIZE > 1
+    rank, world, local_rank = grp.rank, grp.world, grp.local_rank
     torch.cuda.set_device(local_rank)
 
     # Round 1: the slab-decomposed multi-GPU path is not built yet; with N > 1 every rank
@@ -124,8 +120,7 @@ def main():
     ctx.sync()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        grp.barrier()
         torch.cuda.synchronize()
         ctx.sync()
 
@@ -139,14 +134,10 @@ def main():
     wall = time.perf_counter() - t0
     launches, kms = ctx.profile_read()
     ctx.profile_enable(-1)
-    if dist is not None:
-        tt = torch.tensor([wall], device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
+    sps, wall = aggregate_throughput(grp, args.steps, wall)   # all ranks' steps / max-over-ranks time
 
     if rank == 0:
         npts = float(args.nx) ** 2
-        sps = world * args.steps / wall
         k_ms = kms / max(launches, 1)
         k_bytes = X_PRODUCTS_B_PER_PT[args.model] * npts
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
@@ -172,9 +163,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, args.nx)
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,120 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header
+declares, the layout helpers, the run-loop batching logic, and the loud failure without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import niwqg_amd
+    niwqg_amd.build()
+    from niwqg_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built):
+    header = open(os.path.join(ROOT, "include", "niwqg_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(nq_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 25
+    L = built.lib()
+    missing = [name for name in declared if not hasattr(L, name)]
+    assert not missing, missing
+    assert sorted(built.EXPORTS) == declared
+
+
+def test_params_struct_matches_header(built):
+    header = open(os.path.join(ROOT, "include", "niwqg_amd.h")).read()
+    body = header[header.index("typedef struct nq_params {"):header.index("} nq_params;")]
+    fields = re.findall(r"\b(?:int|double)\s+([^;]+);", body)
+    names = [n.strip() for f in fields for n in f.split(",")]
+    assert names == [n for n, _ in built.Params._fields_]
+
+
+def test_no_gpu_means_loud_failure(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import niwqg_amd
+    with pytest.raises(RuntimeError, match="no HIP device|hip"):
+        niwqg_amd.CoupledModel.Model(nx=64)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "niwqg_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, f
+
+
+def test_hermitian_expansion_matches_numpy():
+    from niwqg_amd.Kernel import hermitian_full, project_self_mirrored_columns
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((16, 16))
+    assert np.allclose(hermitian_full(np.fft.rfft2(a)), np.fft.fft2(a), rtol=1e-13, atol=1e-13)
+    h = np.fft.rfft2(a) * (1 + 0.3j)
+    p = project_self_mirrored_columns(h)
+    assert np.allclose(np.fft.irfft2(p), np.fft.irfft2(h), atol=1e-13)
+    assert np.allclose(p[:, 0], np.fft.fft(np.fft.ifft(p[:, 0]).real), atol=1e-13)
+
+
+class _FakeCtx(object):
+    budgets_enabled = False
+
+    def __init__(self):
+        self.calls = []
+
+    def step(self, n):
+        self.calls.append(n)
+
+
+def _bare_kernel(tdiags, twrite, dt, tmax):
+    from niwqg_amd import Kernel
+    k = object.__new__(Kernel.Kernel)
+    k.__dict__.update(tdiags=tdiags, twrite=twrite, dt=dt, tmax=tmax, t=0, tc=0, _cache={}, _user={},
+                      _ctx=_FakeCtx(), diagnostics={})
+    k.ticks, k.status = [], []
+    k._calc_derived_fields = lambda: k.ticks.append(k.tc)
+    k._print_status_orig = Kernel.Kernel._print_status
+    k._calc_ke_qg = k._calc_ke_niw = k._calc_pe_niw = lambda: 0.0
+    k._calc_cfl = lambda: 0.0
+    k.cflmax = 1.0
+
+    class Log(object):
+        def info(self, *a):
+            k.status.append(k.tc)
+
+        def error(self, *a):
+            return ""
+    k.logger = Log()
+    return k
+
+
+@pytest.mark.parametrize("tdiags,twrite,nsteps", [(10, 1000., 25), (1, 7, 20), (10 ** 9, 10 ** 9, 33), (4, 6., 30)])
+def test_run_loop_batches_steps_but_keeps_the_reference_event_sequence(tdiags, twrite, nsteps):
+    """run() may batch quiet steps into one nq_step call, but diagnostics ticks must fire after the steps
+    with tc_before % tdiags == 0 (Diagnostics.py:43) and status lines when tc % twrite == 0 (Kernel.py:590)."""
+    dt = 0.1
+    k = _bare_kernel(tdiags, twrite, dt, (nsteps - 0.5) * dt)
+    k.run()
+    assert k.tc == nsteps and sum(k._ctx.calls) == nsteps
+    assert k.ticks == [n for n in range(nsteps) if n % tdiags == 0]
+    assert k.status == [n for n in range(1, nsteps + 1) if n % twrite == 0]
+    if tdiags > nsteps and twrite > nsteps:
+        assert len(k._ctx.calls) <= 3          # really batched
+
+
+def test_float_clock_is_the_references():
+    """`while t < tmax: t += dt` (Kernel.py:198,:588) decides the step count, not round(tmax/dt)."""
+    k = _bare_kernel(10 ** 9, 10 ** 9, 0.1, 0.3)      # 0.1+0.1+0.1 = 0.30000000000000004 > 0.3 -> 3 steps
+    k.run()
+    t, n = 0, 0
+    while t < 0.3:
+        t += 0.1
+        n += 1
+    assert k.tc == n

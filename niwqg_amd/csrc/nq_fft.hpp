@@ -30,6 +30,16 @@ __device__ __forceinline__ cd cmul_i(cd a) { return make_double2(-a.y, a.x); }  
 __device__ __forceinline__ cd cmul_mi(cd a) { return make_double2(a.y, -a.x); }   // a * (-i)
 __device__ __forceinline__ cd cmake(double x, double y) { return make_double2(x, y); }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding
+// global load/store (s_waitcnt vmcnt(0)), which would serialise the prefetched rows behind each of the
+// FFT's exchanges.  0xC07F = lgkmcnt(0) with vmcnt/expcnt left alone.
+__device__ __forceinline__ void wg_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+}
+
+__device__ __forceinline__ void wg_barrier_all() { __syncthreads(); }   // also waits for global memory
+
 // ---- small DFTs on register arrays, natural order in and out ------------------------------
 // forward: X[k] = sum x[n] exp(-2 pi i n k / R);  INV: conjugate kernel, no scaling.
 template <bool INV> __device__ __forceinline__ cd rot90(cd a) { return INV ? cmul_i(a) : cmul_mi(a); }  // * exp(-+ i pi/2)
@@ -119,13 +129,18 @@ template <bool INV> struct Dft<16, INV> {
 };
 
 // ---- stage twiddles ----------------------------------------------------------------------------
-// v[u] *= w^u, u = 1..R-1, with w = tw[base].  Only w^1, w^4 (and w^8 for radix 16) are fetched from the
-// table; the others are products of at most two fetched/derived values (<= 2 roundings deep), which
-// keeps 15 gathered 16-byte loads and 60 VGPRs of twiddles per butterfly out of the inner loop.
+// v[u] *= w^u, u = 1..R-1.  Only w^1, w^4 (and w^8 for radix 16) come from the table; the others are
+// products of at most two fetched/derived values (<= 2 roundings deep).  The fetched values are loaded
+// ONCE per kernel into registers (WgFft::Tw): they depend on the thread and the stage only, not on the
+// field, and a global load inside the transform would make every barrier-free prefetch wait (vmcnt is
+// in order).
 template <int R, bool INV>
-__device__ __forceinline__ void twiddle_apply(cd (&v)[R], const cd* __restrict__ tw, int base) {
-  cd w1 = tw[base];
-  if (INV) w1.y = -w1.y;
+__device__ __forceinline__ void twiddle_apply(cd (&v)[R], cd w1, cd w4, cd w8) {
+  if (INV) {
+    w1.y = -w1.y;
+    w4.y = -w4.y;
+    w8.y = -w8.y;
+  }
   v[1] = cmul(v[1], w1);
   if constexpr (R >= 4) {
     const cd w2 = cmul(w1, w1);
@@ -133,15 +148,11 @@ __device__ __forceinline__ void twiddle_apply(cd (&v)[R], const cd* __restrict__
     v[2] = cmul(v[2], w2);
     v[3] = cmul(v[3], w3);
     if constexpr (R >= 8) {
-      cd w4 = tw[4 * base];
-      if (INV) w4.y = -w4.y;
       v[4] = cmul(v[4], w4);
       v[5] = cmul(v[5], cmul(w4, w1));
       v[6] = cmul(v[6], cmul(w4, w2));
       v[7] = cmul(v[7], cmul(w4, w3));
       if constexpr (R >= 16) {
-        cd w8 = tw[8 * base];
-        if (INV) w8.y = -w8.y;
         const cd w12 = cmul(w8, w4);
         v[8] = cmul(v[8], w8);
         v[9] = cmul(v[9], cmul(w8, w1));
@@ -180,6 +191,26 @@ __host__ __device__ constexpr int plan_ns(int N, int P, int stage) {   // produc
   return ns;
 }
 
+// XOR swizzle of the element index inside aligned blocks of 16 (one 256-byte LDS row): the stride-16
+// scatter of the first stage becomes conflict-free while 16 consecutive elements stay a permutation of
+// the same row, so the canonical reads stay conflict-free as well (padding misaligned their lane groups:
+// 24 % of LDS cycles were conflicts, profiles/r01_c_pmc.txt).
+__host__ __device__ constexpr int plan_max_nb(int N, int P) {     // most butterflies per thread in a stage
+  int m = 1;
+  for (int s = 0; s < plan_stages(N, P); ++s) {
+    const int nb = P / plan_radix(N, P, s);
+    m = nb > m ? nb : m;
+  }
+  return m;
+}
+__host__ __device__ constexpr int plan_max_radix(int N, int P) {
+  int m = 1;
+  for (int s = 0; s < plan_stages(N, P); ++s) m = plan_radix(N, P, s) > m ? plan_radix(N, P, s) : m;
+  return m;
+}
+
+__device__ __forceinline__ int lds_swz(int p) { return p ^ ((p >> 4) & 15); }
+// column tiles (C adjacent lines, element-major) keep the 1-in-16 padding: measured conflict-free there
 __device__ __forceinline__ int lds_pad(int p) { return p + (p >> 4); }
 template <int N> __host__ __device__ constexpr int lds_line_elems() { return N + (N >> 4) + 1; }
 
@@ -188,15 +219,82 @@ template <int N, int P, int C, bool LINE_MAJOR>
 struct WgFft {
   static constexpr int T = N / P;
   static constexpr int STAGES = plan_stages(N, P);
-  static constexpr int LDS_ELEMS = (STAGES > 1) ? lds_line_elems<N>() * C : 0;   // cd elements
+  static constexpr int LINE = LINE_MAJOR ? N : lds_line_elems<N>();
+  static constexpr int LDS_ELEMS = (STAGES > 1) ? LINE * C : 0;   // cd elements
   static_assert(N % P == 0, "P must divide N");
 
-  __device__ __forceinline__ static int lds_index(int p, int c) {
-    return LINE_MAJOR ? c * lds_line_elems<N>() + lds_pad(p) : lds_pad(p) * C + c;
+  static constexpr int NBMAX = plan_max_nb(N, P);
+  static constexpr int RMAX = plan_max_radix(N, P);
+  struct Tw {                               // per twiddled stage, per butterfly of this thread
+    cd w1[STAGES][NBMAX];
+    cd w4[RMAX >= 8 ? STAGES : 1][RMAX >= 8 ? NBMAX : 1];
+    cd w8[RMAX >= 16 ? STAGES : 1][RMAX >= 16 ? NBMAX : 1];
+  };
+
+  template <int STAGE>
+  __device__ __forceinline__ static void load_tw_from(Tw& t, int j, const cd* __restrict__ tw, int tw_step) {
+    if constexpr (STAGE < STAGES) {
+      constexpr int R = plan_radix(N, P, STAGE);
+      constexpr int NS = plan_ns(N, P, STAGE);
+      constexpr int NB = P / R;
+      if constexpr (NS > 1) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int base = ((j + b * T) % NS) * (N / (NS * R)) * tw_step;
+          t.w1[STAGE][b] = tw[base];
+          if constexpr (R >= 8) t.w4[STAGE][b] = tw[4 * base];
+          if constexpr (R >= 16) t.w8[STAGE][b] = tw[8 * base];
+        }
+      }
+      load_tw_from<STAGE + 1>(t, j, tw, tw_step);
+    }
+  }
+  // tw_step = NT / N  (table stride for w_N)
+  __device__ __forceinline__ static void load_tw(Tw& t, int j, const cd* __restrict__ tw, int tw_step) {
+    load_tw_from<0>(t, j, tw, tw_step);
   }
 
-  template <bool INV, int STAGE>
-  __device__ __forceinline__ static void stage(cd (&r)[P], int j, int c, cd* lds, const cd* __restrict__ tw, int tw_step) {
+  // Alternative twiddle source for the row kernels: per-stage tables in LDS, entry jr of stage s holds
+  // w^1 | w^4 | w^8 for butterflies with jj % NS == jr (layout: [stage][3][NS]); built on the host
+  // (nq_lib.hip: build_stage_table), copied into LDS once per workgroup.  Costs no registers and no
+  // VMEM inside the transforms.
+  __host__ __device__ static constexpr int tw_off(int stage) {
+    int o = 0;
+    for (int s = 1; s < stage; ++s) o += 3 * plan_ns(N, P, s);
+    return o;
+  }
+  static constexpr int TW_LDS_ELEMS = tw_off(STAGES);
+  struct TwLds {
+    const cd* base;
+  };
+
+  template <int STAGE>
+  __device__ __forceinline__ static void fetch_tw(const Tw& src, int b, int jr, cd& w1, cd& w4, cd& w8) {
+    constexpr int R = plan_radix(N, P, STAGE);
+    w1 = src.w1[STAGE][b];
+    w4 = cmake(1, 0);
+    w8 = cmake(1, 0);
+    if constexpr (R >= 8) w4 = src.w4[STAGE][b];
+    if constexpr (R >= 16) w8 = src.w8[STAGE][b];
+  }
+  template <int STAGE>
+  __device__ __forceinline__ static void fetch_tw(const TwLds& src, int b, int jr, cd& w1, cd& w4, cd& w8) {
+    constexpr int R = plan_radix(N, P, STAGE);
+    constexpr int NS = plan_ns(N, P, STAGE);
+    const cd* t = src.base + tw_off(STAGE);
+    w1 = t[jr];
+    w4 = cmake(1, 0);
+    w8 = cmake(1, 0);
+    if constexpr (R >= 8) w4 = t[NS + jr];
+    if constexpr (R >= 16) w8 = t[2 * NS + jr];
+  }
+
+  __device__ __forceinline__ static int lds_index(int p, int c) {
+    return LINE_MAJOR ? c * N + lds_swz(p) : lds_pad(p) * C + c;
+  }
+
+  template <bool INV, int STAGE, typename Src>
+  __device__ __forceinline__ static void stage(cd (&r)[P], int j, int c, cd* lds, const Src& twr) {
     constexpr int R = plan_radix(N, P, STAGE);
     constexpr int NS = plan_ns(N, P, STAGE);
     constexpr int NB = P / R;                     // butterflies per thread in this stage
@@ -209,54 +307,47 @@ struct WgFft {
       for (int u = 0; u < R; ++u) v[u] = r[b + u * NB];
       const int jj = j + b * T;
       const int jr = jj % NS;
-      if (NS > 1) twiddle_apply<R, INV>(v, tw, jr * (N / (NS * R)) * tw_step);
+      if constexpr (NS > 1) {
+        cd w1, w4, w8;
+        fetch_tw<STAGE>(twr, b, jr, w1, w4, w8);
+        twiddle_apply<R, INV>(v, w1, w4, w8);
+      }
       Dft<R, INV>::run(v);
       if (LAST) {
 #pragma unroll
         for (int u = 0; u < R; ++u) r[b + u * NB] = v[u];
       } else {
         const int pos = (jj / NS) * (NS * R) + jr;
-        // padded index of pos + u*NS is affine in u whenever NS % 16 == 0, or NS == 1 with R == 16
-        // (pos is then a multiple of 16); saying so lets the compiler use one address register plus
-        // immediate offsets instead of R separately computed addresses.
-        constexpr bool AFFINE = (NS % 16 == 0) || (NS == 1 && R == 16);
-        if constexpr (AFFINE) {
-          constexpr int STRIDE = (NS == 1) ? 1 : NS + NS / 16;
-          cd* dst = lds + lds_index(pos, c);
 #pragma unroll
-          for (int u = 0; u < R; ++u) dst[(LINE_MAJOR ? 1 : C) * u * STRIDE] = v[u];
-        } else {
-#pragma unroll
-          for (int u = 0; u < R; ++u) lds[lds_index(pos + u * NS, c)] = v[u];
-        }
+        for (int u = 0; u < R; ++u) lds[lds_index(pos + u * NS, c)] = v[u];
       }
     }
     if (!LAST) {
-      __syncthreads();
-      if constexpr (T % 16 == 0) {
+      wg_barrier();
+      if constexpr (LINE_MAJOR && T % 256 == 0) {
+        // (j + t*T) ^ (((j + t*T) >> 4) & 15) = swz(j) + t*T when T is a multiple of 256
         const cd* src = lds + lds_index(j, c);
 #pragma unroll
-        for (int t = 0; t < P; ++t) r[t] = src[(LINE_MAJOR ? 1 : C) * t * (T + T / 16)];
+        for (int t = 0; t < P; ++t) r[t] = src[t * T];
       } else {
 #pragma unroll
         for (int t = 0; t < P; ++t) r[t] = lds[lds_index(j + t * T, c)];
       }
-      __syncthreads();
+      wg_barrier();
     }
   }
 
-  template <bool INV, int STAGE>
-  __device__ __forceinline__ static void stages_from(cd (&r)[P], int j, int c, cd* lds, const cd* __restrict__ tw, int tw_step) {
+  template <bool INV, int STAGE, typename Src>
+  __device__ __forceinline__ static void stages_from(cd (&r)[P], int j, int c, cd* lds, const Src& twr) {
     if constexpr (STAGE < STAGES) {
-      stage<INV, STAGE>(r, j, c, lds, tw, tw_step);
-      stages_from<INV, STAGE + 1>(r, j, c, lds, tw, tw_step);
+      stage<INV, STAGE, Src>(r, j, c, lds, twr);
+      stages_from<INV, STAGE + 1, Src>(r, j, c, lds, twr);
     }
   }
 
-  // tw_step = NT / N  (table stride for w_N)
-  template <bool INV>
-  __device__ __forceinline__ static void run(cd (&r)[P], int j, int c, cd* lds, const cd* __restrict__ tw, int tw_step) {
-    stages_from<INV, 0>(r, j, c, lds, tw, tw_step);
+  template <bool INV, typename Src>
+  __device__ __forceinline__ static void run(cd (&r)[P], int j, int c, cd* lds, const Src& twr) {
+    stages_from<INV, 0, Src>(r, j, c, lds, twr);
   }
 };
 

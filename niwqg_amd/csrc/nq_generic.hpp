@@ -25,7 +25,7 @@ template <int S> struct YPlan {
 };
 
 #ifndef NQ_XP
-#define NQ_XP 16
+#define NQ_XP 8      // points per thread in the row kernels: 8 -> 512 threads per 4096-point row, no spills
 #endif
 template <int N> struct XPlan {
   static constexpr int P = (N >= 128) ? NQ_XP : 8;
@@ -33,12 +33,13 @@ template <int N> struct XPlan {
   static constexpr int C = (T >= 64) ? 1 : 64 / T;     // rows per workgroup (>= one wave)
   static constexpr int THREADS = C * T;
 #ifndef NQ_XWG
-#define NQ_XWG 2
+#define NQ_XWG 1
 #endif
   // workgroups per CU the fused row kernels are compiled for (LDS allows 2 at N = 4096)
   static constexpr int MIN_WAVES = (THREADS * NQ_XWG + 255) / 256;
   typedef WgFft<N, P, C, true> F;
-  static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cd) + 16 * C + 512;   // + per-row words + reduction scratch
+  // [exchange][stage twiddle table][per-row scratch words][reduction scratch]
+  static constexpr size_t LDS_BYTES = (size_t)(F::LDS_ELEMS + F::TW_LDS_ELEMS) * sizeof(cd) + 16 * C + 512;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char nq_smem[];
@@ -60,12 +61,12 @@ __device__ __forceinline__ void block_sum_store(double (&vals)[NV], double* scra
     }
     vals[i] = x;
   }
-  __syncthreads();
+  wg_barrier();
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = vals[i];
   }
-  __syncthreads();
+  wg_barrier();
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -87,6 +88,8 @@ k_x_c2c(const cd* __restrict__ in, cd* __restrict__ out, int pitch_in, int pitch
   const int j = threadIdx.x % T, c = threadIdx.x / T;
   const int row = blockIdx.x * X::C + c;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename XPlan<N>::F::Tw twr;
+  XPlan<N>::F::load_tw(twr, j, tw, 1);
   cd r[P];
   const bool ok = row < nrows;
 #pragma unroll
@@ -96,7 +99,7 @@ k_x_c2c(const cd* __restrict__ in, cd* __restrict__ out, int pitch_in, int pitch
     if (mul_ik) v = cscale(cmul_i(v), kk[kx]);
     r[t] = v;
   }
-  X::F::template run<INV>(r, j, c, lds, tw, 1);
+  X::F::template run<INV>(r, j, c, lds, twr);
   if (ok) {
 #pragma unroll
     for (int t = 0; t < P; ++t) out[(size_t)row * pitch_out + j + t * T] = cscale(r[t], scale);
@@ -113,11 +116,13 @@ k_x_r2c(const double* __restrict__ in, cd* __restrict__ out, int pitch_in, int p
   const int j = threadIdx.x % T, c = threadIdx.x / T;
   const int row = blockIdx.x * X::C + c;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename XPlan<N>::F::Tw twr;
+  XPlan<N>::F::load_tw(twr, j, tw, 1);
   cd r[P];
   const bool ok = row < nrows;
 #pragma unroll
   for (int t = 0; t < P; ++t) r[t] = cmake(ok ? in[(size_t)row * pitch_in + j + t * T] : 0.0, 0.0);
-  X::F::template run<false>(r, j, c, lds, tw, 1);
+  X::F::template run<false>(r, j, c, lds, twr);
   if (ok) {
 #pragma unroll
     for (int t = 0; t <= P / 2; ++t) {
@@ -138,6 +143,8 @@ k_x_c2r(const cd* __restrict__ in, double* __restrict__ out, int pitch_in, int p
   const int j = threadIdx.x % T, c = threadIdx.x / T;
   const int row = blockIdx.x * X::C + c;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename XPlan<N>::F::Tw twr;
+  XPlan<N>::F::load_tw(twr, j, tw, 1);
   cd r[P];
   const bool ok = row < nrows;
 #pragma unroll
@@ -154,7 +161,7 @@ k_x_c2r(const cd* __restrict__ in, double* __restrict__ out, int pitch_in, int p
     }
     r[t] = v;
   }
-  X::F::template run<true>(r, j, c, lds, tw, 1);
+  X::F::template run<true>(r, j, c, lds, twr);
   if (ok) {
 #pragma unroll
     for (int t = 0; t < P; ++t) out[(size_t)row * pitch_out + j + t * T] = r[t].x * scale;
@@ -183,6 +190,8 @@ k_y_A(ArrayList al, int S1, const cd* __restrict__ tw, int tw_step_N /* NT/N */)
   const bool ok = col < width;
   const int N = S1 * S2;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename Y::F::Tw twr;
+  Y::F::load_tw(twr, j, tw, tw_step_N * (N / S2));
   cd r[P];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
@@ -191,7 +200,7 @@ k_y_A(ArrayList al, int S1, const cd* __restrict__ tw, int tw_step_N /* NT/N */)
     if (INV) v = cmulc(v, tw[(size_t)(y1 * i2) * tw_step_N]);
     r[t] = v;
   }
-  Y::F::template run<INV>(r, j, c, lds, tw, tw_step_N * (N / S2));
+  Y::F::template run<INV>(r, j, c, lds, twr);
   if (ok) {
 #pragma unroll
     for (int t = 0; t < P; ++t) {
@@ -218,6 +227,8 @@ k_y_B(const cd* __restrict__ in, cd* __restrict__ out, int width, int pitch_in, 
   const bool ok = col < width;
   const int N = S1 * S2;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename Y::F::Tw twr;
+  Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
   cd r[P];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
@@ -225,7 +236,7 @@ k_y_B(const cd* __restrict__ in, cd* __restrict__ out, int width, int pitch_in, 
     const size_t row = INV ? (size_t)(l1 + S2 * i) : (size_t)(l1 * S1 + i);
     r[t] = ok ? in[row * pitch_in + col] : cmake(0, 0);
   }
-  Y::F::template run<INV>(r, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<INV>(r, j, c, lds, twr);
   if (ok) {
 #pragma unroll
     for (int t = 0; t < P; ++t) {

@@ -49,6 +49,7 @@ struct nq_ctx {
   std::vector<void*> allocs;
   // tables
   cd* tw = nullptr;
+  cd* twx = nullptr;            // per-stage twiddle table of the row-kernel plan (WgFft::tw_off layout)
   double *kk = nullptr, *ll = nullptr, *filt_h = nullptr, *filt_f = nullptr;
   cd* contour = nullptr;
   // equations
@@ -70,6 +71,7 @@ struct nq_ctx {
   double *part0W = nullptr, *part0Q = nullptr;    // partials of set_phi / set_q / nq_invert
   double *carryW = nullptr, *carryQ = nullptr;    // spectral sums of the state at the start of the next step
   double *gradS1 = nullptr, *acc = nullptr;       // stale-aware sum wv2|phih_grad|^2 ; Ke,Pw,Kw increments
+  double* bsums = nullptr;                        // [4 stages][11] reduced sums of one step
   int prof_class = -1;
   std::vector<hipEvent_t> prof_ev;               // pairs
   size_t prof_used = 0;
@@ -248,33 +250,32 @@ __global__ void k_reduce_partials(const double* __restrict__ part, int nwg, int 
   }
 }
 
+// Stage sums: one workgroup per (stage, quantity); quantity 0-2: partQ, 3-8: partW, 9-10: partX.
+// sums[stage][11]
+__global__ void k_budget_sums(BudgetAcc b, double* __restrict__ sums) {
+  __shared__ double sh[16];
+  const int s = blockIdx.x / 11, q = blockIdx.x % 11;
+  double t = 0.0;
+  if (q < 3) t = block_total(b.partQ + (size_t)s * b.nwq * 3 + q, b.nwq, 3, sh);
+  else if (b.model != NQ_MODEL_QG) {
+    if (q < 9) t = block_total(b.partW + (size_t)s * b.nww * 6 + (q - 3), b.nww, 6, sh);
+    else t = block_total(b.partX + (size_t)s * b.nwx * 2 + (q - 9), b.nwx, 2, sh);
+  }
+  if (threadIdx.x == 0) sums[s * 11 + q] = t;
+}
+
 // One ETDRK4 step's worth of budget rates -> Ke, Pw, Kw increments (ref Kernel.py:319-322, :390-392;
 // QGModel.py:355-407).  Slot s of the spectral sums = state at the start of stage s.
-__global__ void k_budget_accumulate(BudgetAcc b) {
-  __shared__ double sh[16];
-  __shared__ double sw[5][4], sj[4][2], sq[5][3], sx[4][2];
+__global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double sw[5][4], sj[4][2], sq[5][3], sx[4][2];
   const bool qg = b.model == NQ_MODEL_QG;
   for (int s = 0; s < 4; ++s) {
-    for (int q = 0; q < 3; ++q) {
-      const double t = block_total(b.partQ + (size_t)s * b.nwq * 3 + q, b.nwq, 3, sh);
-      if (threadIdx.x == 0) sq[qg ? s : s + 1][q] = t;
-    }
-    if (!qg) {
-      for (int q = 0; q < 6; ++q) {
-        const double t = block_total(b.partW + (size_t)s * b.nww * 6 + q, b.nww, 6, sh);
-        if (threadIdx.x == 0) {
-          if (q < 4) sw[s + 1][q] = t;
-          else sj[s][q - 4] = t;
-        }
-      }
-      for (int q = 0; q < 2; ++q) {
-        const double t = block_total(b.partX + (size_t)s * b.nwx * 2 + q, b.nwx, 2, sh);
-        if (threadIdx.x == 0) sx[s][q] = t;
-      }
-    }
+    for (int q = 0; q < 3; ++q) sq[qg ? s : s + 1][q] = sums[s * 11 + q];
+    for (int q = 0; q < 4; ++q) sw[s + 1][q] = sums[s * 11 + 3 + q];
+    for (int q = 0; q < 2; ++q) sj[s][q] = sums[s * 11 + 7 + q];
+    for (int q = 0; q < 2; ++q) sx[s][q] = sums[s * 11 + 9 + q];
   }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
   const double M = b.M, M2 = b.M * b.M;
   if (!qg) {
     for (int q = 0; q < 3; ++q) sq[0][q] = b.carryQ[q];
@@ -447,7 +448,7 @@ static void inv2d_half(nq_ctx* c, const cd* spec, double* phys, cd* tmp_h) {
 static void launch_wavepv(nq_ctx* c) {
   ProfScope ps(c, PK_WAVEPV);
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mphi, c->Mphiy, c->Ma, c->Mb, c->Ph, c->tw, c->kk); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mphi, c->Mphiy, c->Ma, c->Mb, c->Ph, c->twx, c->kk); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
@@ -464,7 +465,7 @@ static void launch_products_mb(nq_ctx* c, int stage) {
   bx.muw = c->p.muw;
   bx.part = BUD ? c->partX + (size_t)stage * c->nwx * 2 : nullptr;
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE, BUD>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mu, c->Mp, c->Mq, c->Mqw, c->Mphi, gx, gy, c->Muq, c->Mvq, c->Mj, c->Mr, c->Ph, c->tw, c->kk, vz, bx); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE, BUD>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mu, c->Mp, c->Mq, c->Mqw, c->Mphi, gx, gy, c->Muq, c->Mvq, c->Mj, c->Mr, c->Ph, c->twx, c->kk, vz, bx); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
@@ -624,7 +625,11 @@ static void do_step(nq_ctx* c) {
     const cd* q_bud = (!c->kernel_family && s < 3) ? c->q.y[c->q.cur] : nullptr;
     do_invert(c, c->q.y[qslot], s == 3, c->partQ + (size_t)s * c->nwq * 3, q_bud);
   }
-  if (c->bud) hipLaunchKernelGGL(k_budget_accumulate, dim3(1), dim3(1024), 0, c->stream, budget_acc(c));
+  if (c->bud) {
+    BudgetAcc ba = budget_acc(c);
+    hipLaunchKernelGGL(k_budget_sums, dim3(44), dim3(1024), 0, c->stream, ba, c->bsums);
+    hipLaunchKernelGGL(k_budget_accumulate, dim3(1), dim3(64), 0, c->stream, ba, (const double*)c->bsums);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -678,6 +683,24 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
     }
     ALLOC(c, c->tw, (size_t)N);
     HIPCHK(c, hipMemcpyAsync(c->tw, twh.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
+    {
+      // stage table for the fused row kernels: [stage >= 1][w^1 | w^4 | w^8][jr < NS]
+      const int P = (N >= 128) ? NQ_XP : 8;
+      std::vector<double> st;
+      for (int sidx = 1; sidx < plan_stages(N, P); ++sidx) {
+        const int R = plan_radix(N, P, sidx), NS = plan_ns(N, P, sidx);
+        for (int pw = 1; pw <= 8; pw *= (pw == 1 ? 4 : 2)) {          // powers 1, 4, 8
+          for (int jr = 0; jr < NS; ++jr) {
+            const long long m = ((long long)pw * jr * (N / (NS * R))) % N;
+            st.push_back(twh[2 * m]);
+            st.push_back(twh[2 * m + 1]);
+          }
+        }
+      }
+      ALLOC(c, c->twx, st.size() / 2 + 1);
+      HIPCHK(c, hipMemcpyAsync(c->twx, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     ALLOC(c, c->kk, (size_t)N);
     ALLOC(c, c->ll, (size_t)N);
     HIPCHK(c, hipMemcpyAsync(c->kk, kk, sizeof(double) * c->nk, hipMemcpyHostToDevice, c->stream));
@@ -744,6 +767,7 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
       ALLOC(c, c->part0Q, (size_t)c->nwq * 3);
       ALLOC(c, c->carryQ, (size_t)4);
       ALLOC(c, c->acc, (size_t)4);
+      ALLOC(c, c->bsums, (size_t)44);
       if (c->kernel_family) {
         c->need_diss = p->nu4w != 0.0;
         ALLOC(c, c->partX, (size_t)4 * c->nwx * 2);

@@ -19,6 +19,10 @@ namespace nq {
 
 enum { MODE_COUPLED = 0, MODE_UNCOUPLED = 1, MODE_QG = 2 };
 
+#ifndef NQ_STAGGER
+#define NQ_STAGGER 0
+#endif
+
 // Keeps hipcc from hoisting the next phase's global loads (and interleaving independent FFTs) across a
 // phase boundary of the fused row kernels: that inflates the live set past 256 VGPRs and spills.
 #define NQ_PHASE_FENCE()                      \
@@ -51,21 +55,69 @@ __device__ __forceinline__ cd pack_pair(const cd* __restrict__ rowA, const cd* _
   return cmake(a.x - b.y, a.y + b.x);
 }
 
+
+// Half-spectrum row pair held in registers between its (prefetched) load and its use.
+template <int P> struct HsRegs {
+  cd a[P / 2], b[P / 2], an, bn;      // elements m = j + t*T (t < P/2) and, for thread j = 0, m = N/2
+};
+template <int N, int P, int T, bool PAIR>
+__device__ __forceinline__ void hs_load(HsRegs<P>& r, const cd* __restrict__ rowA, const cd* __restrict__ rowB, int j) {
+#pragma unroll
+  for (int t = 0; t < P / 2; ++t) {
+    r.a[t] = rowA[j + t * T];
+    r.b[t] = PAIR ? rowB[j + t * T] : cmake(0, 0);
+  }
+  r.an = cmake(0, 0);
+  r.bn = cmake(0, 0);
+  if (j == 0) {
+    r.an = rowA[N / 2];
+    if (PAIR) r.bn = rowB[N / 2];
+  }
+}
+// Build Z = A + i*B over the full row from the registers: every half-spectrum element was fetched from
+// global memory ONCE; thread (j, t < P/2) keeps Z[m] and hands conj(A[m]) + i*conj(B[m]) = Z[N-m] to the
+// owner of position N-m through LDS (the double fetch was 0.5 GB per launch, profiles/r01_c_pmc.txt).
+template <int N, int P, int T, typename F, bool PAIR>
+__device__ __forceinline__ void hs_pack(cd (&w)[P], const HsRegs<P>& r, int j, int c, cd* lds,
+                                        const double* __restrict__ kk, bool b_mul_ik, bool b_zero_nyq) {
+#pragma unroll
+  for (int t = 0; t < P / 2; ++t) {
+    const int m = j + t * T;
+    cd a = r.a[t], b = r.b[t];
+    if (PAIR && b_mul_ik) b = cscale(cmul_i(b), kk[m]);
+    if (m == 0) {
+      a.y = 0.0;
+      b.y = 0.0;
+    }
+    w[t] = cmake(a.x - b.y, a.y + b.x);
+    if (m != 0) lds[F::lds_index(m, c)] = cmake(a.x + b.y, b.x - a.y);      // conj(a) + i conj(b)
+  }
+  if (j == 0) {                                                             // self-mirrored m = N/2
+    cd a = r.an, b = r.bn;
+    if (PAIR && b_mul_ik) b = cscale(cmul_i(b), kk[N / 2]);
+    a.y = 0.0;
+    b.y = 0.0;
+    if (b_zero_nyq) b.x = 0.0;
+    w[P / 2] = cmake(a.x - b.y, a.y + b.x);
+  }
+  wg_barrier();
+#pragma unroll
+  for (int t = P / 2; t < P; ++t) {
+    const int kx = j + t * T;
+    if (kx > N / 2) w[t] = lds[F::lds_index(N - kx, c)];
+  }
+  wg_barrier();
+}
+
 // After a forward row FFT of z = a + i*b (a, b real), split into the two half spectra and store
 // kx = 0..N/2.  Needs the mirrored element Z[N-kx], fetched through LDS.
 template <int N, int P, int T, typename F>
 __device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* lds, cd* __restrict__ rowA,
                                                   cd* __restrict__ rowB, double scaleB = 1.0) {
-  __syncthreads();
-  if constexpr (T % 16 == 0) {
-    cd* dst = lds + F::lds_index(j, c);
+  wg_barrier();
 #pragma unroll
-    for (int t = 0; t < P; ++t) dst[t * (T + T / 16)] = r[t];
-  } else {
-#pragma unroll
-    for (int t = 0; t < P; ++t) lds[F::lds_index(j + t * T, c)] = r[t];
-  }
-  __syncthreads();
+  for (int t = 0; t < P; ++t) lds[F::lds_index(j + t * T, c)] = r[t];
+  wg_barrier();
 #pragma unroll
   for (int t = 0; t <= P / 2; ++t) {
     const int kx = j + t * T;
@@ -77,13 +129,11 @@ __device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* 
       rowB[kx] = cmake(scaleB * 0.5 * (z.y + zm.y), scaleB * 0.5 * (zm.x - z.x));
     }
   }
-  __syncthreads();
+  wg_barrier();
 }
 
 // ---- X1: wave potential-vorticity sources (CoupledModel._invert, ref CoupledModel.py:59-88) ------
-// Register plan (P = 16: a complex row slice is 64 VGPRs, a real one 32): the peak is
-// a(32) + phix(64) + working(64); everything is ordered so that this stays below the 256-VGPR budget
-// of two workgroups per CU.
+// The spectral row of phi is fetched once and kept (sp) for the second transform (phix = ifft(ik phi)).
 template <int N>
 __global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
 k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __restrict__ Ma, cd* __restrict__ Mb,
@@ -95,29 +145,36 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
   const cd* __restrict__ rphi = Mphi + row * N;
   const cd* __restrict__ rphiy = Mphiy + row * N;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
-  cd w[P], gx[P];
+  // stage twiddles: table in LDS behind the exchange area (`tw` = host-built stage table here)
+  cd* twl = lds + XPlan<N>::F::LDS_ELEMS;
+  for (int i = threadIdx.x; i < XPlan<N>::F::TW_LDS_ELEMS; i += XPlan<N>::THREADS) twl[i] = tw[i];
+  typename XPlan<N>::F::TwLds twr;
+  twr.base = twl;
+  wg_barrier_all();
+  cd w[P], gx[P], py[P];
   double a[P];
 #pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = rphi[j + t * T];
+  for (int t = 0; t < P; ++t) {
+    const int kx = j + t * T;
+    w[t] = rphi[kx];
+    gx[t] = cscale(cmul_i(w[t]), kk[kx]);
+  }
+#pragma unroll
+  for (int t = 0; t < P; ++t) py[t] = rphiy[j + t * T];      // in flight during the next two transforms
   NQ_PHASE_FENCE();
-  X::F::template run<true>(w, j, c, lds, tw, 1);
+  X::F::template run<true>(w, j, c, lds, twr);
   double ma = 0.0, mb = 0.0;
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     a[t] = w[t].x * w[t].x + w[t].y * w[t].y;
     ma = fmax(ma, a[t]);
   }
-#pragma unroll
-  for (int t = 0; t < P; ++t) {
-    const int kx = j + t * T;
-    gx[t] = cscale(cmul_i(rphi[kx]), kk[kx]);
-  }
   NQ_PHASE_FENCE();
-  X::F::template run<true>(gx, j, c, lds, tw, 1);
+  X::F::template run<true>(gx, j, c, lds, twr);
 #pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = rphiy[j + t * T];
+  for (int t = 0; t < P; ++t) w[t] = py[t];
   NQ_PHASE_FENCE();
-  X::F::template run<true>(w, j, c, lds, tw, 1);
+  X::F::template run<true>(w, j, c, lds, twr);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const double b = -2.0 * (gx[t].x * w[t].y - gx[t].y * w[t].x);
@@ -127,15 +184,15 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
   // The two real fields share one complex transform; |phi|^2 is typically 1e8 times larger than
   // J(phi*,phi), so the second is rescaled per row by a power of two (exactly undone after the
   // split) to keep the roundoff of one from swamping the other.
-  unsigned long long* mx = reinterpret_cast<unsigned long long*>(lds + X::F::LDS_ELEMS) + 2 * c;
+  unsigned long long* mx = reinterpret_cast<unsigned long long*>(lds + X::F::LDS_ELEMS + X::F::TW_LDS_ELEMS) + 2 * c;
   if (j == 0) {
     mx[0] = 0ull;
     mx[1] = 0ull;
   }
-  __syncthreads();
+  wg_barrier();
   atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
   atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
-  __syncthreads();
+  wg_barrier();
   ma = __longlong_as_double((long long)mx[0]);
   mb = __longlong_as_double((long long)mx[1]);
   int e = 0;
@@ -145,7 +202,7 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
 #pragma unroll
   for (int t = 0; t < P; ++t) w[t].y *= sb;
   NQ_PHASE_FENCE();
-  X::F::template run<false>(w, j, c, lds, tw, 1);
+  X::F::template run<false>(w, j, c, lds, twr);
   NQ_PHASE_FENCE();
   unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, Ma + row * Ph, Mb + row * Ph, isb);
 }
@@ -170,89 +227,46 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
              cd* __restrict__ Mr, int Ph, const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq,
              BudgetX bx) {
   typedef XPlan<N> X;
+  typedef typename X::F F;
   constexpr int P = X::P, T = X::T;
   const int j = threadIdx.x % T, c = threadIdx.x / T;
   const size_t row = (size_t)blockIdx.x * X::C + c;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  // stage twiddles: table in LDS behind the exchange area (`tw` = host-built stage table here)
+  cd* twl = lds + XPlan<N>::F::LDS_ELEMS;
+  for (int i = threadIdx.x; i < XPlan<N>::F::TW_LDS_ELEMS; i += XPlan<N>::THREADS) twl[i] = tw[i];
+  typename XPlan<N>::F::TwLds twr;
+  twr.base = twl;
+  wg_barrier_all();
   double* red = reinterpret_cast<double*>(nq_smem + X::LDS_BYTES - 512);
   cd w[P];
-  double q[P], qpsi[P];
-  // (q, qw)
-#pragma unroll
-  for (int t = 0; t < P; ++t) {
-    if (MODE == MODE_COUPLED) {
-      w[t] = pack_pair<N>(Mq + row * Ph, Mqw + row * Ph, j + t * T, kk, false, false);
-    } else {
-      const int kx = j + t * T;
-      const bool mirror = kx > N / 2;
-      const int m = mirror ? N - kx : kx;
-      cd a = Mq[row * Ph + m];
-      if (m == 0 || m == N / 2) a.y = 0.0;
-      if (mirror) a.y = -a.y;
-      w[t] = a;
-    }
-  }
+  double q[P], qpsi[P], u[P], v[P];
+  // Software pipeline: the rows of the NEXT phase are requested before each transform and consumed after
+  // it (barriers inside the transforms no longer wait for global memory), so with one workgroup per CU
+  // the HBM latency hides behind the FFTs.  Every mixed-space input is fetched exactly once.
+  HsRegs<P> h1, h2;
+  hs_load<N, P, T, MODE == MODE_COUPLED>(h1, Mq + row * Ph, Mqw + row * Ph, j);
+  hs_load<N, P, T, true>(h2, Mu + row * Ph, Mp + row * Ph, j);
   NQ_PHASE_FENCE();
-  X::F::template run<true>(w, j, c, lds, tw, 1);
+  hs_pack<N, P, T, F, MODE == MODE_COUPLED>(w, h1, j, c, lds, kk, false, false);
+  NQ_PHASE_FENCE();
+  F::template run<true>(w, j, c, lds, twr);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     q[t] = w[t].x;
     qpsi[t] = (MODE == MODE_COUPLED) ? w[t].x - w[t].y : w[t].x;
   }
-  if (MODE != MODE_QG) {
-    // phi (physical), budget triple products, refraction source phi * q_psi
-    {
-      const cd* __restrict__ rp = Mphi + row * N;
-#pragma unroll
-      for (int t = 0; t < P; ++t) w[t] = rp[j + t * T];
-    }
-    NQ_PHASE_FENCE();
-    X::F::template run<true>(w, j, c, lds, tw, 1);
-    if (BUD) {
-      cd w2[P];
-      double acc[2] = {0.0, 0.0};
-      {
-        const cd* __restrict__ rp = bx.Mlap + row * N;
-#pragma unroll
-        for (int t = 0; t < P; ++t) w2[t] = rp[j + t * T];
-      }
-      NQ_PHASE_FENCE();
-      X::F::template run<true>(w2, j, c, lds, tw, 1);
-#pragma unroll
-      for (int t = 0; t < P; ++t) {
-        acc[0] += qpsi[t] * (w[t].x * w2[t].y - w[t].y * w2[t].x);
-        if (!bx.Mdiss)
-          acc[1] += qpsi[t] * (bx.nuw * (w2[t].x * w[t].x + w2[t].y * w[t].y) -
-                               bx.muw * (w[t].x * w[t].x + w[t].y * w[t].y));
-      }
-      if (bx.Mdiss) {
-        const cd* __restrict__ rp = bx.Mdiss + row * N;
-#pragma unroll
-        for (int t = 0; t < P; ++t) w2[t] = rp[j + t * T];
-        NQ_PHASE_FENCE();
-        X::F::template run<true>(w2, j, c, lds, tw, 1);
-#pragma unroll
-        for (int t = 0; t < P; ++t) acc[1] += qpsi[t] * (w2[t].x * w[t].x + w2[t].y * w[t].y);
-      }
-      NQ_PHASE_FENCE();
-      block_sum_store<2>(acc, red, bx.part + 2 * (size_t)blockIdx.x);
-    }
-#pragma unroll
-    for (int t = 0; t < P; ++t) w[t] = cscale(w[t], qpsi[t]);
-    NQ_PHASE_FENCE();
-    X::F::template run<false>(w, j, c, lds, tw, 1);
-    {
-      cd* __restrict__ rp = Mr + row * N;
-#pragma unroll
-      for (int t = 0; t < P; ++t) rp[j + t * T] = w[t];
-    }
-  }
   // (u, v) = ifft of (-il psi, ik psi): Mu already holds T_y^-1[-il psi], Mp holds T_y^-1[psi]
-  double u[P], v[P];
-#pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = pack_pair<N>(Mu + row * Ph, Mp + row * Ph, j + t * T, kk, true, v_zero_nyq);
   NQ_PHASE_FENCE();
-  X::F::template run<true>(w, j, c, lds, tw, 1);
+  hs_pack<N, P, T, F, true>(w, h2, j, c, lds, kk, true, v_zero_nyq != 0);
+  cd sp[P];          // spectral row of phi: kept for phix (Coupled) and for the budget's diss row
+  if (MODE != MODE_QG) {
+    const cd* __restrict__ rp = Mphi + row * N;
+#pragma unroll
+    for (int t = 0; t < P; ++t) sp[t] = rp[j + t * T];
+  }
+  NQ_PHASE_FENCE();
+  F::template run<true>(w, j, c, lds, twr);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     u[t] = w[t].x;
@@ -260,35 +274,62 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
     w[t] = cmake(u[t] * q[t], v[t] * q[t]);                  // u q + i v q
   }
   NQ_PHASE_FENCE();
-  X::F::template run<false>(w, j, c, lds, tw, 1);
+  F::template run<false>(w, j, c, lds, twr);
   NQ_PHASE_FENCE();
-  unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, Muq + row * Ph, Mvq + row * Ph);
+  unpack_pair_store<N, P, T, F>(w, j, c, lds, Muq + row * Ph, Mvq + row * Ph);
   if (MODE == MODE_QG) return;
-  // advection u phix + v phiy: w <- u*phix, then w += v*phiy with phiy in w2
-  {
-    const cd* __restrict__ rp = Mgx + row * N;
+  cd pre[P];         // prefetch buffer: Mlap (budgets), then Mgx (UnCoupled), then Mgy
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    w[t] = sp[t];
+    if (BUD) pre[t] = bx.Mlap[row * N + j + t * T];
+  }
+  NQ_PHASE_FENCE();
+  F::template run<true>(w, j, c, lds, twr);
+#pragma unroll
+  for (int t = 0; t < P; ++t) w[t] = cscale(w[t], qpsi[t]);  // refraction source phi * q_psi
+  NQ_PHASE_FENCE();
+  F::template run<false>(w, j, c, lds, twr);
+  if (BUD) {
+    // gamma1 ~ sum_x q_psi Im(conj(phi) lap phi), xi2 ~ sum_x q_psi Re(diss conj(phi))  (ref Kernel.py:691-700)
+    // by Parseval along the row: sum_x conj(r) g = sum_kx conj(R^[kx]) G[kx] with r = phi q_psi (just
+    // transformed, in w) and G the mixed-space row of g (already carries the 1/M of the inverse).
+    double acc[2] = {0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < P; ++t) {
-      const int kx = j + t * T;
-      w[t] = cscale(cmul_i(rp[kx]), kk[kx]);
+      const cd L = pre[t];
+      acc[0] += w[t].x * L.y - w[t].y * L.x;
+      cd G;
+      if (bx.Mdiss) G = bx.Mdiss[row * N + j + t * T];
+      else G = cmake(bx.nuw * L.x - bx.muw * sp[t].x, bx.nuw * L.y - bx.muw * sp[t].y);
+      acc[1] += w[t].x * G.x + w[t].y * G.y;
     }
+    NQ_PHASE_FENCE();
+    block_sum_store<2>(acc, red, bx.part + 2 * (size_t)blockIdx.x);
+  }
+  {
+    cd* __restrict__ rp = Mr + row * N;
+#pragma unroll
+    for (int t = 0; t < P; ++t) rp[j + t * T] = w[t];
+  }
+  // advection u phix + v phiy: w <- u*phix, then w += v*phiy
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int kx = j + t * T;
+    const cd g = (MODE == MODE_COUPLED) ? sp[t] : Mgx[row * N + kx];
+    w[t] = cscale(cmul_i(g), kk[kx]);
+    pre[t] = Mgy[row * N + kx];
   }
   NQ_PHASE_FENCE();
-  X::F::template run<true>(w, j, c, lds, tw, 1);
+  F::template run<true>(w, j, c, lds, twr);
 #pragma unroll
   for (int t = 0; t < P; ++t) w[t] = cscale(w[t], u[t]);
-  cd w2[P];
-  {
-    const cd* __restrict__ rp = Mgy + row * N;
-#pragma unroll
-    for (int t = 0; t < P; ++t) w2[t] = rp[j + t * T];
-  }
   NQ_PHASE_FENCE();
-  X::F::template run<true>(w2, j, c, lds, tw, 1);
+  F::template run<true>(pre, j, c, lds, twr);
 #pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = cmake(w[t].x + w2[t].x * v[t], w[t].y + w2[t].y * v[t]);
+  for (int t = 0; t < P; ++t) w[t] = cmake(w[t].x + pre[t].x * v[t], w[t].y + pre[t].y * v[t]);
   NQ_PHASE_FENCE();
-  X::F::template run<false>(w, j, c, lds, tw, 1);
+  F::template run<false>(w, j, c, lds, twr);
   {
     cd* __restrict__ rp = Mj + row * N;
 #pragma unroll
@@ -348,6 +389,8 @@ k_s_q(const cd* __restrict__ Huq, const cd* __restrict__ Hvq, EtdArrays ea, int 
   const bool ok = k < Wh;
   const int N = S1 * S2;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename Y::F::Tw twr;
+  Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
   cd f1[P], f2[P];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
@@ -355,8 +398,8 @@ k_s_q(const cd* __restrict__ Huq, const cd* __restrict__ Hvq, EtdArrays ea, int 
     f1[t] = ok ? Huq[at] : cmake(0, 0);
     f2[t] = ok ? Hvq[at] : cmake(0, 0);
   }
-  Y::F::template run<false>(f1, j, c, lds, tw, tw_step_N * (N / S1));
-  Y::F::template run<false>(f2, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<false>(f1, j, c, lds, twr);
+  Y::F::template run<false>(f2, j, c, lds, twr);
   if (!ok) return;
   const double kx = kk[k];
   const bool interior = (k > 0) && (k < N / 2);
@@ -419,6 +462,8 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
   const int N = S1 * S2;
   const bool bud = bw.part != nullptr;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename Y::F::Tw twr;
+  Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
   double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
   double* part = bud ? bw.part + 6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
   cd a[P], b[P], y[P];
@@ -428,8 +473,8 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
     a[t] = Hj[at];
     b[t] = Hr[at];
   }
-  Y::F::template run<false>(a, j, c, lds, tw, tw_step_N * (N / S1));
-  Y::F::template run<false>(b, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<false>(a, j, c, lds, twr);
+  Y::F::template run<false>(b, j, c, lds, twr);
   double sj[2] = {0.0, 0.0};
   const double kx = kk[k];
 #pragma unroll
@@ -454,8 +499,8 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
   double s4[4] = {0.0, 0.0, 0.0, 0.0};
   cd lap[P];
   phi_outputs<P, T>(y, a, b, lap, l1, S2, j, k, invM, kk, ll, bud, s4);
-  Y::F::template run<true>(a, j, c, lds, tw, tw_step_N * (N / S1));
-  Y::F::template run<true>(b, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<true>(a, j, c, lds, twr);
+  Y::F::template run<true>(b, j, c, lds, twr);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const size_t at = (size_t)(l1 * S1 + j + t * T) * N + k;
@@ -463,7 +508,7 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
     Hphiy[at] = b[t];
   }
   if (bud) {
-    Y::F::template run<true>(lap, j, c, lds, tw, tw_step_N * (N / S1));
+    Y::F::template run<true>(lap, j, c, lds, twr);
 #pragma unroll
     for (int t = 0; t < P; ++t) bw.Hlap[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
     if (bw.Hdiss) {
@@ -473,7 +518,7 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
         const double wv2 = kx * kx + ly * ly;
         lap[t] = cscale(y[t], -(bw.nu4w * wv2 * wv2 + bw.nuw * wv2 + bw.muw) * invM);
       }
-      Y::F::template run<true>(lap, j, c, lds, tw, tw_step_N * (N / S1));
+      Y::F::template run<true>(lap, j, c, lds, twr);
 #pragma unroll
       for (int t = 0; t < P; ++t) bw.Hdiss[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
     }
@@ -495,14 +540,16 @@ k_s_emit_phi(const cd* __restrict__ phih, int S2, cd* __restrict__ Hphi, cd* __r
   const int N = S1 * S2;
   const bool bud = bw.part != nullptr;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename Y::F::Tw twr;
+  Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
   double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
   cd a[P], b[P], y[P], lap[P];
 #pragma unroll
   for (int t = 0; t < P; ++t) y[t] = phih[(size_t)(l1 + S2 * (j + t * T)) * N + k];
   double s4[4] = {0.0, 0.0, 0.0, 0.0};
   phi_outputs<P, T>(y, a, b, lap, l1, S2, j, k, invM, kk, ll, bud, s4);
-  Y::F::template run<true>(a, j, c, lds, tw, tw_step_N * (N / S1));
-  Y::F::template run<true>(b, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<true>(a, j, c, lds, twr);
+  Y::F::template run<true>(b, j, c, lds, twr);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const size_t at = (size_t)(l1 * S1 + j + t * T) * N + k;
@@ -511,7 +558,7 @@ k_s_emit_phi(const cd* __restrict__ phih, int S2, cd* __restrict__ Hphi, cd* __r
   }
   if (bud) {
     const double kx = kk[k];
-    Y::F::template run<true>(lap, j, c, lds, tw, tw_step_N * (N / S1));
+    Y::F::template run<true>(lap, j, c, lds, twr);
 #pragma unroll
     for (int t = 0; t < P; ++t) bw.Hlap[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
     if (bw.Hdiss) {
@@ -521,7 +568,7 @@ k_s_emit_phi(const cd* __restrict__ phih, int S2, cd* __restrict__ Hphi, cd* __r
         const double wv2 = kx * kx + ly * ly;
         lap[t] = cscale(y[t], -(bw.nu4w * wv2 * wv2 + bw.nuw * wv2 + bw.muw) * invM);
       }
-      Y::F::template run<true>(lap, j, c, lds, tw, tw_step_N * (N / S1));
+      Y::F::template run<true>(lap, j, c, lds, twr);
 #pragma unroll
       for (int t = 0; t < P; ++t) bw.Hdiss[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
     }
@@ -552,6 +599,8 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
   const bool ok = k < Wh;
   const int N = S1 * S2;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename Y::F::Tw twr;
+  Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
   double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
   double s3[3] = {0.0, 0.0, 0.0};
   cd a[P], b[P], u[P], q[P];
@@ -562,8 +611,8 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
       a[t] = ok ? Ha[at] : cmake(0, 0);
       b[t] = ok ? Hb[at] : cmake(0, 0);
     }
-    Y::F::template run<false>(a, j, c, lds, tw, tw_step_N * (N / S1));
-    Y::F::template run<false>(b, j, c, lds, tw, tw_step_N * (N / S1));
+    Y::F::template run<false>(a, j, c, lds, twr);
+    Y::F::template run<false>(b, j, c, lds, twr);
   }
   const double kx = ok ? kk[k] : 0.0;
 #pragma unroll
@@ -621,10 +670,10 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
     q[t] = cscale(qv, invM);
     b[t] = cscale(qw, invM);
   }
-  Y::F::template run<true>(u, j, c, lds, tw, tw_step_N * (N / S1));
-  Y::F::template run<true>(a, j, c, lds, tw, tw_step_N * (N / S1));
-  Y::F::template run<true>(q, j, c, lds, tw, tw_step_N * (N / S1));
-  if (MODE == MODE_COUPLED) Y::F::template run<true>(b, j, c, lds, tw, tw_step_N * (N / S1));
+  Y::F::template run<true>(u, j, c, lds, twr);
+  Y::F::template run<true>(a, j, c, lds, twr);
+  Y::F::template run<true>(q, j, c, lds, twr);
+  if (MODE == MODE_COUPLED) Y::F::template run<true>(b, j, c, lds, twr);
   if (ok) {
 #pragma unroll
     for (int t = 0; t < P; ++t) {

@@ -34,6 +34,20 @@ X_PRODUCTS_B_PER_PT = {"coupled": 4 * 8 + 2 * 16 + 2 * 8 + 2 * 16, "uncoupled": 
 HBM_PEAK_GBS = 8000.0
 
 
+def measured_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/r01_pmc_summary.json: FETCH_SIZE/WRITE_SIZE in separate passes, FETCH doubled as the gfx950
+    note in MI355X_MICROARCH.md prescribes; same workload, same command).  None if the file is absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        for name, v in d["kernels"].items():
+            if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def c3_kwargs(nx, model):
     dt = 0.025 * TE * 128 / nx
     kw = dict(L=L, nx=nx, tmax=1e30, dt=dt, twrite=10 ** 9, tdiags=10 ** 9, use_filter=True, U=-U0)
@@ -139,7 +153,7 @@ def main():
     if rank == 0:
         npts = float(args.nx) ** 2
         k_ms = kms / max(launches, 1)
-        k_bytes = X_PRODUCTS_B_PER_PT[args.model] * npts
+        k_bytes = (X_PRODUCTS_B_PER_PT[args.model] + (16 if ctx.budgets_enabled and args.model != "qg" else 0)) * npts
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
         step_bytes = CANONICAL_B_PER_PT_STEP[args.model] * npts
         out = {
@@ -154,7 +168,9 @@ def main():
                        "device_ms_per_step_hip_events": dev_ms / args.steps,
                        "device_bytes": ctx.device_bytes()},
             "roofline": {"bound": "hbm", "kernel": "k_x_products", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic("k_x_products<%d, %d" % (args.nx, {"coupled": 0, "uncoupled": 1, "qg": 2}[args.model]))
+                         if ctx.budgets_enabled else None,
                          "launches": launches, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
                          "step_canonical_bytes": step_bytes,
                          "step_achieved_GBs": step_bytes / (wall / args.steps) / 1e9,

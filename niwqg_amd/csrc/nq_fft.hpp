@@ -209,7 +209,7 @@ __host__ __device__ constexpr int plan_max_radix(int N, int P) {
   return m;
 }
 
-__device__ __forceinline__ int lds_swz(int p) { return p ^ ((p >> 4) & 15); }
+template <int LOG> __device__ __forceinline__ int lds_swz(int p) { return p ^ ((p >> LOG) & ((1 << LOG) - 1)); }
 // column tiles (C adjacent lines, element-major) keep the 1-in-16 padding: measured conflict-free there
 __device__ __forceinline__ int lds_pad(int p) { return p + (p >> 4); }
 template <int N> __host__ __device__ constexpr int lds_line_elems() { return N + (N >> 4) + 1; }
@@ -290,7 +290,8 @@ struct WgFft {
   }
 
   __device__ __forceinline__ static int lds_index(int p, int c) {
-    return LINE_MAJOR ? c * N + lds_swz(p) : lds_pad(p) * C + c;
+    // XOR granule = first-stage radix (8 or 16): its stride-R scatter must spread over R bank groups
+    return LINE_MAJOR ? c * N + lds_swz<(plan_radix(N, P, 0) >= 16 ? 4 : 3)>(p) : lds_pad(p) * C + c;
   }
 
   template <bool INV, int STAGE, typename Src>

@@ -25,22 +25,24 @@ template <int S> struct YPlan {
 };
 
 #ifndef NQ_XP
-#define NQ_XP 8      // points per thread in the row kernels: 8 -> 512 threads per 4096-point row, no spills
+#define NQ_XP 8      // points per thread in k_x_products: 8 -> 512 threads per 4096-point row, no spills
 #endif
-template <int N> struct XPlan {
-  static constexpr int P = (N >= 128) ? NQ_XP : 8;
+#ifndef NQ_XP1
+#define NQ_XP1 16    // points per thread in k_x_wavepv (fewer live fields: 16 points, two workgroups per CU)
+#endif
+// Row-kernel plan: PP points per thread, WG workgroups per CU the kernel is compiled for.
+template <int N, int PP = NQ_XP, int WG = 1> struct XPlanT {
+  static constexpr int P = (N >= 128) ? PP : 8;
   static constexpr int T = N / P;
   static constexpr int C = (T >= 64) ? 1 : 64 / T;     // rows per workgroup (>= one wave)
   static constexpr int THREADS = C * T;
-#ifndef NQ_XWG
-#define NQ_XWG 1
-#endif
-  // workgroups per CU the fused row kernels are compiled for (LDS allows 2 at N = 4096)
-  static constexpr int MIN_WAVES = (THREADS * NQ_XWG + 255) / 256;
+  static constexpr int MIN_WAVES = (THREADS * WG + 255) / 256;
   typedef WgFft<N, P, C, true> F;
   // [exchange][stage twiddle table][per-row scratch words][reduction scratch]
   static constexpr size_t LDS_BYTES = (size_t)(F::LDS_ELEMS + F::TW_LDS_ELEMS) * sizeof(cd) + 16 * C + 512;
 };
+template <int N> using XPlan = XPlanT<N, NQ_XP, 1>;
+template <int N> using XPlan1 = XPlanT<N, NQ_XP1, 2>;
 
 extern __shared__ __attribute__((aligned(16))) unsigned char nq_smem[];
 

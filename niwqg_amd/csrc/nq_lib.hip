@@ -49,7 +49,7 @@ struct nq_ctx {
   std::vector<void*> allocs;
   // tables
   cd* tw = nullptr;
-  cd* twx = nullptr;            // per-stage twiddle table of the row-kernel plan (WgFft::tw_off layout)
+  cd *twx = nullptr, *twx1 = nullptr;   // per-stage twiddle tables of the two row-kernel plans (WgFft::tw_off layout)
   double *kk = nullptr, *ll = nullptr, *filt_h = nullptr, *filt_f = nullptr;
   cd* contour = nullptr;
   // equations
@@ -448,7 +448,7 @@ static void inv2d_half(nq_ctx* c, const cd* spec, double* phys, cd* tmp_h) {
 static void launch_wavepv(nq_ctx* c) {
   ProfScope ps(c, PK_WAVEPV);
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mphi, c->Mphiy, c->Ma, c->Mb, c->Ph, c->twx, c->kk); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mphi, c->Mphiy, c->Ma, c->Mb, c->Ph, c->twx1, c->kk); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
@@ -683,9 +683,9 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
     }
     ALLOC(c, c->tw, (size_t)N);
     HIPCHK(c, hipMemcpyAsync(c->tw, twh.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
-    {
-      // stage table for the fused row kernels: [stage >= 1][w^1 | w^4 | w^8][jr < NS]
-      const int P = (N >= 128) ? NQ_XP : 8;
+    // stage tables for the fused row kernels: [stage >= 1][w^1 | w^4 | w^8][jr < NS]
+    for (int which = 0; which < 2; ++which) {
+      const int P = (N >= 128) ? (which == 0 ? NQ_XP : NQ_XP1) : 8;
       std::vector<double> st;
       for (int sidx = 1; sidx < plan_stages(N, P); ++sidx) {
         const int R = plan_radix(N, P, sidx), NS = plan_ns(N, P, sidx);
@@ -697,8 +697,9 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
           }
         }
       }
-      ALLOC(c, c->twx, st.size() / 2 + 1);
-      HIPCHK(c, hipMemcpyAsync(c->twx, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice, c->stream));
+      cd*& dst = which == 0 ? c->twx : c->twx1;
+      ALLOC(c, dst, st.size() / 2 + 1);
+      HIPCHK(c, hipMemcpyAsync(dst, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     ALLOC(c, c->kk, (size_t)N);

@@ -135,10 +135,10 @@ __device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* 
 // ---- X1: wave potential-vorticity sources (CoupledModel._invert, ref CoupledModel.py:59-88) ------
 // The spectral row of phi is fetched once and kept (sp) for the second transform (phix = ifft(ik phi)).
 template <int N>
-__global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
+__global__ void __launch_bounds__(XPlan1<N>::THREADS, XPlan1<N>::MIN_WAVES)
 k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __restrict__ Ma, cd* __restrict__ Mb,
            int Ph, const cd* __restrict__ tw, const double* __restrict__ kk) {
-  typedef XPlan<N> X;
+  typedef XPlan1<N> X;
   constexpr int P = X::P, T = X::T;
   const int j = threadIdx.x % T, c = threadIdx.x / T;
   const size_t row = (size_t)blockIdx.x * X::C + c;
@@ -146,9 +146,9 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
   const cd* __restrict__ rphiy = Mphiy + row * N;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
   // stage twiddles: table in LDS behind the exchange area (`tw` = host-built stage table here)
-  cd* twl = lds + XPlan<N>::F::LDS_ELEMS;
-  for (int i = threadIdx.x; i < XPlan<N>::F::TW_LDS_ELEMS; i += XPlan<N>::THREADS) twl[i] = tw[i];
-  typename XPlan<N>::F::TwLds twr;
+  cd* twl = lds + XPlan1<N>::F::LDS_ELEMS;
+  for (int i = threadIdx.x; i < XPlan1<N>::F::TW_LDS_ELEMS; i += XPlan1<N>::THREADS) twl[i] = tw[i];
+  typename XPlan1<N>::F::TwLds twr;
   twr.base = twl;
   wg_barrier_all();
   cd w[P], gx[P], py[P];
@@ -159,8 +159,11 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
     w[t] = rphi[kx];
     gx[t] = cscale(cmul_i(w[t]), kk[kx]);
   }
+  constexpr bool PREFETCH = (P <= 8);       // with 16 points/thread the extra 64 VGPRs would spill
+  if (PREFETCH) {
 #pragma unroll
-  for (int t = 0; t < P; ++t) py[t] = rphiy[j + t * T];      // in flight during the next two transforms
+    for (int t = 0; t < P; ++t) py[t] = rphiy[j + t * T];      // in flight during the next two transforms
+  }
   NQ_PHASE_FENCE();
   X::F::template run<true>(w, j, c, lds, twr);
   double ma = 0.0, mb = 0.0;
@@ -172,7 +175,7 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
   NQ_PHASE_FENCE();
   X::F::template run<true>(gx, j, c, lds, twr);
 #pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = py[t];
+  for (int t = 0; t < P; ++t) w[t] = PREFETCH ? py[t] : rphiy[j + t * T];
   NQ_PHASE_FENCE();
   X::F::template run<true>(w, j, c, lds, twr);
 #pragma unroll

@@ -38,7 +38,8 @@ enum {
   NQ_F_QW = 9,     /* real               qw                                                                     */
   NQ_F_QWH = 10,   /* cplx spectral      qwh                                  CoupledModel.py:86-88            */
   NQ_F_PHIX = 11,  /* cplx               phix (as last refreshed: quirk Q1)   Kernel.py:610                    */
-  NQ_F_PHIY = 12   /* cplx               phiy                                                                   */
+  NQ_F_PHIY = 12,  /* cplx               phiy                                                                   */
+  NQ_F_QH_MINUS = 13 /* cplx half spectrum conj(qh(-l,-k)), k = 0..nx/2 (dual_q contexts only)                  */
 };
 
 /* scalar ids for nq_get_scalar */
@@ -55,7 +56,8 @@ typedef struct nq_params {
   int model;          /* NQ_MODEL_*                                                             */
   int nx;             /* grid is nx x nx (the reference ignores ny, Kernel.py:100-101)          */
   int budgets;        /* 1: accumulate Ke,Pw,Kw inside the step like Kernel.py:319-322,:390-392 */
-  int reserved;
+  int dual_q;         /* 1: keep the second q-hat copy X-(l,k) = conj(qh(-l,-k)) (needed when filtr is not
+                         mirror-symmetric, i.e. dealias=True, Kernel.py:277-281; also makes qh exact on row N/2) */
   double dt;
   double U;           /* uniform zonal flow                                                     */
   double f;           /* Coriolis                                                               */

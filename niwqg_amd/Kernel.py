@@ -44,7 +44,7 @@ class Kernel(object):
     def __init__(self, nx=128, ny=None, L=5e5, dt=10000., twrite=1000., tmax=250000., use_filter=True,
                  cflmax=0.8, U=.0, f=1.e-4, N=0.01, m=0.025, g=9.81, nu4=0, nu4w=0, nu=20, nuw=50., mu=0,
                  muw=0, dealias=False, save_to_disk=False, overwrite=True, tsave_snapshots=10, tdiags=10,
-                 path='output/', use_mkl=False, nthreads=1, device=0, budgets=True):
+                 path='output/', use_mkl=False, nthreads=1, device=0, budgets=True, exact_qh=False):
         # ref: niwqg/Kernel.py:100-137 -- note ny is ignored there too (quirk Q3)
         self.nx = nx
         self.ny = nx
@@ -70,17 +70,18 @@ class Kernel(object):
         self.use_mkl, self.nthreads = use_mkl, nthreads
         if save_to_disk:
             raise NotImplementedError("save_to_disk: HDF5 output is outside the accelerated path (SURVEY 8f)")
-        if dealias and not use_filter:
-            raise NotImplementedError(
-                "dealias=True: the reference's 2/3 mask (Kernel.py:277-281) is not mirror-symmetric, which "
-                "needs a second q-hat copy on the device; not built yet (DESIGN.md, known gaps)")
+        # The reference's 2/3 mask (Kernel.py:277-281) is not mirror-symmetric, so its q-hat is not Hermitian:
+        # the device then keeps a second half-spectrum copy ("dual copy").  exact_qh=True asks for
+        # the same with symmetric filters, which reproduces the reference's qh on the Nyquist row as well.
+        self._dual = bool(exact_qh) or (bool(dealias) and not use_filter)
 
         self._initialize_logger()
         self.logger.info(self.model)
         self._initialize_grid()
         self._initialize_filter()
         self._ctx = _lib.Context(self.model_id, nx, self.kk, self.ll, self.filtr, dt, U=U, f=f, kappa2=self.kappa2,
-                                 nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw, budgets=budgets, device=device)
+                                 nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw, budgets=budgets, device=device,
+                                 dual_q=self._dual)
         self._cache = {}
         self._user = {}
         self._initialize_time()
@@ -148,6 +149,11 @@ class Kernel(object):
             self.filtr = np.exp(-23.6 * (wvx - cphi) ** 4.)
             self.filtr[wvx <= cphi] = 1.
             self.logger.info(' Using filter')
+        elif self.dealias:
+            self.filtr = np.ones((self.nl, self.nk))
+            self.filtr[self.nx // 3:2 * self.nx // 3, :] = 0.
+            self.filtr[:, self.ny // 3:2 * self.ny // 3] = 0.
+            self.logger.info(' Dealiasing with 2/3 rule')
         else:
             self.filtr = np.ones((self.nl, self.nk))
             self.logger.info(' No dealiasing; no filter')
@@ -164,6 +170,10 @@ class Kernel(object):
             c = self._ctx
             if name == "qh":
                 v = hermitian_full(c.field(_lib.F_QH))
+                if self._dual:          # k < 0 side from the second copy: qh(-l,-k) = conj(X-(l,k))
+                    n = self.nx
+                    inner = c.field(_lib.F_QH_MINUS)[:, 1:n // 2]
+                    v[:, n // 2 + 1:] = np.conj(np.roll(inner[::-1, :], 1, axis=0))[:, ::-1]
             elif name == "ph":
                 v = hermitian_full(project_self_mirrored_columns(c.field(_lib.F_PH)))
             elif name == "qwh":

@@ -21,7 +21,7 @@ HEADERS = [os.path.join(HERE, "csrc", h) for h in ("nq_fft.hpp", "nq_generic.hpp
     os.path.join(os.path.dirname(HERE), "include", "niwqg_amd.h")]
 
 COUPLED, UNCOUPLED, QG = 0, 1, 2
-(F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY) = range(13)
+(F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY, F_QH_MINUS) = range(14)
 (S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL) = range(7)
 
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
@@ -32,7 +32,7 @@ EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_phi",
 
 class Params(ctypes.Structure):
     _fields_ = [("model", ctypes.c_int), ("nx", ctypes.c_int), ("budgets", ctypes.c_int),
-                ("reserved", ctypes.c_int), ("dt", ctypes.c_double), ("U", ctypes.c_double),
+                ("dual_q", ctypes.c_int), ("dt", ctypes.c_double), ("U", ctypes.c_double),
                 ("f", ctypes.c_double), ("kappa2", ctypes.c_double), ("nu", ctypes.c_double),
                 ("nu4", ctypes.c_double), ("mu", ctypes.c_double), ("nuw", ctypes.c_double),
                 ("nu4w", ctypes.c_double), ("muw", ctypes.c_double), ("beta", ctypes.c_double)]
@@ -103,11 +103,12 @@ class Context:
     """Thin object wrapper over nq_ctx; all arrays in and out are numpy."""
 
     def __init__(self, model, nx, kk, ll, filtr, dt, U=0.0, f=1e-4, kappa2=1.0, nu=0.0, nu4=0.0, mu=0.0,
-                 nuw=0.0, nu4w=0.0, muw=0.0, beta=0.0, budgets=True, device=0):
+                 nuw=0.0, nu4w=0.0, muw=0.0, beta=0.0, budgets=True, device=0, dual_q=False):
         self.L = lib()
         self.model, self.nx = model, int(nx)
         self.nk = nx if model != QG else nx // 2 + 1
-        p = Params(model=model, nx=nx, budgets=int(bool(budgets)), reserved=0, dt=dt, U=U, f=f, kappa2=kappa2,
+        self.dual_q = bool(dual_q) and model != QG
+        p = Params(model=model, nx=nx, budgets=int(bool(budgets)), dual_q=int(self.dual_q), dt=dt, U=U, f=f, kappa2=kappa2,
                    nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw, beta=beta)
         kk = np.ascontiguousarray(kk, dtype=np.float64)
         ll = np.ascontiguousarray(ll, dtype=np.float64)
@@ -167,7 +168,7 @@ class Context:
 
     # --- reads
     _REAL = (F_Q, F_P, F_U, F_V, F_QPSI, F_QW)
-    _HALF = (F_QH, F_PH, F_QWH)
+    _HALF = (F_QH, F_PH, F_QWH, F_QH_MINUS)
 
     def field(self, fid):
         n, h = self.nx, self.nx // 2 + 1

@@ -54,6 +54,11 @@ struct nq_ctx {
   cd* contour = nullptr;
   // equations
   EqState q, w;
+  // dual-copy q equation (dealias=True, or exact full-plane qh on request): second copy + unfolded filters
+  bool dual = false;
+  EqState q2;
+  cd* coefu[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // q coefficients without the filter
+  double* filt_m = nullptr;                                                 // filter at (-l, -k)
   // half-spectrum aux spectra
   cd *qwh = nullptr, *ph = nullptr;
   // mixed arrays
@@ -174,6 +179,20 @@ __global__ void k_spec_mul(const cd* __restrict__ in, cd* __restrict__ out, int 
     o = cmake(-wv2i * v.x, -wv2i * v.y);
   }
   out[idx] = o;
+}
+
+// out = a on the self-mirrored columns, (a + b)/2 on the interior columns (dual-copy q-hat -> Hermitian part)
+__global__ void k_avg_interior(const cd* __restrict__ a, const cd* __restrict__ b, cd* __restrict__ out, int width,
+                               int pitch, int N) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+  if (k >= width) return;
+  const size_t idx = (size_t)l * pitch + k;
+  cd v = a[idx];
+  if (k > 0 && k < N / 2) {
+    const cd w = b[idx];
+    v = cmake(0.5 * (v.x + w.x), 0.5 * (v.y + w.y));
+  }
+  out[idx] = v;
 }
 
 // reductions: sum over a real/complex plane of a pointwise expression; result in out[0..] via atomics
@@ -501,7 +520,25 @@ static EtdArrays etd_arrays(EqState& e, int stage, int* out_slot) {
 template <int S>
 static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage) {
   typedef YPlan<S> Y;
-  hipLaunchKernelGGL((k_s_q<S>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Muq, c->Mvq, ea, stage, c->Wh, c->Ph, c->S2, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1);
+  DualQ dq;
+  EtdArrays eap = ea;
+  memset(&dq, 0, sizeof(dq));
+  if (c->dual) {
+    int slot = 0;
+    dq.minus = etd_arrays(c->q2, stage, &slot);
+    dq.filt_p = c->filt_h;
+    dq.filt_m = c->filt_m;
+    const cd** dst[2] = {nullptr, nullptr};
+    (void)dst;
+    eap.E = dq.minus.E = c->coefu[0];
+    eap.Eh = dq.minus.Eh = c->coefu[1];
+    eap.Q = dq.minus.Q = c->coefu[2];
+    eap.f0 = dq.minus.f0 = c->coefu[3];
+    eap.fab = dq.minus.fab = c->coefu[4];
+    eap.fc = dq.minus.fc = c->coefu[5];
+  }
+  if (c->dual) hipLaunchKernelGGL((k_s_q<S, true>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Muq, c->Mvq, eap, stage, c->Wh, c->Ph, c->S2, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1, dq);
+  else hipLaunchKernelGGL((k_s_q<S, false>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Muq, c->Mvq, eap, stage, c->Wh, c->Ph, c->S2, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1, dq);
 }
 static BudgetW budget_w(nq_ctx* c, double* part, const cd* y_start) {
   BudgetW bw;
@@ -529,7 +566,12 @@ static void launch_emit_phi_s(nq_ctx* c, const cd* phih) {
 template <int S, int MODE>
 static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud) {
   typedef YPlan<S> Y;
-  hipLaunchKernelGGL((k_s_invert<S, MODE>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Ma, c->Mb, qh, c->filt_h, c->Mu, c->Mp, c->Mq, c->Mqw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, c->Wh, c->Ph, c->S2, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1, c->bud ? part : nullptr, q_bud);
+  // the second copy lives in the same rotating slot as qh
+  const cd* qh_minus = nullptr;
+  if (c->dual)
+    for (int i = 0; i < 3; ++i)
+      if (c->q.y[i] == qh) qh_minus = c->q2.y[i];
+  hipLaunchKernelGGL((k_s_invert<S, MODE>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Ma, c->Mb, qh, c->filt_h, c->Mu, c->Mp, c->Mq, c->Mqw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, c->Wh, c->Ph, c->S2, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1, c->bud ? part : nullptr, q_bud, qh_minus, c->dual ? c->filt_m : nullptr);
 }
 #define NQ_S1_SWITCH(c, CALL)         \
   switch ((c)->S1) {                  \
@@ -723,6 +765,20 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
     for (int i = 0; i < 6; ++i) ALLOC(c, c->q.coef[i], half);
     dim3 blk(64), grdh((c->Wh + 63) / 64, N), grdf((N + 63) / 64, N);
     hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, c->kernel_family ? 0 : 2, N, c->Wh, c->Ph, c->p, c->kk, c->ll, c->filt_h, c->contour, c->q.coef[0], c->q.coef[1], c->q.coef[2], c->q.coef[3], c->q.coef[4], c->q.coef[5]);
+    c->dual = c->kernel_family && p->dual_q != 0;
+    if (c->dual) {
+      for (int i = 0; i < 3; ++i) ALLOC(c, c->q2.y[i], half);
+      ALLOC(c, c->q2.fn0, half);
+      ALLOC(c, c->q2.fna, half);
+      for (int i = 0; i < 6; ++i) ALLOC(c, c->coefu[i], half);
+      hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, 0, N, c->Wh, c->Ph, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, c->coefu[0], c->coefu[1], c->coefu[2], c->coefu[3], c->coefu[4], c->coefu[5]);
+      std::vector<double> fm((size_t)N * c->Ph, 0.0);
+      for (int l = 0; l < N; ++l)
+        for (int k = 0; k < c->Wh; ++k) fm[(size_t)l * c->Ph + k] = filtr[(size_t)((N - l) % N) * c->nk + (N - k) % N];
+      ALLOC(c, c->filt_m, half);
+      HIPCHK(c, hipMemcpyAsync(c->filt_m, fm.data(), sizeof(double) * half, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     ALLOC(c, c->ph, half);
     ALLOC(c, c->qwh, half);
     ALLOC(c, c->Ma, half);
@@ -853,6 +909,7 @@ int nq_set_q(nq_ctx* c, const double* q_host) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(c->scr_r, q_host, sizeof(double) * full, hipMemcpyHostToDevice, c->stream));
   fwd2d_half(c, c->scr_r, c->q.y[c->q.cur], c->scr_h0);
+  if (c->dual) HIPCHK(c, hipMemcpyAsync(c->q2.y[c->q2.cur], c->q.y[c->q.cur], sizeof(cd) * (size_t)c->N * c->Ph, hipMemcpyDeviceToDevice, c->stream));
   do_invert_now(c);
   c->have_q = true;
   return nq_sync(c);
@@ -965,11 +1022,19 @@ int nq_get_field(nq_ctx* c, int id, double* host) {
   const bool waves = c->kernel_family;
   switch (id) {
     case NQ_F_QH: return get_half_spec(c, qh, host);
+    case NQ_F_QH_MINUS:
+      if (!c->dual) NQ_FAIL(c, -4, "NQ_F_QH_MINUS needs a dual_q context");
+      return get_half_spec(c, c->q2.y[c->q2.cur], host);
     case NQ_F_PH: return get_half_spec(c, c->ph, host);
     case NQ_F_QWH:
       if (c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qwh exists only in the coupled model");
       return get_half_spec(c, c->qwh, host);
-    case NQ_F_Q: return get_real_from_half(c, qh, 0, host);
+    case NQ_F_Q:
+      if (c->dual) {
+        hipLaunchKernelGGL(k_avg_interior, dim3((c->Wh + 63) / 64, c->N), dim3(64), 0, c->stream, qh, (const cd*)c->q2.y[c->q2.cur], c->scr_f1, c->Wh, c->Ph, c->N);
+        return get_real_from_half(c, c->scr_f1, 0, host);
+      }
+      return get_real_from_half(c, qh, 0, host);
     case NQ_F_P: return get_real_from_half(c, c->ph, 0, host);
     case NQ_F_U: return get_real_from_half(c, c->ph, 1, host);
     case NQ_F_V: {

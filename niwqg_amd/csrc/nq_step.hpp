@@ -379,18 +379,56 @@ __device__ __forceinline__ cd etd_update(const EtdArrays& a, size_t idx, cd Nl, 
   return y;
 }
 
+// Same update with an explicit filter factor (coefficient planes WITHOUT the filter folded in); used by the
+// dual-copy q equation where the two copies see different (mirrored) filter planes.
+__device__ __forceinline__ cd etd_update_f(const EtdArrays& a, size_t idx, cd Nl, int stage, double fl) {
+  cd y;
+  if (stage == 0) {
+    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], Nl));
+    a.fn0[idx] = Nl;
+  } else if (stage == 1) {
+    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], Nl));
+    a.fna[idx] = Nl;
+  } else if (stage == 2) {
+    const cd n0 = a.fn0[idx];
+    const cd comb = cmake(2.0 * Nl.x - n0.x, 2.0 * Nl.y - n0.y);
+    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], comb));
+    const cd na = a.fna[idx];
+    a.fna[idx] = cadd(na, Nl);
+  } else {
+    const cd n0 = a.fn0[idx], nab = a.fna[idx];
+    y = cadd(cadd(cmul(a.E[idx], a.y_in[idx]), cmul(a.f0[idx], n0)),
+             cadd(cscale(cmul(a.fab[idx], nab), 2.0), cmul(a.fc[idx], Nl)));
+  }
+  y = cscale(y, fl);
+  a.y_out[idx] = y;
+  return y;
+}
+
+// Dual-copy q equation (DESIGN.md "dual copy"): X+ = qh(l,k), X- = conj(qh(-l,-k)), k = 0..N/2.  The
+// reference's full-plane q-hat is not Hermitian when its filter is not mirror-symmetric (the 2/3 mask,
+// ref Kernel.py:277-281) and always carries an anti-Hermitian passenger on row l = N/2; both copies obey the
+// same ETDRK4 recursion with the filter taken at (l,k) and at (-l,-k), and N- = conj(N(-l,-k)) differs from
+// N+ only by the sign of the il term on row N/2.  Physical space sees (X+ + X-)/2.
+struct DualQ {
+  EtdArrays minus;          // state of X- (y_in == nullptr: single-copy mode)
+  const double* filt_p;     // filter at (l, k)
+  const double* filt_m;     // filter at (-l, -k)
+};
+
 // ---- Sq: nonlinear term + stage update of q-hat on the half spectrum --------------------------------
-template <int S1>
+template <int S1, bool DUAL>
 __global__ void __launch_bounds__(YPlan<S1>::THREADS)
 k_s_q(const cd* __restrict__ Huq, const cd* __restrict__ Hvq, EtdArrays ea, int stage, int Wh, int Ph, int S2,
       const double* __restrict__ kk, const double* __restrict__ ll, int kernel_family, const cd* __restrict__ tw,
-      int tw_step_N) {
+      int tw_step_N, DualQ dq) {
   typedef YPlan<S1> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
   const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
   const bool ok = k < Wh;
   const int N = S1 * S2;
+  constexpr bool dual = DUAL;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
   typename Y::F::Tw twr;
   Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
@@ -409,12 +447,26 @@ k_s_q(const cd* __restrict__ Huq, const cd* __restrict__ Hvq, EtdArrays ea, int 
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int l = l1 + S2 * (j + t * T);
-    double ly = ll[l];
-    if (kernel_family && interior && l == N / 2) ly = 0.0;      // see DESIGN.md "Nyquist row"
-    // N_q = -(ik F1 + il F2)
-    cd Nl = cmake(kx * f1[t].y + ly * f2[t].y, -(kx * f1[t].x + ly * f2[t].x));
-    if (kernel_family && l == 0 && k == 0) Nl = cmake(0, 0);   // jach[0,0] = 0 (QGModel does not)
-    etd_update(ea, (size_t)l * Ph + k, Nl, stage);
+    const size_t idx = (size_t)l * Ph + k;
+    const double ly = ll[l];
+    const bool pass_row = kernel_family && interior && l == N / 2;      // see DESIGN.md "Nyquist lines"
+    if constexpr (!dual) {
+      const double lz = pass_row ? 0.0 : ly;
+      // N_q = -(ik F1 + il F2)
+      cd Nl = cmake(kx * f1[t].y + lz * f2[t].y, -(kx * f1[t].x + lz * f2[t].x));
+      if (kernel_family && l == 0 && k == 0) Nl = cmake(0, 0);   // jach[0,0] = 0 (QGModel does not)
+      etd_update(ea, idx, Nl, stage);
+    } else {
+      const double lm = pass_row ? -ly : ly;
+      cd Np = cmake(kx * f1[t].y + ly * f2[t].y, -(kx * f1[t].x + ly * f2[t].x));
+      cd Nm = cmake(kx * f1[t].y + lm * f2[t].y, -(kx * f1[t].x + lm * f2[t].x));
+      if (l == 0 && k == 0) {
+        Np = cmake(0, 0);
+        Nm = cmake(0, 0);
+      }
+      etd_update_f(ea, idx, Np, stage, dq.filt_p[idx]);
+      if (interior) etd_update_f(dq.minus, idx, Nm, stage, dq.filt_m[idx]);
+    }
   }
 }
 
@@ -591,7 +643,8 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
            const double* __restrict__ filt, cd* __restrict__ Hu, cd* __restrict__ Hp, cd* __restrict__ Hq,
            cd* __restrict__ Hqw, cd* __restrict__ qwh_out, cd* __restrict__ ph_out, int Wh, int Ph, int S2,
            double invM, double f, const double* __restrict__ kk, const double* __restrict__ ll, int kernel_family,
-           const cd* __restrict__ tw, int tw_step_N, double* __restrict__ bud_part, const cd* __restrict__ q_bud) {
+           const cd* __restrict__ tw, int tw_step_N, double* __restrict__ bud_part, const cd* __restrict__ q_bud,
+           const cd* __restrict__ qh_minus, const double* __restrict__ filt_m) {
   // bud_part: [workgroup][3] Parseval sums for ep_psi (ref Kernel.py:635-640 / QGModel.py:588-593):
   //   sum w*wv4*Re(qb conj psi), sum w*wv2*Re(q conj psi), sum w*Re(qb conj psi); qb = q_bud (QGModel's
   //   stale q, QGModel.py:401) or q; w = 1 on the self-mirrored columns, 2 elsewhere.
@@ -625,13 +678,18 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
     const double ly = ll[l];
     const double wv2 = kx * kx + ly * ly;
     const double wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
-    const cd qv = ok ? qh[idx] : cmake(0, 0);
+    cd qv = ok ? qh[idx] : cmake(0, 0);
+    if (qh_minus && ok && k > 0 && k < N / 2) {          // dual copy: physical space sees the mean
+      const cd qm = qh_minus[idx];
+      qv = cmake(0.5 * (qv.x + qm.x), 0.5 * (qv.y + qm.y));
+    }
     cd qw = cmake(0, 0), psi;
     if (MODE == MODE_COUPLED) {
       cd B = b[t];
       if (l == 0 && k == 0) B = cmake(0, 0);
       const double g = 0.5 * (-wv2);
-      const double fl = ok ? filt[idx] : 0.0;
+      double fl = ok ? filt[idx] : 0.0;
+      if (filt_m && ok) fl = 0.5 * (fl + filt_m[idx]);     // Hermitian part of filtr * (Hermitian field)
       qw = cmake(0.5 * (g * a[t].x + B.x) / f * fl, 0.5 * (g * a[t].y + B.y) / f * fl);
       psi = cmake(wv2i * (qw.x - qv.x), wv2i * (qw.y - qv.y));
     } else {

@@ -261,9 +261,52 @@ def test_notebook_status_lines_and_diagnostics(golden):
     assert rel(m.q, g["final_q"]) < 1e-11 and rel(m.phi, g["final_phi"]) < 1e-11
 
 
+def test_two_thirds_dealias_golden(golden):
+    """dealias=True: the reference's mask is not mirror-symmetric, q-hat is genuinely non-Hermitian; the
+    dual-copy device path must reproduce the reference's full-plane qh, not just the physical fields."""
+    g = golden("g4_quirks_64.npz")
+    kw = notebook_kwargs(64, False)
+    kw.update(dealias=True, nu4w=1e10, mu=1e-8, muw=2e-8)
+    m = models().CoupledModel.Model(**kw)
+    m.set_q(g["rough_q0"])
+    m.set_phi(g["rough_phi0"])
+    steps(m, 5)
+    assert rel(m.q, g["rough_q"]) < 1e-11 and rel(m.phi, g["rough_phi"]) < 1e-11
+    assert rel(m.phih, g["rough_phih"]) < 1e-11
+    assert rel(m.qh, g["rough_qh"]) < 1e-11          # full plane, both signs of k, Nyquist row included
+    assert np.allclose([m.Ke, m.Pw, m.Kw], g["rough_budgets"], rtol=1e-8)
+    # and a smooth case against the oracle, UnCoupled too
+    for kind, Mod in (("coupled", models().CoupledModel), ("uncoupled", models().UnCoupledModel)):
+        kw = notebook_kwargs(64, False)
+        kw.update(dealias=True)
+        o = O.NIWQGOracle(kind, **kw)
+        mm = Mod.Model(**kw)
+        q0 = O.lamb_dipole(o.grid, U=U0, R=2 * np.pi / K0)
+        phi0 = 0.2 * O.wave_packet(o.grid, k=K0, l=K0 / 2, R=L / 6, x0=L / 2, y0=L / 2)
+        for x in (o, mm):
+            x.set_q(q0)
+            x.set_phi(phi0)
+        for _ in range(10):
+            o._step_forward()
+        steps(mm, 10)
+        assert rel(mm.q, o.q) < 1e-12 and rel(mm.phi, o.phi) < 1e-12 and rel(mm.qh, o.qh) < 1e-12, kind
+        assert np.allclose([mm.Ke, mm.Pw, mm.Kw], [o.Ke, o.Pw, o.Kw], rtol=1e-9), kind
+
+
+def test_exact_qh_option_tracks_the_nyquist_row_passenger(golden):
+    g = golden("g2_coupled_64_nofilter.npz")
+    m = models().CoupledModel.Model(exact_qh=True, **notebook_kwargs(64, False))
+    m.set_q(g["q0"])
+    m.set_phi(g["phi0"])
+    steps(m, 10)
+    assert rel(m.qh, g["qh_10"]) < 1e-12             # no row excluded
+    assert rel(m.q, g["q_10"]) < 1e-12 and rel(m.phi, g["phi_10"]) < 1e-12
+    assert np.allclose([m.Ke, m.Pw, m.Kw], g["budgets_10"], rtol=1e-9)
+
+
 def test_unsupported_options_fail_loudly():
-    with pytest.raises(NotImplementedError):
-        models().CoupledModel.Model(nx=64, use_filter=False, dealias=True)
+    with pytest.raises(TypeError):
+        models().QGModel.Model(nx=64, use_filter=False, dealias=True)     # the reference fails here too
     with pytest.raises(NotImplementedError):
         models().QGModel.Model(nx=64, passive_scalar=True)
     with pytest.raises(RuntimeError):

@@ -684,6 +684,9 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
   if (!p || !kk || !ll || !filtr || !contour || !out) NQ_FAIL((nq_ctx*)nullptr, -1, "nq_create: null argument");
   int S1, S2;
   if (!plan_for(p->nx, &S1, &S2)) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d unsupported (power of two in [64, 8192])", p->nx);
+  if (p->nx > 4096)
+    NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d: rows longer than 4096 need a split LDS exchange in the fused row "
+            "kernels (128 KB exchange + twiddle table exceed the 160 KB LDS); not built yet", p->nx);
   if (p->model < 0 || p->model > 2) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: unknown model %d", p->model);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: no HIP device available");

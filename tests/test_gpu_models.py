@@ -311,6 +311,8 @@ def test_unsupported_options_fail_loudly():
         models().QGModel.Model(nx=64, passive_scalar=True)
     with pytest.raises(RuntimeError):
         models().CoupledModel.Model(nx=96)
+    with pytest.raises(RuntimeError, match="4096"):
+        models().CoupledModel.Model(nx=8192)
 
 
 # ---- larger sizes ------------------------------------------------------------------------------------

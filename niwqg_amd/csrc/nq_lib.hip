@@ -528,8 +528,6 @@ static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage) {
     dq.minus = etd_arrays(c->q2, stage, &slot);
     dq.filt_p = c->filt_h;
     dq.filt_m = c->filt_m;
-    const cd** dst[2] = {nullptr, nullptr};
-    (void)dst;
     eap.E = dq.minus.E = c->coefu[0];
     eap.Eh = dq.minus.Eh = c->coefu[1];
     eap.Q = dq.minus.Q = c->coefu[2];

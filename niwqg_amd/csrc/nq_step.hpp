@@ -19,9 +19,6 @@ namespace nq {
 
 enum { MODE_COUPLED = 0, MODE_UNCOUPLED = 1, MODE_QG = 2 };
 
-#ifndef NQ_STAGGER
-#define NQ_STAGGER 0
-#endif
 
 // Keeps hipcc from hoisting the next phase's global loads (and interleaving independent FFTs) across a
 // phase boundary of the fused row kernels: that inflates the live set past 256 VGPRs and spills.
@@ -33,29 +30,6 @@ enum { MODE_COUPLED = 0, MODE_UNCOUPLED = 1, MODE_QG = 2 };
   } while (0)
 
 // ---- helpers for the row kernels ----------------------------------------------------------
-// Build Z = A + i*B at full-row position kx from two half-spectrum rows (Hermitian completion);
-// `a_mul_ik` multiplies B by i*kk first (for v = ifft(ik psi)).  Self-mirrored entries kx = 0, N/2
-// keep only their real part (what numpy's irfft does, and what `.real` does in the reference).
-template <int N>
-__device__ __forceinline__ cd pack_pair(const cd* __restrict__ rowA, const cd* __restrict__ rowB, int kx,
-                                        const double* __restrict__ kk, bool b_mul_ik, bool b_zero_nyq) {
-  const bool mirror = kx > N / 2;
-  const int m = mirror ? N - kx : kx;
-  cd a = rowA[m], b = rowB[m];
-  if (b_mul_ik) b = cscale(cmul_i(b), kk[m]);
-  if (m == 0 || m == N / 2) {
-    a.y = 0.0;
-    b.y = 0.0;
-    if (b_zero_nyq && m == N / 2) b.x = 0.0;
-  }
-  if (mirror) {
-    a.y = -a.y;
-    b.y = -b.y;
-  }
-  return cmake(a.x - b.y, a.y + b.x);
-}
-
-
 // Half-spectrum row pair held in registers between its (prefetched) load and its use.
 template <int P> struct HsRegs {
   cd a[P / 2], b[P / 2], an, bn;      // elements m = j + t*T (t < P/2) and, for thread j = 0, m = N/2

@@ -49,7 +49,8 @@ enum {
   NQ_S_KE_QG = 3,                          /* _calc_ke_qg()                        Kernel.py:600-602 */
   NQ_S_KE_NIW = 4,                         /* _calc_ke_niw()                       Kernel.py:604-606 */
   NQ_S_PE_NIW = 5,                         /* _calc_pe_niw() (no side effect here) Kernel.py:608-611 */
-  NQ_S_CFL = 6                             /* _calc_cfl()                          Kernel.py:660-662 */
+  NQ_S_CFL = 6                             /* max(|u|,|v|,|phi|): _calc_cfl() without the dt/dx factor
+                                                                                   Kernel.py:660-662 */
 };
 
 typedef struct nq_params {

@@ -331,7 +331,7 @@ class Kernel(object):
 
     def _calc_cfl(self):
         """ref: niwqg/Kernel.py:660-662"""
-        return np.abs(np.hstack([self.u, self.v, np.abs(self.phi)])).max() * self.dt / self.dx
+        return self._ctx.scalar(_lib.S_CFL) * self.dt / self.dx      # max reduction on the device
 
     def _calc_ens(self):
         return 0.5 * (self.q ** 2).mean()

@@ -224,7 +224,7 @@ class Model(object):
         return -self.nu4 * self.spec_var(self.wv2 * self.qh)
 
     def _calc_cfl(self):
-        return np.abs(np.hstack([self.u, self.v])).max() * self.dt / self.dx
+        return self._ctx.scalar(_lib.S_CFL) * self.dt / self.dx      # max reduction on the device
 
     def _initialize_diagnostics(self):
         """ref: niwqg/QGModel.py:632-722 (the passive-scalar entries report zeros, as the reference

@@ -1096,6 +1096,18 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
     *out = 0.5 * h[0] / (M * M);
     return rc;
   }
+  if (!c->kernel_family && id == NQ_S_CFL) {
+    const size_t full = (size_t)N * N;
+    for (int which = 0; which < 2; ++which) {        // QGModel._calc_cfl: literal irfft2 (QGModel.py:621-629)
+      hipLaunchKernelGGL(k_spec_mul, dim3((c->Wh + 63) / 64, N), dim3(64), 0, c->stream, c->ph, c->scr_h1, c->Wh, c->Ph, which == 0 ? 1 : 2, c->kk, c->ll, N, 0);
+      inv2d_half(c, c->scr_h1, c->scr_r, c->scr_f1);
+      hipLaunchKernelGGL(k_reduce_real_max, dim3(1024), dim3(256), 0, c->stream, c->scr_r, full, d);
+    }
+    HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    int rc = nq_sync(c);
+    *out = h[0];
+    return rc;
+  }
   if (!c->kernel_family) NQ_FAIL(c, -4, "scalar %d needs the wave field", id);
   const cd* phih = c->w.y[c->w.cur];
   if (id == NQ_S_KE_NIW || id == NQ_S_PE_NIW) {
@@ -1103,6 +1115,22 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
     HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     int rc = nq_sync(c);
     *out = (id == NQ_S_KE_NIW) ? 0.5 * h[0] / (M * M) : 0.25 * h[0] / (M * M) / c->p.kappa2;
+    return rc;
+  }
+  if (id == NQ_S_CFL) {
+    // max(|u|, |v|, |phi|) on the device (the caller multiplies by dt/dx): ref Kernel.py:660-662
+    const size_t full = (size_t)N * N;
+    for (int which = 0; which < 2; ++which) {
+      hipLaunchKernelGGL(k_spec_mul, dim3((c->Wh + 63) / 64, N), dim3(64), 0, c->stream, c->ph, c->scr_h1, c->Wh, c->Ph, which == 0 ? 1 : 2, c->kk, c->ll, N, 1);
+      if (which == 1 && c->kernel_family) HIPCHK(c, hipMemset2DAsync(c->scr_h1 + N / 2, sizeof(cd) * c->Ph, 0, sizeof(cd), N, c->stream));
+      inv2d_half(c, c->scr_h1, c->scr_r, c->scr_f1);
+      hipLaunchKernelGGL(k_reduce_real_max, dim3(1024), dim3(256), 0, c->stream, c->scr_r, full, d);
+    }
+    launch_x_c2c(c, true, c->Mphi, c->scr_f0, N, N, 1.0);
+    hipLaunchKernelGGL(k_reduce, dim3((N + 255) / 256, N), dim3(256), 0, c->stream, c->scr_f0, N, N, N, 3, c->kk, c->ll, d);
+    HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    int rc = nq_sync(c);
+    *out = h[0];
     return rc;
   }
   NQ_FAIL(c, -1, "nq_get_scalar: id %d not available", id);

@@ -68,6 +68,10 @@ def test_initial_inversion_and_fields():
     assert rel(ctx.field(_lib.F_QW), orc.qw) < 1e-13
     assert rel(ctx.field(_lib.F_PHIX), orc.phix) < 1e-13
     assert rel(ctx.field(_lib.F_PHIY), orc.phiy) < 1e-13
+    assert abs(ctx.scalar(_lib.S_CFL) * orc.dt / orc.dx - orc._calc_cfl()) < 1e-13 * orc._calc_cfl()
+    assert abs(ctx.scalar(_lib.S_KE_QG) - orc._calc_ke_qg()) < 1e-13 * orc._calc_ke_qg()
+    assert abs(ctx.scalar(_lib.S_KE_NIW) - orc._calc_ke_niw()) < 1e-13 * orc._calc_ke_niw()
+    assert abs(ctx.scalar(_lib.S_PE_NIW) - orc._calc_pe_niw()) < 1e-13 * orc._calc_pe_niw()
     f1, f2 = ctx.products_uq_vq()
     assert rel(f1, np.fft.rfft2(orc.u * orc.q)) < 1e-13
     assert rel(f2, np.fft.rfft2(orc.v * orc.q)) < 1e-13

@@ -115,6 +115,36 @@ int nq_jacobian_phic_phi(nq_ctx* ctx, double* out_cplx);
  * without the filter folded in; host layout as the reference's expch, expch_h, Qh, f0, fab, fc.      */
 int nq_get_coeff(nq_ctx* ctx, int eq, int which, double* out_cplx);
 
+/* ---- 1-D slab decomposition over nranks GPUs (one process per GPU) -----------------
+ * Rows of the mixed-space planes are split over ranks on the "x side" (row kernels), columns on the "y side"
+ * (spectral kernels).  Arrays that cross together form an exchange group g = 0..3; each group has an x-side
+ * and a y-side buffer of nq_group_elems() complex128 elements, both cut into nranks equal blocks, so that ONE
+ * all_to_all_single(recv = other side, send = this side) moves the group.  The caller owns the collectives
+ * (torch.distributed / RCCL); the library only runs the phases in between, on the stream it was given.
+ *   buffers[2g], buffers[2g+1] : x-side and y-side device buffers of group g (may be NULL for empty groups)
+ *   buffers[8]                 : 64 doubles for the per-step budget sums (summed over ranks by the caller)  */
+long long nq_group_elems(const nq_params* p, int nranks, int group);
+int nq_create_slab(const nq_params* p, const double* kk, const double* ll, const double* filtr,
+                   const double* contour, int device, int nranks, int rank, void* const* buffers, void* stream,
+                   nq_ctx** out);
+int nq_slab_info(const nq_ctx* ctx, int* info8);
+int nq_group_buffers(nq_ctx* ctx, int group, void** x_side, void** y_side, long long* elems);
+/* local column slab of qh (which 0: (ny, local half-spectrum columns)) or phih (which 1: (ny, nx/nranks)) */
+int nq_upload_spectral(nq_ctx* ctx, int which, const double* host);
+int nq_download_spectral(nq_ctx* ctx, int which, double* host);
+enum {
+  NQ_PH_PRODUCTS = 0,      /* rows: nonlinear products (Kernel.py:471-486,:457-469,:332)   then exchange group 0 (x->y) */
+  NQ_PH_UPDATE = 1,        /* spectral: N_q, N_phi, ETDRK4 stage update                    then group 1 (y->x) [+3]    */
+  NQ_PH_WAVEPV = 2,        /* rows: wave-PV sources (CoupledModel.py:59-88)                then group 2 (x->y)         */
+  NQ_PH_INVERT = 3,        /* spectral: psi inversion (CoupledModel.py:75-97)              then group 3 (y->x)         */
+  NQ_PH_EMIT_PHI = 4,      /* after uploading phih (set_phi)                               then group 1 (y->x)         */
+  NQ_PH_INVERT_NOW = 5,    /* inversion of the current qh (set_q)                          then group 3 (y->x)         */
+  NQ_PH_BUDGET_SUMS = 6,   /* local budget sums of the finished step                       then all-reduce buffer 0    */
+  NQ_PH_BUDGET_FINISH = 7  /* Ke, Pw, Kw increments from the reduced sums (Kernel.py:390-392)                          */
+};
+int nq_phase(nq_ctx* ctx, int phase, int stage);
+int nq_reduce_buffer(nq_ctx* ctx, int which, void** device_ptr, int* count);
+
 /* timing of the hot loop with HIP events on the context's stream */
 int nq_timer_start(nq_ctx* ctx);
 int nq_timer_stop(nq_ctx* ctx, float* elapsed_ms);

@@ -27,7 +27,9 @@ COUPLED, UNCOUPLED, QG = 0, 1, 2
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
            "nq_step", "nq_sync", "nq_get_field", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
            "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_get_coeff",
-           "nq_timer_start", "nq_timer_stop", "nq_profile_enable", "nq_profile_read", "nq_device_bytes", "nq_stream"]
+           "nq_timer_start", "nq_timer_stop", "nq_profile_enable", "nq_profile_read", "nq_group_elems", "nq_create_slab",
+           "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
+           "nq_reduce_buffer", "nq_device_bytes", "nq_stream"]
 
 
 class Params(ctypes.Structure):
@@ -87,6 +89,17 @@ def lib():
     L.nq_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.nq_profile_enable.argtypes = [vp, ctypes.c_int]
     L.nq_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)]
+    L.nq_group_elems.argtypes = [ctypes.POINTER(Params), ctypes.c_int, ctypes.c_int]
+    L.nq_group_elems.restype = ctypes.c_longlong
+    L.nq_create_slab.argtypes = [ctypes.POINTER(Params), dp, dp, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                 ctypes.POINTER(vp), vp, ctypes.POINTER(vp)]
+    L.nq_slab_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
+    L.nq_group_buffers.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                   ctypes.POINTER(ctypes.c_longlong)]
+    L.nq_upload_spectral.argtypes = [vp, ctypes.c_int, dp]
+    L.nq_download_spectral.argtypes = [vp, ctypes.c_int, dp]
+    L.nq_phase.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.nq_reduce_buffer.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
     L.nq_device_bytes.argtypes = [vp]
     L.nq_device_bytes.restype = ctypes.c_longlong
     L.nq_stream.argtypes = [vp]

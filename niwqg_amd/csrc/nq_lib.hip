@@ -29,6 +29,9 @@ static thread_local std::string g_last_error;
     if (e_ != hipSuccess) NQ_FAIL(ctx, -5, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+#define NQ_SINGLE_RANK(c, what) \
+  if ((c)->P != 1) NQ_FAIL(c, -4, what ": not available on a slab context (nranks > 1)")
+
 // ---------------------------------------------------------------------------------------------
 struct EqState {           // ETDRK4 state of one equation
   cd* y[3] = {nullptr, nullptr, nullptr};   // rotating: y[cur] = y(t_n)
@@ -39,7 +42,10 @@ struct EqState {           // ETDRK4 state of one equation
 
 struct nq_ctx {
   nq_params p;
-  int N = 0, S1 = 0, S2 = 0, Wh = 0, Ph = 0, nk = 0;
+  int N = 0, S1 = 0, S2 = 0, nk = 0;
+  int WhG = 0;           // global half-spectrum width N/2+1
+  int Wh = 0, Ph = 0;    // valid local half-spectrum columns and their pitch (== WhG, N/2+8 when P == 1)
+  bool own_stream = true;
   bool kernel_family = true;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -61,16 +67,25 @@ struct nq_ctx {
   double* filt_m = nullptr;                                                 // filter at (-l, -k)
   // half-spectrum aux spectra
   cd *qwh = nullptr, *ph = nullptr;
-  // mixed arrays
-  cd *Mphi = nullptr, *Mphiy = nullptr, *Mgx = nullptr, *Mgy = nullptr, *Mj = nullptr, *Mr = nullptr;   // full width
-  cd *Ma = nullptr, *Mb = nullptr, *Mu = nullptr, *Mp = nullptr, *Mq = nullptr, *Mqw = nullptr, *Muq = nullptr,
-     *Mvq = nullptr;                                                                                     // half width
+  // slab decomposition; P == 1: one rank owns everything
+  int P = 1, rank = 0;
+  int Nloc = 0;          // local rows on the X side
+  int Wf = 0, kf0 = 0;   // full-width planes: local columns, first global column
+  int Wl = 0, kh0 = 0;   // half-spectrum planes: columns per rank, first global column of this rank
+  // exchange groups: G[0] X->Y {Muq,Mvq,Mj,Mr}, G[1] Y->X {Mphi,Mphiy,Mlap,Mdiss}, G[2] X->Y {Ma,Mb},
+  // G[3] Y->X {Mu,Mp,Mq,Mqw}; Gs = stale copy of G[1]'s X side (UnCoupled's frozen phix/phiy, quirk Q1)
+  struct Group {
+    cd *bx = nullptr, *by = nullptr;
+    int pitch = 0;
+    size_t elems = 0;
+  } G[4];
+  cd* Gs = nullptr;
+  MArr mUq, mVq, mJ, mR, mPhi, mPhiy, mLap, mDiss, mGx, mGy, mA, mB, mU, mP, mQ, mQw;
   // scratch for the generic transforms / downloads
   cd *scr_f0 = nullptr, *scr_f1 = nullptr, *scr_h0 = nullptr, *scr_h1 = nullptr;
   double* scr_r = nullptr;
   // in-step budget integrals (ref Kernel.py:319-322, :390-392)
   bool bud = false, need_diss = false;
-  cd *Mlap = nullptr, *Mdiss = nullptr;
   int nwx = 0, nww = 0, nwq = 0;                  // workgroups of the three kernels that emit partial sums
   double *partX = nullptr, *partW = nullptr, *partQ = nullptr;   // [4 stages][workgroups][2 | 6 | 3]
   double *part0W = nullptr, *part0Q = nullptr;    // partials of set_phi / set_q / nq_invert
@@ -113,13 +128,13 @@ __device__ __forceinline__ cd cdiv(cd a, cd b) {
   return cmake((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
 }
 
-__global__ void k_etdrk4_coeffs(int eq, int N, int width, int pitch, nq_params p, const double* __restrict__ kk,
+__global__ void k_etdrk4_coeffs(int eq, int N, int width, int pitch, int k0, nq_params p, const double* __restrict__ kk,
                                 const double* __restrict__ ll, const double* __restrict__ filt,
                                 const cd* __restrict__ contour, cd* E, cd* Eh, cd* Q, cd* f0, cd* fab, cd* fc) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int l = blockIdx.y;
   if (k >= width) return;
-  const double kx = kk[k], ly = ll[l];
+  const double kx = kk[k0 + k], ly = ll[l];
   const double wv2 = kx * kx + ly * ly, wv4 = wv2 * wv2;
   cd c;
   if (eq == 0) {
@@ -401,9 +416,18 @@ static void launch_A_s(nq_ctx* c, bool inv, const ArrayList& al, int n, int maxw
   if (inv) hipLaunchKernelGGL((k_y_A<S, true>), grid, block, Y::LDS_BYTES, c->stream, al, c->S1, c->tw, 1);
   else hipLaunchKernelGGL((k_y_A<S, false>), grid, block, Y::LDS_BYTES, c->stream, al, c->S1, c->tw, 1);
 }
-// A sub-pass on a list of arrays; `half[i]` selects half-spectrum geometry
-static void launch_A(nq_ctx* c, bool inv, std::initializer_list<cd*> arrs, bool half) {
+static void launch_A_list(nq_ctx* c, bool inv, const ArrayList& al, int n, int maxw) {
   ProfScope ps(c, PK_A);
+  switch (c->S2) {
+    case 8: launch_A_s<8>(c, inv, al, n, maxw); break;
+    case 16: launch_A_s<16>(c, inv, al, n, maxw); break;
+    case 32: launch_A_s<32>(c, inv, al, n, maxw); break;
+    case 64: launch_A_s<64>(c, inv, al, n, maxw); break;
+    case 128: launch_A_s<128>(c, inv, al, n, maxw); break;
+  }
+}
+// A sub-pass on plain arrays (generic path, P == 1): half-spectrum or full-plane geometry
+static void launch_A(nq_ctx* c, bool inv, std::initializer_list<cd*> arrs, bool half) {
   ArrayList al;
   int n = 0, maxw = 0;
   for (cd* a : arrs) {
@@ -414,32 +438,49 @@ static void launch_A(nq_ctx* c, bool inv, std::initializer_list<cd*> arrs, bool 
     ++n;
   }
   for (int i = n; i < 6; ++i) { al.ptr[i] = nullptr; al.width[i] = 0; al.pitch[i] = 0; }
-  switch (c->S2) {
-    case 8: launch_A_s<8>(c, inv, al, n, maxw); break;
-    case 16: launch_A_s<16>(c, inv, al, n, maxw); break;
-    case 32: launch_A_s<32>(c, inv, al, n, maxw); break;
-    case 64: launch_A_s<64>(c, inv, al, n, maxw); break;
-    case 128: launch_A_s<128>(c, inv, al, n, maxw); break;
+  launch_A_list(c, inv, al, n, maxw);
+}
+// local valid width of a mixed-space array on the Y side
+static int y_width(const nq_ctx* c, const MArr& m) {
+  if (m.W == c->Wf) return c->Wf;
+  const int left = c->WhG - c->kh0;
+  return left < 0 ? 0 : (left < c->Wl ? left : c->Wl);
+}
+// A sub-pass on the Y side of exchange-group arrays
+static void launch_A_m(nq_ctx* c, bool inv, std::initializer_list<const MArr*> arrs) {
+  ArrayList al;
+  int n = 0, maxw = 0;
+  for (const MArr* m : arrs) {
+    al.ptr[n] = m->ys;
+    al.width[n] = y_width(c, *m);
+    al.pitch[n] = m->pitch;
+    maxw = al.width[n] > maxw ? al.width[n] : maxw;
+    ++n;
   }
+  for (int i = n; i < 6; ++i) { al.ptr[i] = nullptr; al.width[i] = 0; al.pitch[i] = 0; }
+  if (maxw > 0) launch_A_list(c, inv, al, n, maxw);
 }
 template <int S>
-static void launch_B_s(nq_ctx* c, bool inv, const cd* in, cd* out, int width, int pitch, double scale) {
+static void launch_B_s(nq_ctx* c, bool inv, const cd* in, int pin, cd* out, int pout, int width, double scale) {
   typedef YPlan<S> Y;
   dim3 grid((width + CL - 1) / CL, c->S2), block(Y::THREADS);
-  if (inv) hipLaunchKernelGGL((k_y_B<S, true>), grid, block, Y::LDS_BYTES, c->stream, in, out, width, pitch, pitch, c->S2, scale, c->tw, 1);
-  else hipLaunchKernelGGL((k_y_B<S, false>), grid, block, Y::LDS_BYTES, c->stream, in, out, width, pitch, pitch, c->S2, scale, c->tw, 1);
+  if (inv) hipLaunchKernelGGL((k_y_B<S, true>), grid, block, Y::LDS_BYTES, c->stream, in, out, width, pin, pout, c->S2, scale, c->tw, 1);
+  else hipLaunchKernelGGL((k_y_B<S, false>), grid, block, Y::LDS_BYTES, c->stream, in, out, width, pin, pout, c->S2, scale, c->tw, 1);
+}
+static void launch_B_p(nq_ctx* c, bool inv, const cd* in, int pin, cd* out, int pout, int width, double scale) {
+  switch (c->S1) {
+    case 8: launch_B_s<8>(c, inv, in, pin, out, pout, width, scale); break;
+    case 16: launch_B_s<16>(c, inv, in, pin, out, pout, width, scale); break;
+    case 32: launch_B_s<32>(c, inv, in, pin, out, pout, width, scale); break;
+    case 64: launch_B_s<64>(c, inv, in, pin, out, pout, width, scale); break;
+  }
 }
 static void launch_B(nq_ctx* c, bool inv, const cd* in, cd* out, bool half, double scale) {
   const int width = half ? c->Wh : c->N, pitch = half ? c->Ph : c->N;
-  switch (c->S1) {
-    case 8: launch_B_s<8>(c, inv, in, out, width, pitch, scale); break;
-    case 16: launch_B_s<16>(c, inv, in, out, width, pitch, scale); break;
-    case 32: launch_B_s<32>(c, inv, in, out, width, pitch, scale); break;
-    case 64: launch_B_s<64>(c, inv, in, out, width, pitch, scale); break;
-  }
+  launch_B_p(c, inv, in, pitch, out, pitch, width, scale);
 }
 
-// whole 2-D transforms on device arrays (generic path) --------------------------------------------
+// whole 2-D transforms on device arrays (generic path, P == 1) -------------------------------------
 // complex physical (N,N) -> spectral (N,N), unnormalised; `tmp` is a full-plane scratch
 static void fwd2d_full(nq_ctx* c, const cd* phys, cd* spec, cd* tmp) {
   launch_x_c2c(c, false, phys, tmp, c->N, c->N, 1.0);
@@ -463,28 +504,50 @@ static void inv2d_half(nq_ctx* c, const cd* spec, double* phys, cd* tmp_h) {
   launch_x_c2r(c, tmp_h, phys, 1.0);
 }
 
+// column-slab geometry of the spectral kernels
+static YGeom geom_half(const nq_ctx* c) {
+  YGeom g;
+  g.k0 = c->kh0;
+  const int left = c->WhG - c->kh0;
+  g.width = left < 0 ? 0 : (left < c->Wl ? left : c->Wl);
+  g.pitch_s = c->Ph;
+  g.S2 = c->S2;
+  g.kernel_family = c->kernel_family ? 1 : 0;
+  return g;
+}
+static YGeom geom_full(const nq_ctx* c) {
+  YGeom g;
+  g.k0 = c->kf0;
+  g.width = c->Wf;
+  g.pitch_s = c->Wf;
+  g.S2 = c->S2;
+  g.kernel_family = 1;
+  return g;
+}
+
 // fused-stage launches ----------------------------------------------------------------------------
 static void launch_wavepv(nq_ctx* c) {
   ProfScope ps(c, PK_WAVEPV);
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mphi, c->Mphiy, c->Ma, c->Mb, c->Ph, c->twx1, c->kk); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx1, c->kk); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
 }
 template <int MODE, bool BUD>
 static void launch_products_mb(nq_ctx* c, int stage) {
-  const cd* gx = (MODE == MODE_UNCOUPLED) ? c->Mgx : c->Mphi;
-  const cd* gy = (MODE == MODE_UNCOUPLED) ? c->Mgy : c->Mphiy;
   const int vz = c->kernel_family ? 1 : 0;
   BudgetX bx;
-  bx.Mlap = c->Mlap;
-  bx.Mdiss = c->need_diss ? c->Mdiss : nullptr;
+  bx.Mlap = c->mLap;
+  bx.Mdiss = c->mDiss;
+  bx.has_diss = c->need_diss ? 1 : 0;
   bx.nuw = c->p.nuw;
   bx.muw = c->p.muw;
   bx.part = BUD ? c->partX + (size_t)stage * c->nwx * 2 : nullptr;
+  const MArr& gx = (MODE == MODE_UNCOUPLED) ? c->mGx : c->mPhi;
+  const MArr& gy = (MODE == MODE_UNCOUPLED) ? c->mGy : c->mPhiy;
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE, BUD>), dim3(c->N / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->Mu, c->Mp, c->Mq, c->Mqw, c->Mphi, gx, gy, c->Muq, c->Mvq, c->Mj, c->Mr, c->Ph, c->twx, c->kk, vz, bx); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE, BUD>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mJ, c->mR, c->twx, c->kk, vz, bx); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
@@ -535,15 +598,19 @@ static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage) {
     eap.fab = dq.minus.fab = c->coefu[4];
     eap.fc = dq.minus.fc = c->coefu[5];
   }
-  if (c->dual) hipLaunchKernelGGL((k_s_q<S, true>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Muq, c->Mvq, eap, stage, c->Wh, c->Ph, c->S2, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1, dq);
-  else hipLaunchKernelGGL((k_s_q<S, false>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Muq, c->Mvq, eap, stage, c->Wh, c->Ph, c->S2, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1, dq);
+  const YGeom g = geom_half(c);
+  if (g.width <= 0) return;
+  const dim3 grid((g.width + CL - 1) / CL, c->S2), block(Y::THREADS);
+  if (c->dual) hipLaunchKernelGGL((k_s_q<S, true>), grid, block, Y::LDS_BYTES, c->stream, c->mUq, c->mVq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq);
+  else hipLaunchKernelGGL((k_s_q<S, false>), grid, block, Y::LDS_BYTES, c->stream, c->mUq, c->mVq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq);
 }
 static BudgetW budget_w(nq_ctx* c, double* part, const cd* y_start) {
   BudgetW bw;
   bw.part = c->bud ? part : nullptr;
   bw.y_start = y_start;
-  bw.Hlap = c->Mlap;
-  bw.Hdiss = c->need_diss ? c->Mdiss : nullptr;
+  bw.Hlap = c->mLap;
+  bw.Hdiss = c->mDiss;
+  bw.has_diss = c->need_diss ? 1 : 0;
   bw.nu4w = c->p.nu4w;
   bw.nuw = c->p.nuw;
   bw.muw = c->p.muw;
@@ -553,13 +620,13 @@ template <int S>
 static void launch_sphi_s(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_start) {
   typedef YPlan<S> Y;
   BudgetW bw = budget_w(c, c->partW + (size_t)stage * c->nww * 6, y_start);
-  hipLaunchKernelGGL((k_s_phi<S>), dim3(c->N / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Mj, c->Mr, ea, stage, c->S2, c->Mphi, c->Mphiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
+  hipLaunchKernelGGL((k_s_phi<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mJ, c->mR, ea, stage, geom_full(c), c->mPhi, c->mPhiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
 template <int S>
 static void launch_emit_phi_s(nq_ctx* c, const cd* phih) {
   typedef YPlan<S> Y;
   BudgetW bw = budget_w(c, c->part0W, phih);
-  hipLaunchKernelGGL((k_s_emit_phi<S>), dim3(c->N / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, phih, c->S2, c->Mphi, c->Mphiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
+  hipLaunchKernelGGL((k_s_emit_phi<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, phih, geom_full(c), c->mPhi, c->mPhiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
 template <int S, int MODE>
 static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud) {
@@ -569,7 +636,9 @@ static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux, double* pa
   if (c->dual)
     for (int i = 0; i < 3; ++i)
       if (c->q.y[i] == qh) qh_minus = c->q2.y[i];
-  hipLaunchKernelGGL((k_s_invert<S, MODE>), dim3((c->Wh + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->Ma, c->Mb, qh, c->filt_h, c->Mu, c->Mp, c->Mq, c->Mqw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, c->Wh, c->Ph, c->S2, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->kernel_family ? 1 : 0, c->tw, 1, c->bud ? part : nullptr, q_bud, qh_minus, c->dual ? c->filt_m : nullptr);
+  const YGeom g = geom_half(c);
+  if (g.width <= 0) return;
+  hipLaunchKernelGGL((k_s_invert<S, MODE>), dim3((g.width + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mA, c->mB, qh, c->filt_h, c->mU, c->mP, c->mQ, c->mQw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, g, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->tw, 1, c->bud ? part : nullptr, q_bud, qh_minus, c->dual ? c->filt_m : nullptr);
 }
 #define NQ_S1_SWITCH(c, CALL)         \
   switch ((c)->S1) {                  \
@@ -609,24 +678,6 @@ static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux, double* part,
   }
 }
 
-// the inversion of the current qh (and, Coupled, current Mphi/Mphiy) into Mu, Mp, Mq, Mqw
-// part: where the ep_psi Parseval partials go; q_bud: QGModel's stale q (or null)
-static void do_invert(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud) {
-  if (c->p.model == NQ_MODEL_COUPLED) {
-    launch_wavepv(c);
-    launch_A(c, false, {c->Ma, c->Mb}, true);
-  }
-  launch_invert(c, qh, store_aux, part, q_bud);
-  if (c->p.model == NQ_MODEL_COUPLED) launch_A(c, true, {c->Mu, c->Mp, c->Mq, c->Mqw}, true);
-  else launch_A(c, true, {c->Mu, c->Mp, c->Mq}, true);
-}
-// inversion outside a step (set_q, nq_invert): its spectral sums become the next step's slot 0
-static void do_invert_now(nq_ctx* c) {
-  do_invert(c, c->q.y[c->q.cur], true, c->part0Q, nullptr);
-  if (c->bud && c->kernel_family)
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0Q, c->nwq, 3, 3, c->carryQ);
-}
-
 static BudgetAcc budget_acc(nq_ctx* c) {
   BudgetAcc b;
   b.model = c->p.model;
@@ -639,37 +690,81 @@ static BudgetAcc budget_acc(nq_ctx* c) {
   return b;
 }
 
-static void do_step(nq_ctx* c) {
+// ---- phases of one ETDRK4 stage --------------------------------------------------------------------
+// Between two phases the named exchange group has to cross from one side to the other: with P == 1 both
+// sides are the same buffer and nq_step simply runs the phases back to back; with P > 1 the caller does
+//      nq_phase(PRODUCTS) -> all_to_all(G0) -> nq_phase(UPDATE) -> all_to_all(G1) [-> all_to_all(G3)]
+//      -> nq_phase(WAVEPV) -> all_to_all(G2) -> nq_phase(INVERT) -> all_to_all(G3)         (Coupled)
+// (UnCoupled / QG have no WAVEPV/INVERT: UPDATE also emits G3.)
+static const cd* stage_qh_out(nq_ctx* c, int stage) {
+  const int cur = c->q.cur;
+  return c->q.y[(stage == 0) ? (cur + 1) % 3 : (stage == 3 ? cur : (cur + 2) % 3)];
+}
+static void phase_invert_y(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud) {
+  if (c->p.model == NQ_MODEL_COUPLED) launch_A_m(c, false, {&c->mA, &c->mB});
+  launch_invert(c, qh, store_aux, part, q_bud);
+  if (c->p.model == NQ_MODEL_COUPLED) launch_A_m(c, true, {&c->mU, &c->mP, &c->mQ, &c->mQw});
+  else launch_A_m(c, true, {&c->mU, &c->mP, &c->mQ});
+}
+static void phase_products(nq_ctx* c, int stage) { launch_products(c, stage); }
+static void phase_update(nq_ctx* c, int s) {
   const bool waves = c->p.model != NQ_MODEL_QG;
-  for (int s = 0; s < 4; ++s) {
-    launch_products(c, s);
-    int qslot = 0, wslot = 0;
-    if (waves) launch_A(c, false, {c->Mj, c->Mr}, false);
-    launch_A(c, false, {c->Muq, c->Mvq}, true);
-    EtdArrays eq = etd_arrays(c->q, s, &qslot);
-    launch_sq(c, eq, s);
-    if (waves) {
-      // phih at the start of this stage: y(t_n), stage-0 result, stage-1 result, stage-2 result
-      const int cur = c->w.cur;
-      const cd* y_start = (s == 0) ? c->w.y[cur] : (s == 1 ? c->w.y[(cur + 1) % 3] : c->w.y[(cur + 2) % 3]);
-      EtdArrays ew = etd_arrays(c->w, s, &wslot);
-      launch_sphi(c, ew, s, y_start);
-      if (c->bud) {
-        if (c->need_diss) launch_A(c, true, {c->Mphi, c->Mphiy, c->Mlap, c->Mdiss}, false);
-        else launch_A(c, true, {c->Mphi, c->Mphiy, c->Mlap}, false);
-      } else {
-        launch_A(c, true, {c->Mphi, c->Mphiy}, false);
-      }
+  int qslot = 0, wslot = 0;
+  if (waves) launch_A_m(c, false, {&c->mJ, &c->mR});
+  launch_A_m(c, false, {&c->mUq, &c->mVq});
+  EtdArrays eq = etd_arrays(c->q, s, &qslot);
+  launch_sq(c, eq, s);
+  if (waves) {
+    // phih at the start of this stage: y(t_n), stage-0 result, stage-1 result, stage-2 result
+    const int cur = c->w.cur;
+    const cd* y_start = (s == 0) ? c->w.y[cur] : (s == 1 ? c->w.y[(cur + 1) % 3] : c->w.y[(cur + 2) % 3]);
+    EtdArrays ew = etd_arrays(c->w, s, &wslot);
+    launch_sphi(c, ew, s, y_start);
+    if (c->bud) {
+      if (c->need_diss) launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap, &c->mDiss});
+      else launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap});
+    } else {
+      launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
     }
+  }
+  if (c->p.model != NQ_MODEL_COUPLED) {
+    // no wave feedback on psi: the inversion needs no row pass, it runs here on the spectral side
     // QGModel evaluates ep_psi after each stage's inversion with the start-of-step q (QGModel.py:355,:401)
     const cd* q_bud = (!c->kernel_family && s < 3) ? c->q.y[c->q.cur] : nullptr;
-    do_invert(c, c->q.y[qslot], s == 3, c->partQ + (size_t)s * c->nwq * 3, q_bud);
+    phase_invert_y(c, c->q.y[qslot], s == 3, c->partQ + (size_t)s * c->nwq * 3, q_bud);
   }
-  if (c->bud) {
-    BudgetAcc ba = budget_acc(c);
-    hipLaunchKernelGGL(k_budget_sums, dim3(44), dim3(1024), 0, c->stream, ba, c->bsums);
-    hipLaunchKernelGGL(k_budget_accumulate, dim3(1), dim3(64), 0, c->stream, ba, (const double*)c->bsums);
+}
+static void phase_wavepv(nq_ctx* c) { launch_wavepv(c); }
+static void phase_invert(nq_ctx* c, int s) {      // Coupled only
+  phase_invert_y(c, stage_qh_out(c, s), s == 3, c->partQ + (size_t)s * c->nwq * 3, nullptr);
+}
+static void phase_budget_sums(nq_ctx* c) {
+  if (c->bud) hipLaunchKernelGGL(k_budget_sums, dim3(44), dim3(1024), 0, c->stream, budget_acc(c), c->bsums);
+}
+static void phase_budget_finish(nq_ctx* c) {
+  if (c->bud) hipLaunchKernelGGL(k_budget_accumulate, dim3(1), dim3(64), 0, c->stream, budget_acc(c), (const double*)c->bsums);
+}
+
+// inversion of the CURRENT state outside a step (set_q, nq_invert); P == 1 only.  Its spectral sums become
+// the next step's slot 0.
+static void do_invert_now(nq_ctx* c) {
+  if (c->p.model == NQ_MODEL_COUPLED) launch_wavepv(c);
+  phase_invert_y(c, c->q.y[c->q.cur], true, c->part0Q, nullptr);
+  if (c->bud && c->kernel_family)
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0Q, c->nwq, 3, 3, c->carryQ);
+}
+
+static void do_step(nq_ctx* c) {      // P == 1
+  for (int s = 0; s < 4; ++s) {
+    phase_products(c, s);
+    phase_update(c, s);
+    if (c->p.model == NQ_MODEL_COUPLED) {
+      phase_wavepv(c);
+      phase_invert(c, s);
+    }
   }
+  phase_budget_sums(c);
+  phase_budget_finish(c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -677,8 +772,73 @@ extern "C" {
 
 const char* nq_last_error(const nq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
-int nq_create(const nq_params* p, const double* kk, const double* ll, const double* filtr, const double* contour,
-              int device, nq_ctx** out) {
+// ---- slab geometry (shared by nq_group_elems and the constructor) -----------------------------------
+struct SlabGeom {
+  int N, P, Nloc, Wf, Wl, WhG, Ph;
+  bool waves, coupled, bud, diss;
+  int npitch[4];                 // row pitch of the four exchange groups
+  int off[4][4];                 // column offset of each array inside its group's row
+};
+static int round8(int x) { return (x + 7) / 8 * 8; }
+static SlabGeom slab_geom(const nq_params* p, int P) {
+  SlabGeom g;
+  g.N = p->nx;
+  g.P = P;
+  g.Nloc = g.N / P;
+  g.Wf = g.N / P;
+  g.WhG = g.N / 2 + 1;
+  g.Wl = (g.WhG + P - 1) / P;
+  g.Ph = (P == 1) ? g.N / 2 + 8 : round8(g.Wl);
+  g.waves = p->model != NQ_MODEL_QG;
+  g.coupled = p->model == NQ_MODEL_COUPLED;
+  g.bud = p->budgets != 0;
+  g.diss = g.bud && g.waves && p->nu4w != 0.0;
+  const int hs = g.Ph;                          // segment stride of a half-spectrum array inside a row
+  memset(g.off, 0, sizeof(g.off));
+  // G0: Muq, Mvq, [Mj, Mr]
+  g.off[0][0] = 0; g.off[0][1] = hs; g.off[0][2] = 2 * hs; g.off[0][3] = 2 * hs + g.Wf;
+  g.npitch[0] = 2 * hs + (g.waves ? 2 * g.Wf : 0);
+  // G1: Mphi, Mphiy, [Mlap, [Mdiss]]
+  for (int i = 0; i < 4; ++i) g.off[1][i] = i * g.Wf;
+  g.npitch[1] = g.waves ? (2 + (g.bud ? 1 : 0) + (g.diss ? 1 : 0)) * g.Wf : 0;
+  // G2: Ma, Mb
+  g.off[2][0] = 0; g.off[2][1] = hs;
+  g.npitch[2] = g.coupled ? 2 * hs : 0;
+  // G3: Mu, Mp, Mq, [Mqw]
+  for (int i = 0; i < 4; ++i) g.off[3][i] = i * hs;
+  g.npitch[3] = (g.coupled ? 4 : 3) * hs;
+  return g;
+}
+
+long long nq_group_elems(const nq_params* p, int nranks, int group) {
+  if (!p || group < 0 || group > 3 || nranks < 1 || p->nx % nranks) return -1;
+  const SlabGeom g = slab_geom(p, nranks);
+  return (long long)g.N * g.npitch[group];       // one side: P blocks of Nloc rows = N rows of `pitch`
+}
+
+static MArr make_marr(const SlabGeom& g, cd* bx, cd* by, int group, int idx, bool half) {
+  MArr m;
+  m.xs = bx ? bx + g.off[group][idx] : nullptr;
+  m.ys = by ? by + g.off[group][idx] : nullptr;
+  m.pitch = g.npitch[group];
+  m.W = half ? (g.P == 1 ? g.WhG : g.Wl) : g.Wf;
+  m.blk = (long long)g.Nloc * g.npitch[group];
+  m.shift = -1;
+  m.magic = 0;
+  if (g.P == 1) m.shift = 30;                    // a single block: kx / W == 0
+  else if ((m.W & (m.W - 1)) == 0) {
+    int sh = 0;
+    while ((1 << sh) < m.W) ++sh;
+    m.shift = sh;
+  } else {
+    m.magic = (unsigned)(((1u << 24) + m.W - 1) / m.W);
+  }
+  return m;
+}
+
+static int create_impl(const nq_params* p, const double* kk, const double* ll, const double* filtr,
+                       const double* contour, int device, int P, int rank, void* const* ext, void* ext_stream,
+                       nq_ctx** out) {
   if (!p || !kk || !ll || !filtr || !contour || !out) NQ_FAIL((nq_ctx*)nullptr, -1, "nq_create: null argument");
   int S1, S2;
   if (!plan_for(p->nx, &S1, &S2)) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d unsupported (power of two in [64, 8192])", p->nx);
@@ -686,21 +846,37 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
     NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d: rows longer than 4096 need a split LDS exchange in the fused row "
             "kernels (128 KB exchange + twiddle table exceed the 160 KB LDS); not built yet", p->nx);
   if (p->model < 0 || p->model > 2) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: unknown model %d", p->model);
+  if (P < 1 || rank < 0 || rank >= P || (P & (P - 1)) || p->nx / P < 2 * CL ||
+      (P > 1 && (p->nx / 2 + 1 + P - 1) / P >= 2048))
+    NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: %d ranks unsupported for nx=%d (power of two, at least %d columns per rank)", P, p->nx, 2 * CL);
+  if (P > 1 && !ext) NQ_FAIL((nq_ctx*)nullptr, -1, "nq_create_slab: exchange buffers are required when nranks > 1");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: no HIP device available");
   if (device < 0 || device >= ndev) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: device %d out of range (%d devices)", device, ndev);
   nq_ctx* c = new nq_ctx();
+  const SlabGeom sg = slab_geom(p, P);
   c->p = *p;
   c->N = p->nx;
   c->S1 = S1;
   c->S2 = S2;
-  c->Wh = c->N / 2 + 1;
-  c->Ph = c->N / 2 + 8;
+  c->P = P;
+  c->rank = rank;
+  c->Nloc = sg.Nloc;
+  c->Wf = sg.Wf;
+  c->kf0 = rank * sg.Wf;
+  c->Wl = (P == 1) ? sg.WhG : sg.Wl;
+  c->kh0 = (P == 1) ? 0 : rank * sg.Wl;
+  c->WhG = sg.WhG;
+  {
+    const int left = sg.WhG - c->kh0;
+    c->Wh = left < 0 ? 0 : (left < c->Wl ? left : c->Wl);      // valid local half-spectrum columns
+  }
+  c->Ph = sg.Ph;
   c->kernel_family = p->model != NQ_MODEL_QG;
-  c->nk = c->kernel_family ? c->N : c->Wh;
+  c->nk = c->kernel_family ? c->N : c->WhG;
   c->device = device;
   const int N = c->N;
-  const size_t full = (size_t)N * N, half = (size_t)N * c->Ph;
+  const size_t full = (size_t)N * c->Wf, half = (size_t)N * c->Ph;     // local spectral planes
 #define FAILC(rc)        \
   do {                   \
     g_last_error = c->err; \
@@ -714,7 +890,12 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
   } while (0)
   auto setup = [&]() -> int {
     HIPCHK(c, hipSetDevice(device));
-    HIPCHK(c, hipStreamCreate(&c->stream));
+    if (ext_stream) {
+      c->stream = reinterpret_cast<hipStream_t>(ext_stream);
+      c->own_stream = false;
+    } else {
+      HIPCHK(c, hipStreamCreate(&c->stream));
+    }
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
     // twiddles, long-double accurate
@@ -728,10 +909,10 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
     HIPCHK(c, hipMemcpyAsync(c->tw, twh.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
     // stage tables for the fused row kernels: [stage >= 1][w^1 | w^4 | w^8][jr < NS]
     for (int which = 0; which < 2; ++which) {
-      const int P = (N >= 128) ? (which == 0 ? NQ_XP : NQ_XP1) : 8;
+      const int PP = (N >= 128) ? (which == 0 ? NQ_XP : NQ_XP1) : 8;
       std::vector<double> st;
-      for (int sidx = 1; sidx < plan_stages(N, P); ++sidx) {
-        const int R = plan_radix(N, P, sidx), NS = plan_ns(N, P, sidx);
+      for (int sidx = 1; sidx < plan_stages(N, PP); ++sidx) {
+        const int R = plan_radix(N, PP, sidx), NS = plan_ns(N, PP, sidx);
         for (int pw = 1; pw <= 8; pw *= (pw == 1 ? 4 : 2)) {          // powers 1, 4, 8
           for (int jr = 0; jr < NS; ++jr) {
             const long long m = ((long long)pw * jr * (N / (NS * R))) % N;
@@ -752,65 +933,94 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
     ALLOC(c, c->contour, (size_t)32);
     HIPCHK(c, hipMemcpyAsync(c->contour, contour, sizeof(double) * 64, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // filter planes: half-spectrum copy (pitch Ph) and, for the Kernel family, the full plane
+    // filter planes, local columns: half-spectrum copy (pitch Ph) and, for the Kernel family, full-width copy
     ALLOC(c, c->filt_h, half);
-    HIPCHK(c, hipMemcpy2DAsync(c->filt_h, sizeof(double) * c->Ph, filtr, sizeof(double) * c->nk, sizeof(double) * c->Wh, N, hipMemcpyHostToDevice, c->stream));
+    if (c->Wh > 0)
+      HIPCHK(c, hipMemcpy2DAsync(c->filt_h, sizeof(double) * c->Ph, filtr + c->kh0, sizeof(double) * c->nk, sizeof(double) * c->Wh, N, hipMemcpyHostToDevice, c->stream));
     if (c->kernel_family) {
       ALLOC(c, c->filt_f, full);
-      HIPCHK(c, hipMemcpyAsync(c->filt_f, filtr, sizeof(double) * full, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpy2DAsync(c->filt_f, sizeof(double) * c->Wf, filtr + c->kf0, sizeof(double) * c->nk, sizeof(double) * c->Wf, N, hipMemcpyHostToDevice, c->stream));
     }
     // equations
     for (int i = 0; i < 3; ++i) ALLOC(c, c->q.y[i], half);
     ALLOC(c, c->q.fn0, half);
     ALLOC(c, c->q.fna, half);
     for (int i = 0; i < 6; ++i) ALLOC(c, c->q.coef[i], half);
-    dim3 blk(64), grdh((c->Wh + 63) / 64, N), grdf((N + 63) / 64, N);
-    hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, c->kernel_family ? 0 : 2, N, c->Wh, c->Ph, c->p, c->kk, c->ll, c->filt_h, c->contour, c->q.coef[0], c->q.coef[1], c->q.coef[2], c->q.coef[3], c->q.coef[4], c->q.coef[5]);
+    dim3 blk(64), grdh((c->Wh + 63) / 64, N), grdf((c->Wf + 63) / 64, N);
+    if (c->Wh > 0)
+      hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, c->kernel_family ? 0 : 2, N, c->Wh, c->Ph, c->kh0, c->p, c->kk, c->ll, c->filt_h, c->contour, c->q.coef[0], c->q.coef[1], c->q.coef[2], c->q.coef[3], c->q.coef[4], c->q.coef[5]);
     c->dual = c->kernel_family && p->dual_q != 0;
     if (c->dual) {
       for (int i = 0; i < 3; ++i) ALLOC(c, c->q2.y[i], half);
       ALLOC(c, c->q2.fn0, half);
       ALLOC(c, c->q2.fna, half);
       for (int i = 0; i < 6; ++i) ALLOC(c, c->coefu[i], half);
-      hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, 0, N, c->Wh, c->Ph, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, c->coefu[0], c->coefu[1], c->coefu[2], c->coefu[3], c->coefu[4], c->coefu[5]);
+      if (c->Wh > 0)
+        hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, 0, N, c->Wh, c->Ph, c->kh0, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, c->coefu[0], c->coefu[1], c->coefu[2], c->coefu[3], c->coefu[4], c->coefu[5]);
       std::vector<double> fm((size_t)N * c->Ph, 0.0);
       for (int l = 0; l < N; ++l)
-        for (int k = 0; k < c->Wh; ++k) fm[(size_t)l * c->Ph + k] = filtr[(size_t)((N - l) % N) * c->nk + (N - k) % N];
+        for (int k = 0; k < c->Wh; ++k) fm[(size_t)l * c->Ph + k] = filtr[(size_t)((N - l) % N) * c->nk + (N - (c->kh0 + k)) % N];
       ALLOC(c, c->filt_m, half);
       HIPCHK(c, hipMemcpyAsync(c->filt_m, fm.data(), sizeof(double) * half, hipMemcpyHostToDevice, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     ALLOC(c, c->ph, half);
     ALLOC(c, c->qwh, half);
-    ALLOC(c, c->Ma, half);
-    ALLOC(c, c->Mb, half);
-    ALLOC(c, c->Mu, half);
-    ALLOC(c, c->Mp, half);
-    ALLOC(c, c->Mq, half);
-    ALLOC(c, c->Mqw, half);
-    ALLOC(c, c->Muq, half);
-    ALLOC(c, c->Mvq, half);
-    ALLOC(c, c->scr_h0, half);
-    ALLOC(c, c->scr_h1, half);
-    ALLOC(c, c->scr_r, full);
-    ALLOC(c, c->scr_f0, full);
-    ALLOC(c, c->scr_f1, full);
+    if (P == 1) {                                   // scratch of the generic (single-rank) transform paths
+      ALLOC(c, c->scr_h0, half);
+      ALLOC(c, c->scr_h1, half);
+      ALLOC(c, c->scr_r, (size_t)N * N);
+      ALLOC(c, c->scr_f0, (size_t)N * N);
+      ALLOC(c, c->scr_f1, (size_t)N * N);
+    } else {
+      ALLOC(c, c->scr_h0, (size_t)64);              // reduction scratch only
+    }
     if (c->kernel_family) {
       for (int i = 0; i < 3; ++i) ALLOC(c, c->w.y[i], full);
       ALLOC(c, c->w.fn0, full);
       ALLOC(c, c->w.fna, full);
       for (int i = 0; i < 6; ++i) ALLOC(c, c->w.coef[i], full);
-      hipLaunchKernelGGL(k_etdrk4_coeffs, grdf, blk, 0, c->stream, 1, N, N, N, c->p, c->kk, c->ll, c->filt_f, c->contour, c->w.coef[0], c->w.coef[1], c->w.coef[2], c->w.coef[3], c->w.coef[4], c->w.coef[5]);
-      ALLOC(c, c->Mphi, full);
-      ALLOC(c, c->Mphiy, full);
-      ALLOC(c, c->Mj, full);
-      ALLOC(c, c->Mr, full);
-      if (c->p.model == NQ_MODEL_UNCOUPLED) {
-        ALLOC(c, c->Mgx, full);
-        ALLOC(c, c->Mgy, full);
-      }
+      hipLaunchKernelGGL(k_etdrk4_coeffs, grdf, blk, 0, c->stream, 1, N, c->Wf, c->Wf, c->kf0, c->p, c->kk, c->ll, c->filt_f, c->contour, c->w.coef[0], c->w.coef[1], c->w.coef[2], c->w.coef[3], c->w.coef[4], c->w.coef[5]);
     }
     c->bud = p->budgets != 0;
+    c->need_diss = sg.diss;
+    // exchange groups: one buffer per side (the same buffer when P == 1); external (torch) buffers when given
+    for (int gi = 0; gi < 4; ++gi) {
+      c->G[gi].pitch = sg.npitch[gi];
+      c->G[gi].elems = (size_t)N * sg.npitch[gi];
+      if (c->G[gi].elems == 0) continue;
+      if (ext && ext[2 * gi] && ext[2 * gi + 1]) {
+        c->G[gi].bx = reinterpret_cast<cd*>(ext[2 * gi]);
+        c->G[gi].by = reinterpret_cast<cd*>(ext[2 * gi + 1]);
+        HIPCHK(c, hipMemsetAsync(c->G[gi].bx, 0, c->G[gi].elems * sizeof(cd), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->G[gi].by, 0, c->G[gi].elems * sizeof(cd), c->stream));
+      } else {
+        ALLOC(c, c->G[gi].bx, c->G[gi].elems);
+        if (P == 1) c->G[gi].by = c->G[gi].bx;
+        else ALLOC(c, c->G[gi].by, c->G[gi].elems);
+      }
+    }
+    c->mUq = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 0, true);
+    c->mVq = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 1, true);
+    c->mJ = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 2, false);
+    c->mR = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 3, false);
+    c->mPhi = make_marr(sg, c->G[1].bx, c->G[1].by, 1, 0, false);
+    c->mPhiy = make_marr(sg, c->G[1].bx, c->G[1].by, 1, 1, false);
+    c->mLap = make_marr(sg, c->G[1].bx, c->G[1].by, 1, 2, false);
+    c->mDiss = make_marr(sg, c->G[1].bx, c->G[1].by, 1, 3, false);
+    c->mA = make_marr(sg, c->G[2].bx, c->G[2].by, 2, 0, true);
+    c->mB = make_marr(sg, c->G[2].bx, c->G[2].by, 2, 1, true);
+    c->mU = make_marr(sg, c->G[3].bx, c->G[3].by, 3, 0, true);
+    c->mP = make_marr(sg, c->G[3].bx, c->G[3].by, 3, 1, true);
+    c->mQ = make_marr(sg, c->G[3].bx, c->G[3].by, 3, 2, true);
+    c->mQw = make_marr(sg, c->G[3].bx, c->G[3].by, 3, 3, true);
+    c->mGx = c->mPhi;
+    c->mGy = c->mPhiy;
+    if (c->p.model == NQ_MODEL_UNCOUPLED) {        // frozen copy of the X side of G1 (quirk Q1)
+      ALLOC(c, c->Gs, c->G[1].elems);
+      c->mGx = make_marr(sg, c->Gs, c->Gs, 1, 0, false);
+      c->mGy = make_marr(sg, c->Gs, c->Gs, 1, 1, false);
+    }
     if (c->bud) {
       int xc = 1;
       switch (N) {
@@ -818,23 +1028,22 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
         NQ_FOR_SIZES(CASE_)
 #undef CASE_
       }
-      c->nwx = N / xc;
-      c->nww = (N / CL) * c->S2;
+      c->nwx = c->Nloc / xc;
+      c->nww = (c->Wf / CL) * c->S2;
       c->nwq = ((c->Wh + CL - 1) / CL) * c->S2;
+      if (c->nwq < 1) c->nwq = 1;
       ALLOC(c, c->partQ, (size_t)4 * c->nwq * 3);
       ALLOC(c, c->part0Q, (size_t)c->nwq * 3);
       ALLOC(c, c->carryQ, (size_t)4);
       ALLOC(c, c->acc, (size_t)4);
-      ALLOC(c, c->bsums, (size_t)44);
+      if (ext && ext[8]) c->bsums = reinterpret_cast<double*>(ext[8]);
+      else ALLOC(c, c->bsums, (size_t)64);
       if (c->kernel_family) {
-        c->need_diss = p->nu4w != 0.0;
         ALLOC(c, c->partX, (size_t)4 * c->nwx * 2);
         ALLOC(c, c->partW, (size_t)4 * c->nww * 6);
         ALLOC(c, c->part0W, (size_t)c->nww * 6);
         ALLOC(c, c->carryW, (size_t)4);
         ALLOC(c, c->gradS1, (size_t)1);
-        ALLOC(c, c->Mlap, full);
-        if (c->need_diss) ALLOC(c, c->Mdiss, full);
       }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -846,6 +1055,16 @@ int nq_create(const nq_params* p, const double* kk, const double* ll, const doub
   return 0;
 }
 
+int nq_create(const nq_params* p, const double* kk, const double* ll, const double* filtr, const double* contour,
+              int device, nq_ctx** out) {
+  return create_impl(p, kk, ll, filtr, contour, device, 1, 0, nullptr, nullptr, out);
+}
+
+int nq_create_slab(const nq_params* p, const double* kk, const double* ll, const double* filtr, const double* contour,
+                   int device, int nranks, int rank, void* const* buffers, void* stream, nq_ctx** out) {
+  return create_impl(p, kk, ll, filtr, contour, device, nranks, rank, buffers, stream, out);
+}
+
 int nq_destroy(nq_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->device);
@@ -854,7 +1073,7 @@ int nq_destroy(nq_ctx* c) {
   for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
-  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
@@ -906,6 +1125,7 @@ int nq_timer_stop(nq_ctx* c, float* ms) {
 
 int nq_set_q(nq_ctx* c, const double* q_host) {
   if (!c || !q_host) return -1;
+  NQ_SINGLE_RANK(c, "nq_set_q");
   const size_t full = (size_t)c->N * c->N;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(c->scr_r, q_host, sizeof(double) * full, hipMemcpyHostToDevice, c->stream));
@@ -918,6 +1138,7 @@ int nq_set_q(nq_ctx* c, const double* q_host) {
 
 int nq_set_phi(nq_ctx* c, const double* phi_host) {
   if (!c || !phi_host) return -1;
+  NQ_SINGLE_RANK(c, "nq_set_phi");
   if (!c->kernel_family) NQ_FAIL(c, -4, "nq_set_phi: QGModel has no wave field");
   const size_t full = (size_t)c->N * c->N;
   HIPCHK(c, hipSetDevice(c->device));
@@ -925,11 +1146,11 @@ int nq_set_phi(nq_ctx* c, const double* phi_host) {
   fwd2d_full(c, c->scr_f0, c->w.y[c->w.cur], c->scr_f1);
   launch_emit_phi(c, c->w.y[c->w.cur]);
   if (c->bud) {
-    if (c->need_diss) launch_A(c, true, {c->Mphi, c->Mphiy, c->Mlap, c->Mdiss}, false);
-    else launch_A(c, true, {c->Mphi, c->Mphiy, c->Mlap}, false);
+    if (c->need_diss) launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap, &c->mDiss});
+    else launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap});
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0W, c->nww, 6, 4, c->carryW);
   } else {
-    launch_A(c, true, {c->Mphi, c->Mphiy}, false);
+    launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
   }
   c->have_phi = true;
   int rc = nq_refresh_grad_phi(c);
@@ -939,6 +1160,7 @@ int nq_set_phi(nq_ctx* c, const double* phi_host) {
 
 int nq_invert(nq_ctx* c) {
   if (!c) return -1;
+  NQ_SINGLE_RANK(c, "nq_invert");
   HIPCHK(c, hipSetDevice(c->device));
   do_invert_now(c);
   return nq_sync(c);
@@ -947,9 +1169,8 @@ int nq_invert(nq_ctx* c) {
 int nq_refresh_grad_phi(nq_ctx* c) {
   if (!c) return -1;
   if (c->p.model == NQ_MODEL_UNCOUPLED) {
-    const size_t full = (size_t)c->N * c->N;
-    HIPCHK(c, hipMemcpyAsync(c->Mgx, c->Mphi, sizeof(cd) * full, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->Mgy, c->Mphiy, sizeof(cd) * full, hipMemcpyDeviceToDevice, c->stream));
+    // freeze the X side of group 1 (phi, phiy rows as the row kernels see them)
+    HIPCHK(c, hipMemcpyAsync(c->Gs, c->G[1].bx, sizeof(cd) * c->G[1].elems, hipMemcpyDeviceToDevice, c->stream));
     if (c->bud) HIPCHK(c, hipMemcpyAsync(c->gradS1, c->carryW + 1, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   }
   return 0;
@@ -957,6 +1178,7 @@ int nq_refresh_grad_phi(nq_ctx* c) {
 
 int nq_step(nq_ctx* c, int nsteps) {
   if (!c) return -1;
+  NQ_SINGLE_RANK(c, "nq_step");
   if (nsteps < 0) NQ_FAIL(c, -1, "nq_step: nsteps < 0");
   HIPCHK(c, hipSetDevice(c->device));
   for (int i = 0; i < nsteps; ++i) do_step(c);
@@ -964,9 +1186,114 @@ int nq_step(nq_ctx* c, int nsteps) {
   return 0;
 }
 
+// ---- slab decomposition API ------------------------------------------------------------------------
+int nq_slab_info(const nq_ctx* c, int* info) {
+  // info[0..7] = nranks, rank, local rows, full-plane local columns, first full column,
+  //              half-spectrum local (valid) columns, first half-spectrum column, half-spectrum pitch
+  if (!c || !info) return -1;
+  info[0] = c->P; info[1] = c->rank; info[2] = c->Nloc; info[3] = c->Wf; info[4] = c->kf0;
+  info[5] = c->Wh; info[6] = c->kh0; info[7] = c->Ph;
+  return 0;
+}
+
+int nq_group_buffers(nq_ctx* c, int group, void** x_side, void** y_side, long long* elems) {
+  if (!c || group < 0 || group > 3) return -1;
+  if (x_side) *x_side = c->G[group].bx;
+  if (y_side) *y_side = c->G[group].by;
+  if (elems) *elems = (long long)c->G[group].elems;
+  return 0;
+}
+
+// local column slab of a spectral state plane: which 0 = qh (half spectrum, (ny, local valid columns)),
+// 1 = phih (full plane, (ny, local columns)); host arrays are contiguous
+int nq_upload_spectral(nq_ctx* c, int which, const double* host) {
+  if (!c || !host) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (which == 0) {
+    if (c->Wh > 0) HIPCHK(c, hipMemcpy2DAsync(c->q.y[c->q.cur], sizeof(cd) * c->Ph, host, sizeof(cd) * c->Wh, sizeof(cd) * c->Wh, c->N, hipMemcpyHostToDevice, c->stream));
+    if (c->dual) HIPCHK(c, hipMemcpyAsync(c->q2.y[c->q2.cur], c->q.y[c->q.cur], sizeof(cd) * (size_t)c->N * c->Ph, hipMemcpyDeviceToDevice, c->stream));
+  } else if (which == 1) {
+    if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
+    HIPCHK(c, hipMemcpyAsync(c->w.y[c->w.cur], host, sizeof(cd) * (size_t)c->N * c->Wf, hipMemcpyHostToDevice, c->stream));
+  } else NQ_FAIL(c, -1, "nq_upload_spectral: which = %d", which);
+  return nq_sync(c);
+}
+int nq_download_spectral(nq_ctx* c, int which, double* host) {
+  if (!c || !host) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (which == 0) {
+    if (c->Wh > 0) HIPCHK(c, hipMemcpy2DAsync(host, sizeof(cd) * c->Wh, c->q.y[c->q.cur], sizeof(cd) * c->Ph, sizeof(cd) * c->Wh, c->N, hipMemcpyDeviceToHost, c->stream));
+  } else if (which == 1) {
+    if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
+    HIPCHK(c, hipMemcpyAsync(host, c->w.y[c->w.cur], sizeof(cd) * (size_t)c->N * c->Wf, hipMemcpyDeviceToHost, c->stream));
+  } else NQ_FAIL(c, -1, "nq_download_spectral: which = %d", which);
+  return nq_sync(c);
+}
+
+// One phase of the distributed step (see "phases of one ETDRK4 stage").  Asynchronous on the stream.
+//   NQ_PH_PRODUCTS(stage)  row kernel: reads G3.x, G1.x, writes G0.x             then exchange G0 (x -> y)
+//   NQ_PH_UPDATE(stage)    y passes + stage updates: reads G0.y, writes G1.y (and G3.y unless Coupled)
+//                                                                                  then exchange G1 (y -> x) [, G3]
+//   NQ_PH_WAVEPV           Coupled row kernel: reads G1.x, writes G2.x            then exchange G2 (x -> y)
+//   NQ_PH_INVERT(stage)    Coupled inversion: reads G2.y, writes G3.y             then exchange G3 (y -> x)
+//   NQ_PH_EMIT_PHI         after nq_upload_spectral(phih): writes G1.y            then exchange G1 (y -> x)
+//   NQ_PH_INVERT_NOW       inversion of the current qh (set_q): Coupled: run NQ_PH_WAVEPV + exchange G2 first
+//   NQ_PH_BUDGET_SUMS      local sums of one step -> nq_budget_sums buffer        then all-reduce (sum) it
+//   NQ_PH_BUDGET_FINISH    RK-weighted accumulation from the (reduced) sums
+int nq_phase(nq_ctx* c, int phase, int stage) {
+  if (!c) return -1;
+  if (stage < 0 || stage > 3) NQ_FAIL(c, -1, "nq_phase: stage %d", stage);
+  HIPCHK(c, hipSetDevice(c->device));
+  switch (phase) {
+    case NQ_PH_PRODUCTS: phase_products(c, stage); break;
+    case NQ_PH_UPDATE: phase_update(c, stage); break;
+    case NQ_PH_WAVEPV: phase_wavepv(c); break;
+    case NQ_PH_INVERT: phase_invert(c, stage); break;
+    case NQ_PH_EMIT_PHI:
+      if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
+      launch_emit_phi(c, c->w.y[c->w.cur]);
+      if (c->bud) {
+        if (c->need_diss) launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap, &c->mDiss});
+        else launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap});
+        // local part of the carried sums; the caller all-reduces them through nq_carry_buffer
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0W, c->nww, 6, 4, c->carryW);
+      } else {
+        launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
+      }
+      break;
+    case NQ_PH_INVERT_NOW:
+      phase_invert_y(c, c->q.y[c->q.cur], true, c->part0Q, nullptr);
+      if (c->bud && c->kernel_family)
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0Q, c->nwq, 3, 3, c->carryQ);
+      break;
+    case NQ_PH_BUDGET_SUMS: phase_budget_sums(c); break;
+    case NQ_PH_BUDGET_FINISH: phase_budget_finish(c); break;
+    default: NQ_FAIL(c, -1, "nq_phase: unknown phase %d", phase);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// device buffers that must be summed over ranks: which 0 = the 44 stage sums of one step (between
+// NQ_PH_BUDGET_SUMS and NQ_PH_BUDGET_FINISH), 1 = carried phi sums (4, after NQ_PH_EMIT_PHI),
+// 2 = carried q sums (3, after NQ_PH_INVERT_NOW), 3 = frozen gradient sum (1, after nq_refresh_grad_phi)
+int nq_reduce_buffer(nq_ctx* c, int which, void** ptr, int* count) {
+  if (!c || !ptr || !count) return -1;
+  if (!c->bud) NQ_FAIL(c, -4, "budgets are disabled in this context");
+  switch (which) {
+    case 0: *ptr = c->bsums; *count = 44; break;
+    case 1: *ptr = c->carryW; *count = 4; break;
+    case 2: *ptr = c->carryQ; *count = 3; break;
+    case 3: *ptr = c->gradS1; *count = 1; break;
+    default: NQ_FAIL(c, -1, "nq_reduce_buffer: which = %d", which);
+  }
+  return 0;
+}
+
 // ---- FFT seam ----------------------------------------------------------------------------------
 int nq_fft2(nq_ctx* c, const double* in, double* out) {
   if (!c || !in || !out) return -1;
+  NQ_SINGLE_RANK(c, "nq_fft2");
   const size_t full = (size_t)c->N * c->N;
   HIPCHK(c, hipMemcpyAsync(c->scr_f0, in, sizeof(cd) * full, hipMemcpyHostToDevice, c->stream));
   fwd2d_full(c, c->scr_f0, c->scr_f0, c->scr_f1);
@@ -975,6 +1302,7 @@ int nq_fft2(nq_ctx* c, const double* in, double* out) {
 }
 int nq_ifft2(nq_ctx* c, const double* in, double* out) {
   if (!c || !in || !out) return -1;
+  NQ_SINGLE_RANK(c, "nq_ifft2");
   const size_t full = (size_t)c->N * c->N;
   HIPCHK(c, hipMemcpyAsync(c->scr_f0, in, sizeof(cd) * full, hipMemcpyHostToDevice, c->stream));
   inv2d_full(c, c->scr_f0, c->scr_f0, c->scr_f1);
@@ -983,6 +1311,7 @@ int nq_ifft2(nq_ctx* c, const double* in, double* out) {
 }
 int nq_rfft2(nq_ctx* c, const double* in, double* out) {
   if (!c || !in || !out) return -1;
+  NQ_SINGLE_RANK(c, "nq_rfft2");
   const int N = c->N;
   HIPCHK(c, hipMemcpyAsync(c->scr_r, in, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
   fwd2d_half(c, c->scr_r, c->scr_h1, c->scr_h0);
@@ -991,6 +1320,7 @@ int nq_rfft2(nq_ctx* c, const double* in, double* out) {
 }
 int nq_irfft2(nq_ctx* c, const double* in, double* out) {
   if (!c || !in || !out) return -1;
+  NQ_SINGLE_RANK(c, "nq_irfft2");
   const int N = c->N;
   HIPCHK(c, hipMemcpy2DAsync(c->scr_h1, sizeof(cd) * c->Ph, in, sizeof(cd) * c->Wh, sizeof(cd) * c->Wh, N, hipMemcpyHostToDevice, c->stream));
   inv2d_half(c, c->scr_h1, c->scr_r, c->scr_h0);
@@ -1017,6 +1347,7 @@ static int get_real_from_half(nq_ctx* c, const cd* spec, int mul_mode, double* h
 
 int nq_get_field(nq_ctx* c, int id, double* host) {
   if (!c || !host) return -1;
+  NQ_SINGLE_RANK(c, "nq_get_field");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t full = (size_t)c->N * c->N;
   const cd* qh = c->q.y[c->q.cur];
@@ -1056,15 +1387,16 @@ int nq_get_field(nq_ctx* c, int id, double* host) {
       return nq_sync(c);
     case NQ_F_PHI:
       if (!waves) NQ_FAIL(c, -4, "no wave field in QGModel");
-      launch_x_c2c(c, true, c->Mphi, c->scr_f0, c->N, c->N, 1.0);
+      launch_x_c2c(c, true, c->mPhi.xs, c->scr_f0, c->mPhi.pitch, c->N, 1.0);
       HIPCHK(c, hipMemcpyAsync(host, c->scr_f0, sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
       return nq_sync(c);
     case NQ_F_PHIX:
     case NQ_F_PHIY: {
       if (!waves) NQ_FAIL(c, -4, "no wave field in QGModel");
       const bool unc = c->p.model == NQ_MODEL_UNCOUPLED;
-      const cd* src = (id == NQ_F_PHIX) ? (unc ? c->Mgx : c->Mphi) : (unc ? c->Mgy : c->Mphiy);
-      launch_x_c2c(c, true, src, c->scr_f0, c->N, c->N, 1.0, id == NQ_F_PHIX ? 1 : 0);
+      (void)unc;
+      const MArr& src = (id == NQ_F_PHIX) ? c->mGx : c->mGy;       // == mPhi/mPhiy unless UnCoupled
+      launch_x_c2c(c, true, src.xs, c->scr_f0, src.pitch, c->N, 1.0, id == NQ_F_PHIX ? 1 : 0);
       HIPCHK(c, hipMemcpyAsync(host, c->scr_f0, sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
       return nq_sync(c);
     }
@@ -1126,7 +1458,7 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
       inv2d_half(c, c->scr_h1, c->scr_r, c->scr_f1);
       hipLaunchKernelGGL(k_reduce_real_max, dim3(1024), dim3(256), 0, c->stream, c->scr_r, full, d);
     }
-    launch_x_c2c(c, true, c->Mphi, c->scr_f0, N, N, 1.0);
+    launch_x_c2c(c, true, c->mPhi.xs, c->scr_f0, c->mPhi.pitch, N, 1.0);
     hipLaunchKernelGGL(k_reduce, dim3((N + 255) / 256, N), dim3(256), 0, c->stream, c->scr_f0, N, N, N, 3, c->kk, c->ll, d);
     HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     int rc = nq_sync(c);
@@ -1138,6 +1470,7 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
 
 int nq_get_coeff(nq_ctx* c, int eq, int which, double* out) {
   if (!c || !out || which < 0 || which > 5 || eq < 0 || eq > 1) return -1;
+  NQ_SINGLE_RANK(c, "nq_get_coeff");
   if (eq == 1 && !c->kernel_family) NQ_FAIL(c, -4, "no phi equation in QGModel");
   HIPCHK(c, hipSetDevice(c->device));
   const int N = c->N;
@@ -1151,7 +1484,7 @@ int nq_get_coeff(nq_ctx* c, int eq, int which, double* out) {
     tmp[i] = reinterpret_cast<cd*>(p);
   }
   const int e = half ? (c->kernel_family ? 0 : 2) : 1;
-  hipLaunchKernelGGL(k_etdrk4_coeffs, dim3((width + 63) / 64, N), dim3(64), 0, c->stream, e, N, width, pitch, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5]);
+  hipLaunchKernelGGL(k_etdrk4_coeffs, dim3((width + 63) / 64, N), dim3(64), 0, c->stream, e, N, width, pitch, 0, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5]);
   hipError_t er = hipMemcpy2DAsync(out, sizeof(cd) * width, tmp[which], sizeof(cd) * pitch, sizeof(cd) * width, N, hipMemcpyDeviceToHost, c->stream);
   int rc = nq_sync(c);
   for (int i = 0; i < 6; ++i) hipFree(tmp[i]);
@@ -1163,35 +1496,38 @@ int nq_get_coeff(nq_ctx* c, int eq, int which, double* out) {
 // reference's full-plane arrays (multiplying by ik/il and expanding Hermitian halves).
 int nq_jacobian_psi_q(nq_ctx* c, double* out_cplx) {
   // out: 2 half-spectrum planes (ny, nx/2+1): F[u q] then F[v q]
+  NQ_SINGLE_RANK(c, "nq_jacobian_psi_q");
   if (!c || !out_cplx) return -1;
   HIPCHK(c, hipSetDevice(c->device));
   launch_products(c);
-  launch_A(c, false, {c->Muq, c->Mvq}, true);
-  launch_B(c, false, c->Muq, c->scr_h0, true, 1.0);
-  launch_B(c, false, c->Mvq, c->scr_h1, true, 1.0);
+  launch_A_m(c, false, {&c->mUq, &c->mVq});
+  launch_B_p(c, false, c->mUq.ys, c->mUq.pitch, c->scr_h0, c->Ph, c->Wh, 1.0);
+  launch_B_p(c, false, c->mVq.ys, c->mVq.pitch, c->scr_h1, c->Ph, c->Wh, 1.0);
   int rc = get_half_spec(c, c->scr_h0, out_cplx);
   if (rc) return rc;
   return get_half_spec(c, c->scr_h1, out_cplx + 2 * (size_t)c->N * c->Wh);
 }
 int nq_jacobian_psi_phi(nq_ctx* c, double* out_cplx) {
   // out: full plane F[u phix + v phiy] (the caller zeroes [0,0])
+  NQ_SINGLE_RANK(c, "nq_jacobian_psi_phi");
   if (!c || !out_cplx) return -1;
   if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
   HIPCHK(c, hipSetDevice(c->device));
   launch_products(c);
-  launch_A(c, false, {c->Mj}, false);
-  launch_B(c, false, c->Mj, c->scr_f0, false, 1.0);
+  launch_A_m(c, false, {&c->mJ});
+  launch_B_p(c, false, c->mJ.ys, c->mJ.pitch, c->scr_f0, c->N, c->N, 1.0);
   HIPCHK(c, hipMemcpyAsync(out_cplx, c->scr_f0, sizeof(cd) * (size_t)c->N * c->N, hipMemcpyDeviceToHost, c->stream));
   return nq_sync(c);
 }
 int nq_jacobian_phic_phi(nq_ctx* c, double* out_cplx) {
   // out: half-spectrum plane F[Re i(phix* phiy - phiy* phix)]
+  NQ_SINGLE_RANK(c, "nq_jacobian_phic_phi");
   if (!c || !out_cplx) return -1;
   if (c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "jacobian_phic_phi exists only in the coupled model");
   HIPCHK(c, hipSetDevice(c->device));
   launch_wavepv(c);
-  launch_A(c, false, {c->Mb}, true);
-  launch_B(c, false, c->Mb, c->scr_h0, true, 1.0);
+  launch_A_m(c, false, {&c->mB});
+  launch_B_p(c, false, c->mB.ys, c->mB.pitch, c->scr_h0, c->Ph, c->Wh, 1.0);
   return get_half_spec(c, c->scr_h0, out_cplx);
 }
 

@@ -19,6 +19,53 @@ namespace nq {
 
 enum { MODE_COUPLED = 0, MODE_UNCOUPLED = 1, MODE_QG = 2 };
 
+// ---- slab decomposition: layouts --------------------------------------------
+// With P ranks, physical / mixed-space rows are split by y (N/P local rows, "X side") and spectral /
+// mixed-space columns by kx (W columns per rank, "Y side").  Arrays that travel together between the two
+// sides form an exchange GROUP: one buffer per side whose rows interleave the group's arrays
+// (row = [array0 segment | array1 segment | ...], `pitch` elements).  On the X side the buffer is cut into P
+// blocks, block d holding the columns owned by rank d for every local row -- exactly the send (or receive)
+// layout of all_to_all_single; on the Y side the P received blocks are simply rows [0, N) of a column slab.
+// So element kx of local row y of one array sits at
+//     X side: xs + (kx / W) * blk + y * pitch + kx % W          Y side: ys + y_global * pitch + k_local
+// and nothing is ever packed or unpacked.  P = 1 is the same code with W = full width (block 0 only).
+struct MArr {
+  cd* xs;            // X-side base, column offset of this array inside the group's rows included
+  cd* ys;            // Y-side base, idem (== xs when P == 1)
+  int pitch;         // row pitch of the group (elements)
+  int W;             // columns of this array owned by one rank
+  int shift;         // kx / W = kx >> shift when >= 0 (power-of-two W, or 30 when P == 1)
+  unsigned magic;    // else kx / W = (kx * magic) >> 24, magic = ceil(2^24 / W); exact for kx < 8192, W < 2048
+  long long blk;     // X-side block stride = local rows * pitch
+};
+struct XRow {        // one local row of an MArr on the X side
+  cd* p;
+  int W, shift;
+  unsigned magic;
+  long long blk;
+  __device__ __forceinline__ cd* at(int kx) const {
+    const int b = shift >= 0 ? (kx >> shift) : (int)(((unsigned)kx * magic) >> 24);
+    return p + (long long)b * blk + (kx - b * W);
+  }
+};
+__device__ __forceinline__ XRow xrow(const MArr& a, size_t row) {
+  XRow r;
+  r.p = a.xs + row * (size_t)a.pitch;
+  r.W = a.W;
+  r.shift = a.shift;
+  r.magic = a.magic;
+  r.blk = a.blk;
+  return r;
+}
+// Column-slab geometry of the spectral (Y-side) kernels.
+struct YGeom {
+  int k0;            // global column index of local column 0
+  int width;         // valid local columns
+  int pitch_s;       // row pitch of the local spectral planes (state, coefficients, filter)
+  int S2;            // N = S1 * S2
+  int kernel_family; // 1: Kernel family (c2c semantics of the reference), 0: QGModel (rfft semantics)
+};
+
 
 // Keeps hipcc from hoisting the next phase's global loads (and interleaving independent FFTs) across a
 // phase boundary of the fused row kernels: that inflates the live set past 256 VGPRs and spills.
@@ -35,17 +82,17 @@ template <int P> struct HsRegs {
   cd a[P / 2], b[P / 2], an, bn;      // elements m = j + t*T (t < P/2) and, for thread j = 0, m = N/2
 };
 template <int N, int P, int T, bool PAIR>
-__device__ __forceinline__ void hs_load(HsRegs<P>& r, const cd* __restrict__ rowA, const cd* __restrict__ rowB, int j) {
+__device__ __forceinline__ void hs_load(HsRegs<P>& r, const XRow& rowA, const XRow& rowB, int j) {
 #pragma unroll
   for (int t = 0; t < P / 2; ++t) {
-    r.a[t] = rowA[j + t * T];
-    r.b[t] = PAIR ? rowB[j + t * T] : cmake(0, 0);
+    r.a[t] = *rowA.at(j + t * T);
+    r.b[t] = PAIR ? *rowB.at(j + t * T) : cmake(0, 0);
   }
   r.an = cmake(0, 0);
   r.bn = cmake(0, 0);
   if (j == 0) {
-    r.an = rowA[N / 2];
-    if (PAIR) r.bn = rowB[N / 2];
+    r.an = *rowA.at(N / 2);
+    if (PAIR) r.bn = *rowB.at(N / 2);
   }
 }
 // Build Z = A + i*B over the full row from the registers: every half-spectrum element was fetched from
@@ -86,8 +133,8 @@ __device__ __forceinline__ void hs_pack(cd (&w)[P], const HsRegs<P>& r, int j, i
 // After a forward row FFT of z = a + i*b (a, b real), split into the two half spectra and store
 // kx = 0..N/2.  Needs the mirrored element Z[N-kx], fetched through LDS.
 template <int N, int P, int T, typename F>
-__device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* lds, cd* __restrict__ rowA,
-                                                  cd* __restrict__ rowB, double scaleB = 1.0) {
+__device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* lds, const XRow& rowA,
+                                                  const XRow& rowB, double scaleB = 1.0) {
   wg_barrier();
 #pragma unroll
   for (int t = 0; t < P; ++t) lds[F::lds_index(j + t * T, c)] = r[t];
@@ -99,8 +146,8 @@ __device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* 
       const cd z = r[t];
       const cd zm = lds[F::lds_index((N - kx) % N, c)];
       // A = (Z + conj Zm)/2 ; B = (Z - conj Zm)/(2i)
-      rowA[kx] = cmake(0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y));
-      rowB[kx] = cmake(scaleB * 0.5 * (z.y + zm.y), scaleB * 0.5 * (zm.x - z.x));
+      *rowA.at(kx) = cmake(0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y));
+      *rowB.at(kx) = cmake(scaleB * 0.5 * (z.y + zm.y), scaleB * 0.5 * (zm.x - z.x));
     }
   }
   wg_barrier();
@@ -110,14 +157,12 @@ __device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* 
 // The spectral row of phi is fetched once and kept (sp) for the second transform (phix = ifft(ik phi)).
 template <int N>
 __global__ void __launch_bounds__(XPlan1<N>::THREADS, XPlan1<N>::MIN_WAVES)
-k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __restrict__ Ma, cd* __restrict__ Mb,
-           int Ph, const cd* __restrict__ tw, const double* __restrict__ kk) {
+k_x_wavepv(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, const double* __restrict__ kk) {
   typedef XPlan1<N> X;
   constexpr int P = X::P, T = X::T;
   const int j = threadIdx.x % T, c = threadIdx.x / T;
   const size_t row = (size_t)blockIdx.x * X::C + c;
-  const cd* __restrict__ rphi = Mphi + row * N;
-  const cd* __restrict__ rphiy = Mphiy + row * N;
+  const XRow rphi = xrow(Mphi, row), rphiy = xrow(Mphiy, row);
   cd* lds = reinterpret_cast<cd*>(nq_smem);
   // stage twiddles: table in LDS behind the exchange area (`tw` = host-built stage table here)
   cd* twl = lds + XPlan1<N>::F::LDS_ELEMS;
@@ -130,13 +175,13 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int kx = j + t * T;
-    w[t] = rphi[kx];
+    w[t] = *rphi.at(kx);
     gx[t] = cscale(cmul_i(w[t]), kk[kx]);
   }
   constexpr bool PREFETCH = (P <= 8);       // with 16 points/thread the extra 64 VGPRs would spill
   if (PREFETCH) {
 #pragma unroll
-    for (int t = 0; t < P; ++t) py[t] = rphiy[j + t * T];      // in flight during the next two transforms
+    for (int t = 0; t < P; ++t) py[t] = *rphiy.at(j + t * T);      // in flight during the next two transforms
   }
   NQ_PHASE_FENCE();
   X::F::template run<true>(w, j, c, lds, twr);
@@ -149,7 +194,7 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
   NQ_PHASE_FENCE();
   X::F::template run<true>(gx, j, c, lds, twr);
 #pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = PREFETCH ? py[t] : rphiy[j + t * T];
+  for (int t = 0; t < P; ++t) w[t] = PREFETCH ? py[t] : *rphiy.at(j + t * T);
   NQ_PHASE_FENCE();
   X::F::template run<true>(w, j, c, lds, twr);
 #pragma unroll
@@ -181,7 +226,7 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
   NQ_PHASE_FENCE();
   X::F::template run<false>(w, j, c, lds, twr);
   NQ_PHASE_FENCE();
-  unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, Ma + row * Ph, Mb + row * Ph, isb);
+  unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, xrow(Ma, row), xrow(Mb, row), isb);
 }
 
 // ---- X2: all nonlinear products of one stage ------------------------------------------------
@@ -190,19 +235,17 @@ k_x_wavepv(const cd* __restrict__ Mphi, const cd* __restrict__ Mphiy, cd* __rest
 // MODE_QG: only Muq, Mvq.  MODE_UNCOUPLED: q_psi = q, phix/phiy from the (possibly stale) Mgx/Mgy.
 // Register plan: q, q_psi, u, v are reals (32 VGPRs each); complex working sets are 64.
 struct BudgetX {
-  const cd* Mlap;     // T_y^-1[-wv2 phih] / M
-  const cd* Mdiss;    // T_y^-1[-(nu4w wv4 + nuw wv2 + muw) phih] / M, or null: diss = nuw lap(phi) - muw phi
+  MArr Mlap;          // T_y^-1[-wv2 phih] / M
+  MArr Mdiss;         // T_y^-1[-(nu4w wv4 + nuw wv2 + muw) phih] / M (has_diss), else diss = nuw lap(phi) - muw phi
+  int has_diss;
   double nuw, muw;
   double* part;       // [workgroup][2]: sum q_psi Im(conj(phi) lap(phi)), sum q_psi Re(diss conj(phi))
 };
 
 template <int N, int MODE, bool BUD>
 __global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
-k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __restrict__ Mq,
-             const cd* __restrict__ Mqw, const cd* __restrict__ Mphi, const cd* __restrict__ Mgx,
-             const cd* __restrict__ Mgy, cd* __restrict__ Muq, cd* __restrict__ Mvq, cd* __restrict__ Mj,
-             cd* __restrict__ Mr, int Ph, const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq,
-             BudgetX bx) {
+k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy, MArr Muq, MArr Mvq, MArr Mj, MArr Mr,
+             const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq, BudgetX bx) {
   typedef XPlan<N> X;
   typedef typename X::F F;
   constexpr int P = X::P, T = X::T;
@@ -222,8 +265,8 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
   // it (barriers inside the transforms no longer wait for global memory), so with one workgroup per CU
   // the HBM latency hides behind the FFTs.  Every mixed-space input is fetched exactly once.
   HsRegs<P> h1, h2;
-  hs_load<N, P, T, MODE == MODE_COUPLED>(h1, Mq + row * Ph, Mqw + row * Ph, j);
-  hs_load<N, P, T, true>(h2, Mu + row * Ph, Mp + row * Ph, j);
+  hs_load<N, P, T, MODE == MODE_COUPLED>(h1, xrow(Mq, row), xrow(MODE == MODE_COUPLED ? Mqw : Mq, row), j);
+  hs_load<N, P, T, true>(h2, xrow(Mu, row), xrow(Mp, row), j);
   NQ_PHASE_FENCE();
   hs_pack<N, P, T, F, MODE == MODE_COUPLED>(w, h1, j, c, lds, kk, false, false);
   NQ_PHASE_FENCE();
@@ -238,9 +281,9 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
   hs_pack<N, P, T, F, true>(w, h2, j, c, lds, kk, true, v_zero_nyq != 0);
   cd sp[P];          // spectral row of phi: kept for phix (Coupled) and for the budget's diss row
   if (MODE != MODE_QG) {
-    const cd* __restrict__ rp = Mphi + row * N;
+    const XRow rp = xrow(Mphi, row);
 #pragma unroll
-    for (int t = 0; t < P; ++t) sp[t] = rp[j + t * T];
+    for (int t = 0; t < P; ++t) sp[t] = *rp.at(j + t * T);
   }
   NQ_PHASE_FENCE();
   F::template run<true>(w, j, c, lds, twr);
@@ -253,13 +296,16 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
   NQ_PHASE_FENCE();
   F::template run<false>(w, j, c, lds, twr);
   NQ_PHASE_FENCE();
-  unpack_pair_store<N, P, T, F>(w, j, c, lds, Muq + row * Ph, Mvq + row * Ph);
+  unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow(Muq, row), xrow(Mvq, row));
   if (MODE == MODE_QG) return;
   cd pre[P];         // prefetch buffer: Mlap (budgets), then Mgx (UnCoupled), then Mgy
+  {
+    const XRow rl = xrow(bx.Mlap, row);
 #pragma unroll
-  for (int t = 0; t < P; ++t) {
-    w[t] = sp[t];
-    if (BUD) pre[t] = bx.Mlap[row * N + j + t * T];
+    for (int t = 0; t < P; ++t) {
+      w[t] = sp[t];
+      if (BUD) pre[t] = *rl.at(j + t * T);
+    }
   }
   NQ_PHASE_FENCE();
   F::template run<true>(w, j, c, lds, twr);
@@ -272,12 +318,13 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
     // by Parseval along the row: sum_x conj(r) g = sum_kx conj(R^[kx]) G[kx] with r = phi q_psi (just
     // transformed, in w) and G the mixed-space row of g (already carries the 1/M of the inverse).
     double acc[2] = {0.0, 0.0};
+    const XRow rd = xrow(bx.has_diss ? bx.Mdiss : bx.Mlap, row);
 #pragma unroll
     for (int t = 0; t < P; ++t) {
       const cd L = pre[t];
       acc[0] += w[t].x * L.y - w[t].y * L.x;
       cd G;
-      if (bx.Mdiss) G = bx.Mdiss[row * N + j + t * T];
+      if (bx.has_diss) G = *rd.at(j + t * T);
       else G = cmake(bx.nuw * L.x - bx.muw * sp[t].x, bx.nuw * L.y - bx.muw * sp[t].y);
       acc[1] += w[t].x * G.x + w[t].y * G.y;
     }
@@ -285,17 +332,20 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
     block_sum_store<2>(acc, red, bx.part + 2 * (size_t)blockIdx.x);
   }
   {
-    cd* __restrict__ rp = Mr + row * N;
+    const XRow rp = xrow(Mr, row);
 #pragma unroll
-    for (int t = 0; t < P; ++t) rp[j + t * T] = w[t];
+    for (int t = 0; t < P; ++t) *rp.at(j + t * T) = w[t];
   }
   // advection u phix + v phiy: w <- u*phix, then w += v*phiy
+  {
+    const XRow rgx = xrow(Mgx, row), rgy = xrow(Mgy, row);
 #pragma unroll
-  for (int t = 0; t < P; ++t) {
-    const int kx = j + t * T;
-    const cd g = (MODE == MODE_COUPLED) ? sp[t] : Mgx[row * N + kx];
-    w[t] = cscale(cmul_i(g), kk[kx]);
-    pre[t] = Mgy[row * N + kx];
+    for (int t = 0; t < P; ++t) {
+      const int kx = j + t * T;
+      const cd g = (MODE == MODE_COUPLED) ? sp[t] : *rgx.at(kx);
+      w[t] = cscale(cmul_i(g), kk[kx]);
+      pre[t] = *rgy.at(kx);
+    }
   }
   NQ_PHASE_FENCE();
   F::template run<true>(w, j, c, lds, twr);
@@ -308,9 +358,9 @@ k_x_products(const cd* __restrict__ Mu, const cd* __restrict__ Mp, const cd* __r
   NQ_PHASE_FENCE();
   F::template run<false>(w, j, c, lds, twr);
   {
-    cd* __restrict__ rp = Mj + row * N;
+    const XRow rp = xrow(Mj, row);
 #pragma unroll
-    for (int t = 0; t < P; ++t) rp[j + t * T] = w[t];
+    for (int t = 0; t < P; ++t) *rp.at(j + t * T) = w[t];
   }
 }
 
@@ -393,14 +443,14 @@ struct DualQ {
 // ---- Sq: nonlinear term + stage update of q-hat on the half spectrum --------------------------------
 template <int S1, bool DUAL>
 __global__ void __launch_bounds__(YPlan<S1>::THREADS)
-k_s_q(const cd* __restrict__ Huq, const cd* __restrict__ Hvq, EtdArrays ea, int stage, int Wh, int Ph, int S2,
-      const double* __restrict__ kk, const double* __restrict__ ll, int kernel_family, const cd* __restrict__ tw,
-      int tw_step_N, DualQ dq) {
+k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __restrict__ kk,
+      const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N, DualQ dq) {
   typedef YPlan<S1> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
   const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
-  const bool ok = k < Wh;
+  const int kg = g.k0 + k, S2 = g.S2, kernel_family = g.kernel_family;
+  const bool ok = k < g.width;
   const int N = S1 * S2;
   constexpr bool dual = DUAL;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
@@ -409,32 +459,32 @@ k_s_q(const cd* __restrict__ Huq, const cd* __restrict__ Hvq, EtdArrays ea, int 
   cd f1[P], f2[P];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
-    const size_t at = (size_t)(l1 * S1 + j + t * T) * Ph + k;
-    f1[t] = ok ? Huq[at] : cmake(0, 0);
-    f2[t] = ok ? Hvq[at] : cmake(0, 0);
+    const size_t at = (size_t)(l1 * S1 + j + t * T) * Huq.pitch + k;
+    f1[t] = ok ? Huq.ys[at] : cmake(0, 0);
+    f2[t] = ok ? Hvq.ys[at] : cmake(0, 0);
   }
   Y::F::template run<false>(f1, j, c, lds, twr);
   Y::F::template run<false>(f2, j, c, lds, twr);
   if (!ok) return;
-  const double kx = kk[k];
-  const bool interior = (k > 0) && (k < N / 2);
+  const double kx = kk[kg];
+  const bool interior = (kg > 0) && (kg < N / 2);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int l = l1 + S2 * (j + t * T);
-    const size_t idx = (size_t)l * Ph + k;
+    const size_t idx = (size_t)l * g.pitch_s + k;
     const double ly = ll[l];
     const bool pass_row = kernel_family && interior && l == N / 2;      // see DESIGN.md "Nyquist lines"
     if constexpr (!dual) {
       const double lz = pass_row ? 0.0 : ly;
       // N_q = -(ik F1 + il F2)
       cd Nl = cmake(kx * f1[t].y + lz * f2[t].y, -(kx * f1[t].x + lz * f2[t].x));
-      if (kernel_family && l == 0 && k == 0) Nl = cmake(0, 0);   // jach[0,0] = 0 (QGModel does not)
+      if (kernel_family && l == 0 && kg == 0) Nl = cmake(0, 0);   // jach[0,0] = 0 (QGModel does not)
       etd_update(ea, idx, Nl, stage);
     } else {
       const double lm = pass_row ? -ly : ly;
       cd Np = cmake(kx * f1[t].y + ly * f2[t].y, -(kx * f1[t].x + ly * f2[t].x));
       cd Nm = cmake(kx * f1[t].y + lm * f2[t].y, -(kx * f1[t].x + lm * f2[t].x));
-      if (l == 0 && k == 0) {
+      if (l == 0 && kg == 0) {
         Np = cmake(0, 0);
         Nm = cmake(0, 0);
       }
@@ -450,17 +500,18 @@ k_s_q(const cd* __restrict__ Huq, const cd* __restrict__ Hvq, EtdArrays ea, int 
 struct BudgetW {
   double* part;        // [workgroup][6]: S0..S3 of the NEW phih, then GJ, XJ of this stage; null = off
   const cd* y_start;   // phih at the start of this stage (what J was computed from)
-  cd* Hlap;
-  cd* Hdiss;           // null unless nu4w != 0
+  MArr Hlap;
+  MArr Hdiss;          // used when has_diss (nu4w != 0)
+  int has_diss;
   double nu4w, nuw, muw;
 };
 
 // a[], b[] hold y/M and i*l*y/M on return; budgets: sums over the new y and emission of lap / diss
 template <int P, int T>
 __device__ __forceinline__ void phi_outputs(const cd (&y)[P], cd (&a)[P], cd (&b)[P], cd (&lap)[P], int l1, int S2,
-                                            int j, int k, double invM, const double* __restrict__ kk,
+                                            int j, int kg, double invM, const double* __restrict__ kk,
                                             const double* __restrict__ ll, bool bud, double (&s)[4]) {
-  const double kx = kk[k];
+  const double kx = kk[kg];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int l = l1 + S2 * (j + t * T);
@@ -481,13 +532,14 @@ __device__ __forceinline__ void phi_outputs(const cd (&y)[P], cd (&a)[P], cd (&b
 
 template <int S1>
 __global__ void __launch_bounds__(YPlan<S1>::THREADS)
-k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int stage, int S2,
-        cd* __restrict__ Hphi, cd* __restrict__ Hphiy, double invM, const double* __restrict__ kk,
-        const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N, BudgetW bw) {
+k_s_phi(MArr Hj, MArr Hr, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphiy, double invM,
+        const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N,
+        BudgetW bw) {
   typedef YPlan<S1> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
   const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int kg = g.k0 + k, S2 = g.S2;
   const int N = S1 * S2;
   const bool bud = bw.part != nullptr;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
@@ -498,18 +550,18 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
   cd a[P], b[P], y[P];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
-    const size_t at = (size_t)(l1 * S1 + j + t * T) * N + k;
-    a[t] = Hj[at];
-    b[t] = Hr[at];
+    const size_t at = (size_t)(l1 * S1 + j + t * T) * Hj.pitch + k;
+    a[t] = Hj.ys[at];
+    b[t] = Hr.ys[at];
   }
   Y::F::template run<false>(a, j, c, lds, twr);
   Y::F::template run<false>(b, j, c, lds, twr);
   double sj[2] = {0.0, 0.0};
-  const double kx = kk[k];
+  const double kx = kk[kg];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int l = l1 + S2 * (j + t * T);
-    const size_t idx = (size_t)l * N + k;
+    const size_t idx = (size_t)l * g.pitch_s + k;
     if (bud) {
       // gamma2 ~ sum Re(conj(lap_h) J), xi1 ~ -sum Im(diss_h conj(J)) with lap_h = -wv2 ys, diss_h = -d ys
       const cd ys = bw.y_start[idx];
@@ -520,27 +572,27 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
       sj[1] += -d * (ys.y * a[t].x - ys.x * a[t].y);
     }
     cd J = a[t];
-    if (l == 0 && k == 0) J = cmake(0, 0);
+    if (l == 0 && kg == 0) J = cmake(0, 0);
     // N_phi = -J - 0.5 i R
     const cd Nl = cmake(-J.x + 0.5 * b[t].y, -J.y - 0.5 * b[t].x);
     y[t] = etd_update(ea, idx, Nl, stage);
   }
   double s4[4] = {0.0, 0.0, 0.0, 0.0};
   cd lap[P];
-  phi_outputs<P, T>(y, a, b, lap, l1, S2, j, k, invM, kk, ll, bud, s4);
+  phi_outputs<P, T>(y, a, b, lap, l1, S2, j, kg, invM, kk, ll, bud, s4);
   Y::F::template run<true>(a, j, c, lds, twr);
   Y::F::template run<true>(b, j, c, lds, twr);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
-    const size_t at = (size_t)(l1 * S1 + j + t * T) * N + k;
-    Hphi[at] = a[t];
-    Hphiy[at] = b[t];
+    const size_t at = (size_t)(l1 * S1 + j + t * T) * Hphi.pitch + k;
+    Hphi.ys[at] = a[t];
+    Hphiy.ys[at] = b[t];
   }
   if (bud) {
     Y::F::template run<true>(lap, j, c, lds, twr);
 #pragma unroll
-    for (int t = 0; t < P; ++t) bw.Hlap[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
-    if (bw.Hdiss) {
+    for (int t = 0; t < P; ++t) bw.Hlap.ys[(size_t)(l1 * S1 + j + t * T) * bw.Hlap.pitch + k] = lap[t];
+    if (bw.has_diss) {
 #pragma unroll
       for (int t = 0; t < P; ++t) {
         const double ly = ll[l1 + S2 * (j + t * T)];
@@ -549,7 +601,7 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
       }
       Y::F::template run<true>(lap, j, c, lds, twr);
 #pragma unroll
-      for (int t = 0; t < P; ++t) bw.Hdiss[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
+      for (int t = 0; t < P; ++t) bw.Hdiss.ys[(size_t)(l1 * S1 + j + t * T) * bw.Hdiss.pitch + k] = lap[t];
     }
     block_sum_store<4>(s4, red, part);
     block_sum_store<2>(sj, red, part + 4);
@@ -559,13 +611,14 @@ k_s_phi(const cd* __restrict__ Hj, const cd* __restrict__ Hr, EtdArrays ea, int 
 // emit-only variant (set_phi): phih -> Hphi, Hphiy (+ lap, diss, sums with budgets)
 template <int S1>
 __global__ void __launch_bounds__(YPlan<S1>::THREADS)
-k_s_emit_phi(const cd* __restrict__ phih, int S2, cd* __restrict__ Hphi, cd* __restrict__ Hphiy, double invM,
+k_s_emit_phi(const cd* __restrict__ phih, YGeom g, MArr Hphi, MArr Hphiy, double invM,
              const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N,
              BudgetW bw) {
   typedef YPlan<S1> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
   const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int kg = g.k0 + k, S2 = g.S2;
   const int N = S1 * S2;
   const bool bud = bw.part != nullptr;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
@@ -574,23 +627,23 @@ k_s_emit_phi(const cd* __restrict__ phih, int S2, cd* __restrict__ Hphi, cd* __r
   double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
   cd a[P], b[P], y[P], lap[P];
 #pragma unroll
-  for (int t = 0; t < P; ++t) y[t] = phih[(size_t)(l1 + S2 * (j + t * T)) * N + k];
+  for (int t = 0; t < P; ++t) y[t] = phih[(size_t)(l1 + S2 * (j + t * T)) * g.pitch_s + k];
   double s4[4] = {0.0, 0.0, 0.0, 0.0};
-  phi_outputs<P, T>(y, a, b, lap, l1, S2, j, k, invM, kk, ll, bud, s4);
+  phi_outputs<P, T>(y, a, b, lap, l1, S2, j, kg, invM, kk, ll, bud, s4);
   Y::F::template run<true>(a, j, c, lds, twr);
   Y::F::template run<true>(b, j, c, lds, twr);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
-    const size_t at = (size_t)(l1 * S1 + j + t * T) * N + k;
-    Hphi[at] = a[t];
-    Hphiy[at] = b[t];
+    const size_t at = (size_t)(l1 * S1 + j + t * T) * Hphi.pitch + k;
+    Hphi.ys[at] = a[t];
+    Hphiy.ys[at] = b[t];
   }
   if (bud) {
-    const double kx = kk[k];
+    const double kx = kk[kg];
     Y::F::template run<true>(lap, j, c, lds, twr);
 #pragma unroll
-    for (int t = 0; t < P; ++t) bw.Hlap[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
-    if (bw.Hdiss) {
+    for (int t = 0; t < P; ++t) bw.Hlap.ys[(size_t)(l1 * S1 + j + t * T) * bw.Hlap.pitch + k] = lap[t];
+    if (bw.has_diss) {
 #pragma unroll
       for (int t = 0; t < P; ++t) {
         const double ly = ll[l1 + S2 * (j + t * T)];
@@ -599,7 +652,7 @@ k_s_emit_phi(const cd* __restrict__ phih, int S2, cd* __restrict__ Hphi, cd* __r
       }
       Y::F::template run<true>(lap, j, c, lds, twr);
 #pragma unroll
-      for (int t = 0; t < P; ++t) bw.Hdiss[(size_t)(l1 * S1 + j + t * T) * N + k] = lap[t];
+      for (int t = 0; t < P; ++t) bw.Hdiss.ys[(size_t)(l1 * S1 + j + t * T) * bw.Hdiss.pitch + k] = lap[t];
     }
     double* part = bw.part + 6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
     double z2[2] = {0.0, 0.0};
@@ -613,12 +666,11 @@ k_s_emit_phi(const cd* __restrict__ phih, int S2, cd* __restrict__ Hphi, cd* __r
 // (oracle/reduced_pipeline.py proves the equivalence).  Other modes: ph = -wv2i*qh (Ha, Hb unused).
 template <int S1, int MODE>
 __global__ void __launch_bounds__(YPlan<S1>::THREADS)
-k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __restrict__ qh,
-           const double* __restrict__ filt, cd* __restrict__ Hu, cd* __restrict__ Hp, cd* __restrict__ Hq,
-           cd* __restrict__ Hqw, cd* __restrict__ qwh_out, cd* __restrict__ ph_out, int Wh, int Ph, int S2,
-           double invM, double f, const double* __restrict__ kk, const double* __restrict__ ll, int kernel_family,
-           const cd* __restrict__ tw, int tw_step_N, double* __restrict__ bud_part, const cd* __restrict__ q_bud,
-           const cd* __restrict__ qh_minus, const double* __restrict__ filt_m) {
+k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict__ filt, MArr Hu, MArr Hp, MArr Hq,
+           MArr Hqw, cd* __restrict__ qwh_out, cd* __restrict__ ph_out, YGeom g, double invM, double f,
+           const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N,
+           double* __restrict__ bud_part, const cd* __restrict__ q_bud, const cd* __restrict__ qh_minus,
+           const double* __restrict__ filt_m) {
   // bud_part: [workgroup][3] Parseval sums for ep_psi (ref Kernel.py:635-640 / QGModel.py:588-593):
   //   sum w*wv4*Re(qb conj psi), sum w*wv2*Re(q conj psi), sum w*Re(qb conj psi); qb = q_bud (QGModel's
   //   stale q, QGModel.py:401) or q; w = 1 on the self-mirrored columns, 2 elsewhere.
@@ -626,7 +678,8 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
   const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
-  const bool ok = k < Wh;
+  const int kg = g.k0 + k, S2 = g.S2, kernel_family = g.kernel_family;
+  const bool ok = k < g.width;
   const int N = S1 * S2;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
   typename Y::F::Tw twr;
@@ -637,30 +690,30 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
   if (MODE == MODE_COUPLED) {
 #pragma unroll
     for (int t = 0; t < P; ++t) {
-      const size_t at = (size_t)(l1 * S1 + j + t * T) * Ph + k;
-      a[t] = ok ? Ha[at] : cmake(0, 0);
-      b[t] = ok ? Hb[at] : cmake(0, 0);
+      const size_t at = (size_t)(l1 * S1 + j + t * T) * Ha.pitch + k;
+      a[t] = ok ? Ha.ys[at] : cmake(0, 0);
+      b[t] = ok ? Hb.ys[at] : cmake(0, 0);
     }
     Y::F::template run<false>(a, j, c, lds, twr);
     Y::F::template run<false>(b, j, c, lds, twr);
   }
-  const double kx = ok ? kk[k] : 0.0;
+  const double kx = ok ? kk[kg] : 0.0;
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int l = l1 + S2 * (j + t * T);
-    const size_t idx = (size_t)l * Ph + k;
+    const size_t idx = (size_t)l * g.pitch_s + k;
     const double ly = ll[l];
     const double wv2 = kx * kx + ly * ly;
     const double wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
     cd qv = ok ? qh[idx] : cmake(0, 0);
-    if (qh_minus && ok && k > 0 && k < N / 2) {          // dual copy: physical space sees the mean
+    if (qh_minus && ok && kg > 0 && kg < N / 2) {          // dual copy: physical space sees the mean
       const cd qm = qh_minus[idx];
       qv = cmake(0.5 * (qv.x + qm.x), 0.5 * (qv.y + qm.y));
     }
     cd qw = cmake(0, 0), psi;
     if (MODE == MODE_COUPLED) {
       cd B = b[t];
-      if (l == 0 && k == 0) B = cmake(0, 0);
+      if (l == 0 && kg == 0) B = cmake(0, 0);
       const double g = 0.5 * (-wv2);
       double fl = ok ? filt[idx] : 0.0;
       if (filt_m && ok) fl = 0.5 * (fl + filt_m[idx]);     // Hermitian part of filtr * (Hermitian field)
@@ -674,13 +727,13 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
       if (MODE == MODE_COUPLED) qwh_out[idx] = qw;
     }
     if (bud_part && ok) {
-      const bool special = (k == 0 || k == N / 2);
+      const bool special = (kg == 0 || kg == N / 2);
       cd qB = q_bud ? q_bud[idx] : qv, qQ = qv, ps = psi;
       if (special) {
         // mean(a*b) of REAL fields uses the Hermitian part (in l) of the self-mirrored columns -- what
         // irfft2 / `.real` keep.  q-hat(-l) comes from memory; psi(-l) follows from it because qwh is
         // Hermitian there: psi(-l) = wv2i (conj(qwh(l)) - q(-l)).
-        const size_t im = (size_t)((N - l) % N) * Ph + k;
+        const size_t im = (size_t)((N - l) % N) * g.pitch_s + k;
         const cd qm = qh[im];
         const cd qbm = q_bud ? q_bud[im] : qm;
         const cd psm = (MODE == MODE_COUPLED) ? cmake(wv2i * (qw.x - qm.x), wv2i * (-qw.y - qm.y))
@@ -712,11 +765,11 @@ k_s_invert(const cd* __restrict__ Ha, const cd* __restrict__ Hb, const cd* __res
   if (ok) {
 #pragma unroll
     for (int t = 0; t < P; ++t) {
-      const size_t at = (size_t)(l1 * S1 + j + t * T) * Ph + k;
-      Hu[at] = u[t];
-      Hp[at] = a[t];
-      Hq[at] = q[t];
-      if (MODE == MODE_COUPLED) Hqw[at] = b[t];
+      const size_t at = (size_t)(l1 * S1 + j + t * T) * Hu.pitch + k;
+      Hu.ys[at] = u[t];
+      Hp.ys[at] = a[t];
+      Hq.ys[at] = q[t];
+      if (MODE == MODE_COUPLED) Hqw.ys[at] = b[t];
     }
   }
   if (bud_part) block_sum_store<3>(s3, red, bud_part + 3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));

@@ -1034,16 +1034,23 @@ static int create_impl(const nq_params* p, const double* kk, const double* ll, c
       if (c->nwq < 1) c->nwq = 1;
       ALLOC(c, c->partQ, (size_t)4 * c->nwq * 3);
       ALLOC(c, c->part0Q, (size_t)c->nwq * 3);
-      ALLOC(c, c->carryQ, (size_t)4);
       ALLOC(c, c->acc, (size_t)4);
-      if (ext && ext[8]) c->bsums = reinterpret_cast<double*>(ext[8]);
-      else ALLOC(c, c->bsums, (size_t)64);
+      // everything that has to be summed over ranks lives in one 64-double block (external when the caller
+      // does the all-reduce): [0,44) stage sums of a step, [44,48) carried phi sums, [48,51) carried q sums,
+      // [51] frozen gradient sum
+      if (ext && ext[8]) {
+        c->bsums = reinterpret_cast<double*>(ext[8]);
+        HIPCHK(c, hipMemsetAsync(c->bsums, 0, 64 * sizeof(double), c->stream));
+      } else {
+        ALLOC(c, c->bsums, (size_t)64);
+      }
+      c->carryW = c->bsums + 44;
+      c->carryQ = c->bsums + 48;
+      c->gradS1 = c->bsums + 51;
       if (c->kernel_family) {
         ALLOC(c, c->partX, (size_t)4 * c->nwx * 2);
         ALLOC(c, c->partW, (size_t)4 * c->nww * 6);
         ALLOC(c, c->part0W, (size_t)c->nww * 6);
-        ALLOC(c, c->carryW, (size_t)4);
-        ALLOC(c, c->gradS1, (size_t)1);
       }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1274,9 +1281,9 @@ int nq_phase(nq_ctx* c, int phase, int stage) {
   return 0;
 }
 
-// device buffers that must be summed over ranks: which 0 = the 44 stage sums of one step (between
-// NQ_PH_BUDGET_SUMS and NQ_PH_BUDGET_FINISH), 1 = carried phi sums (4, after NQ_PH_EMIT_PHI),
-// 2 = carried q sums (3, after NQ_PH_INVERT_NOW), 3 = frozen gradient sum (1, after nq_refresh_grad_phi)
+// The 64-double block that has to be summed over ranks at three points (see nq_phase): elements [0,44) after
+// NQ_PH_BUDGET_SUMS, [44,48) after NQ_PH_EMIT_PHI, [48,51) after NQ_PH_INVERT_NOW.  It is buffers[8] of
+// nq_create_slab when that was given.
 int nq_reduce_buffer(nq_ctx* c, int which, void** ptr, int* count) {
   if (!c || !ptr || !count) return -1;
   if (!c->bud) NQ_FAIL(c, -4, "budgets are disabled in this context");
@@ -1421,6 +1428,7 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
     *out = h[0];
     return rc;
   }
+  NQ_SINGLE_RANK(c, "nq_get_scalar (ids other than the budget increments)");
   if (id == NQ_S_KE_QG) {
     hipLaunchKernelGGL(k_reduce, dim3((c->Wh + 255) / 256, N), dim3(256), 0, c->stream, c->ph, c->Wh, c->Ph, N, 1, c->kk, c->ll, d);
     HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -1,0 +1,85 @@
+"""Slab decomposition on ONE GPU: P virtual ranks in one process, block copies instead of the RCCL
+all-to-all (niwqg_amd.slab.VirtualTransport).  Everything except the collective call itself is the code that
+runs with one process per GPU: blocked-row addressing in the row kernels, column-slab geometry in the spectral
+kernels, the phase sequence, the cross-rank sums of the budget integrals."""
+import numpy as np
+import pytest
+
+from oracle import niwqg_oracle as O
+from test_oracle_golden import notebook_kwargs, rel, L, K0, U0
+
+pytestmark = pytest.mark.gpu
+
+
+def setup_case(kind, nx, use_filter=True):
+    from niwqg_amd import _lib
+    kw = notebook_kwargs(nx, use_filter)
+    if kind == "qg":
+        o = O.QGOracle(L=L, nx=nx, tmax=1e30, dt=kw["dt"], twrite=10 ** 9, nu4=kw["nu4"], nu=5.0, mu=1e-8,
+                       use_filter=use_filter, U=-U0, tdiags=10 ** 9, beta=2e-11)
+        phys = dict(U=-U0, nu=5.0, nu4=kw["nu4"], mu=1e-8, beta=2e-11)
+        model = _lib.QG
+    else:
+        o = O.NIWQGOracle(kind, **kw)
+        phys = dict(U=kw["U"], f=kw["f"], kappa2=o.kappa2, nu=kw["nu"], nu4=kw["nu4"], mu=kw["mu"], nuw=kw["nuw"],
+                    nu4w=kw["nu4w"], muw=kw["muw"])
+        model = {"coupled": _lib.COUPLED, "uncoupled": _lib.UNCOUPLED}[kind]
+    q0 = O.lamb_dipole(o.grid, U=U0, R=2 * np.pi / K0)
+    phi0 = None if kind == "qg" else 0.2 * O.wave_packet(o.grid, k=2 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2)
+    return model, o, kw["dt"], phys, q0, phi0
+
+
+@pytest.mark.parametrize("kind", ["coupled", "uncoupled", "qg"])
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_virtual_ranks_match_single_context(kind, nranks):
+    from niwqg_amd import _lib, slab
+    nx, nsteps = 256, 3
+    model, o, dt, phys, q0, phi0 = setup_case(kind, nx)
+    # single context
+    one = _lib.Context(model, nx, o.kk, o.ll, o.filtr, dt, budgets=True, **phys)
+    one.set_q(q0)
+    if phi0 is not None:
+        one.set_phi(phi0)
+    one.take_budget_increments() if model != _lib.QG else one.scalar(_lib.S_KE)
+    one.step(nsteps)
+    qh1 = one.field(_lib.F_QH)
+    phih1 = one.field(_lib.F_PHIH) if phi0 is not None else None
+    inc1 = one.take_budget_increments() if model != _lib.QG else (one.scalar(_lib.S_KE),)
+    # P virtual ranks
+    ranks = slab.make_ranks(model, nx, o.kk, o.ll, o.filtr, dt, nranks, budgets=True, **phys)
+    sim = slab.SlabSimulation(ranks, slab.VirtualTransport())
+    sim.set_q_spectrum(np.fft.rfft2(q0))
+    if phi0 is not None:
+        sim.set_phi_spectrum(np.fft.fft2(phi0))
+    for r in ranks:
+        r.budget_increments()
+    sim.step(nsteps)
+    sim.sync()
+    qhP = sim.gather_qh()
+    assert qhP.shape == qh1.shape
+    assert rel(qhP, qh1) < 1e-13
+    if phi0 is not None:
+        assert rel(sim.gather_phih(), phih1) < 1e-13
+    for r in ranks:                      # every rank ends up with the global increments
+        inc = r.budget_increments()
+        assert np.allclose(inc[:len(inc1)], inc1, rtol=1e-10, atol=1e-30), (r.rank, inc, inc1)
+
+
+def test_virtual_ranks_against_the_oracle_with_quirk_q2():
+    """set_q before set_phi (wave-free psi in the first stage), then compare with the reference-pinned oracle."""
+    from niwqg_amd import slab
+    nx, nranks = 256, 4
+    model, o, dt, phys, q0, phi0 = setup_case("coupled", nx, use_filter=False)
+    o.set_q(q0)
+    o.set_phi(phi0)
+    for _ in range(3):
+        o._step_forward()
+    ranks = slab.make_ranks(model, nx, o.kk, o.ll, o.filtr, dt, nranks, budgets=False, **phys)
+    sim = slab.SlabSimulation(ranks, slab.VirtualTransport())
+    sim.set_q_spectrum(np.fft.rfft2(q0))
+    sim.set_phi_spectrum(np.fft.fft2(phi0))
+    sim.step(3)
+    sim.sync()
+    assert rel(sim.gather_phih(), o.phih) < 1e-12
+    qh = sim.gather_qh()
+    assert rel(np.fft.irfft2(qh), o.q) < 1e-12

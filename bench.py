@@ -73,6 +73,57 @@ def build_model(model, nx, device):
     return m
 
 
+class _SlabCtxView(object):
+    """What bench.py needs from a context, on top of a SlabRank."""
+
+    def __init__(self, rank):
+        from niwqg_amd import _lib
+        self.r, self.L, self.h = rank, rank.L, rank.h
+        self.budgets_enabled = rank.budgets
+        self.KERNEL_CLASSES = _lib.Context.KERNEL_CLASSES
+        for name in ("sync", "timer_start", "timer_stop", "profile_enable", "profile_read", "device_bytes", "_chk"):
+            setattr(self, name, getattr(_lib.Context, name).__get__(self))
+
+
+def build_slab(model, nx, grp, local_rank):
+    """One slab-decomposed simulation over all ranks of `grp` (niwqg_amd.slab); every rank prepares the same
+    initial condition on the host and uploads its own column slab of the spectra."""
+    import niwqg_amd
+    from niwqg_amd import _lib, slab, InitialConditions as ic
+    kw = c3_kwargs(nx, model)
+
+    class G(object):          # the grid attributes InitialConditions.LambDipole reads
+        pass
+    g = G()
+    g.nx = nx
+    cell = (np.arange(nx) + 0.5) / nx * L
+    g.x, g.y = np.meshgrid(cell, cell)
+    dk = 2 * np.pi / L
+    ll = dk * np.append(np.arange(0., nx / 2), np.arange(-nx / 2, 0.))
+    kk = ll.copy() if model != "qg" else dk * np.arange(0., nx // 2 + 1)
+    dx = L / nx
+    wvx = np.sqrt((kk[None, :] * dx) ** 2. + (ll[:, None] * dx) ** 2.)
+    filtr = np.exp(-23.6 * (wvx - 0.65 * np.pi) ** 4.)
+    filtr[wvx <= 0.65 * np.pi] = 1.
+    mid = {"coupled": _lib.COUPLED, "uncoupled": _lib.UNCOUPLED, "qg": _lib.QG}[model]
+    phys = dict(U=kw["U"], nu=kw.get("nu", 0.0), nu4=kw["nu4"], mu=kw.get("mu", 0.0))
+    if model != "qg":
+        kappa2 = (kw["m"] * kw["f"] / kw["N"]) ** 2
+        phys.update(f=kw["f"], kappa2=kappa2, nuw=kw["nuw"], nu4w=kw["nu4w"], muw=kw["muw"])
+    ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], grp.world, device=local_rank, only_rank=grp.rank,
+                            budgets=True, **phys)
+    sim = slab.SlabSimulation(ranks, slab.TorchTransport(grp.dist))
+    if model == "qg" and nx == 2048:
+        q = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx))
+    else:
+        q = ic.LambDipole(g, U=U0, R=2 * np.pi / K0)
+    sim.set_q_spectrum(np.fft.rfft2(q))
+    if model != "qg":
+        sim.set_phi_spectrum(np.fft.fft2((np.ones((nx, nx)) + 1j) * (2 * U0) / np.sqrt(2)))
+    sim.sync()
+    return sim, _SlabCtxView(ranks[0])
+
+
 def cpu_baseline(model, nx_target, budget_s=20.0):
     """Reference-faithful numpy oracle (oracle/niwqg_oracle.py), one thread, on a bounded sample:
     the same model at a grid that finishes in ~20 s; steps/s is scaled to nx_target with N^2 log2 N."""
@@ -118,19 +169,48 @@ def main():
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--model", default="coupled", choices=["coupled", "uncoupled", "qg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-slab", action="store_true", help="use the slab path (and its collectives) even with one rank")
+    ap.add_argument("--replicas", action="store_true", help="with --gpus N > 1: N independent replicas instead of one "
+                                                            "slab-decomposed simulation")
     args = ap.parse_args()
 
     from niwqg_amd.distributed import Group, aggregate_throughput
     import torch
-    grp = Group()                      # nccl (= RCCL) when launched with WORLD_SIZE > 1
+    grp = Group(force=args.force_slab)   # nccl (= RCCL) when launched with WORLD_SIZE > 1
     rank, world, local_rank = grp.rank, grp.world, grp.local_rank
     torch.cuda.set_device(local_rank)
 
-    # Round 1: the slab-decomposed multi-GPU path is not built yet; with N > 1 every rank
-    # advances its own replica of the full problem and the line says so ("replicas", weak scaling).
-    m = build_model(args.model, args.nx, local_rank)
-    ctx = m._ctx
-    ctx.step(args.warmup)
+    mode = "single GPU"
+    slab_error = None
+    sim = None
+    if (world > 1 or (args.force_slab and grp.dist is not None)) and not args.replicas:
+        # ONE simulation, slab-decomposed over the ranks: 4 all_to_all_single per stage over RCCL
+        try:
+            sim, ctx = build_slab(args.model, args.nx, grp, local_rank)
+            sim.step(1)                             # exercises every collective once
+            sim.sync()
+            mode = "slab x%d, one all_to_all per transition (16 per step)" % world
+        except Exception as e:                      # never lose the whole scaling run to a transport problem
+            slab_error = "%s: %s" % (type(e).__name__, e)
+            sim = None
+        ok = grp.sum([1.0 if sim is not None else 0.0])[0]
+        if ok < world:                              # all ranks take the same path
+            if slab_error is None:
+                slab_error = "another rank failed to set up the slab path"
+            sim = None
+    if sim is None:
+        m = build_model(args.model, args.nx, local_rank)
+        ctx = m._ctx
+        if world > 1:
+            mode = "replicas x%d (one full problem per GPU)" % world
+
+    def advance(n):
+        if sim is not None:
+            sim.step(n)
+        else:
+            ctx.step(n)
+
+    advance(args.warmup)
     ctx.sync()
 
     def barrier():
@@ -142,18 +222,49 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
-    ctx.step(args.steps)
+    advance(args.steps)
     dev_ms = ctx.timer_stop()
     barrier()
     wall = time.perf_counter() - t0
     launches, kms = ctx.profile_read()
     ctx.profile_enable(-1)
-    sps, wall = aggregate_throughput(grp, args.steps, wall)   # all ranks' steps / max-over-ranks time
+    if sim is not None:
+        # strong scaling: all ranks advance the SAME simulation; whole-job steps/s = steps / slowest rank
+        wall = grp.max(wall)
+        sps = args.steps / wall
+    else:
+        sps, wall = aggregate_throughput(grp, args.steps, wall)   # all ranks' steps / max-over-ranks time
+
+    extra = {}
+    if sim is not None:
+        # volume this rank hands to the all-to-alls per step (off-rank part), for the xGMI arithmetic in DESIGN.md 9
+        per_stage = sum(t.numel() * 16 for t in sim.ranks[0].gx if t is not None)
+        extra["exchange_GB_sent_per_rank_per_step"] = 4 * per_stage * (world - 1) / max(world, 1) / 1e9
+        if world > 1:
+            # the other way to use N GPUs (config 5 style): N independent simulations, no collective.  Timed AFTER
+            # and OUTSIDE the K-step region above; reported as context only, never as `value`.
+            try:
+                sim.sync()
+                m2 = build_model(args.model, args.nx, local_rank)
+                m2._ctx.step(2)
+                m2._ctx.sync()
+                grp.barrier()
+                t1 = time.perf_counter()
+                m2._ctx.step(args.steps)
+                m2._ctx.sync()
+                grp.barrier()
+                extra["replicas_aggregate_steps_per_s"] = aggregate_throughput(grp, args.steps, time.perf_counter() - t1)[0]
+                del m2
+            except Exception as e:
+                extra["replicas_aggregate_steps_per_s"] = None
+                extra["replicas_error"] = "%s: %s" % (type(e).__name__, e)
 
     if rank == 0:
         npts = float(args.nx) ** 2
         k_ms = kms / max(launches, 1)
         k_bytes = (X_PRODUCTS_B_PER_PT[args.model] + (16 if ctx.budgets_enabled and args.model != "qg" else 0)) * npts
+        if sim is not None:
+            k_bytes /= world                       # each rank's launch covers nx/world rows
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
         step_bytes = CANONICAL_B_PER_PT_STEP[args.model] * npts
         out = {
@@ -161,20 +272,20 @@ def main():
                 {"coupled": "Coupled", "uncoupled": "UnCoupled", "qg": "QG"}[args.model], args.nx),
             "value": sps, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%sModel LambDipole %d^2 fp64, ETDRK4, filter on, budgets %s, 1 replica per GPU"
+            "scaling": "strong" if sim is not None else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%sModel LambDipole %d^2 fp64, ETDRK4, filter on, budgets %s"
                                    % (args.model, args.nx, "on" if ctx.budgets_enabled else "off"),
-                       "parallelism": "replicas x%d (slab decomposition not built yet)" % world if world > 1 else "single GPU",
+                       "parallelism": mode, "slab_fallback_reason": slab_error,
                        "device_ms_per_step_hip_events": dev_ms / args.steps,
-                       "device_bytes": ctx.device_bytes()},
+                       "device_bytes": ctx.device_bytes(), **extra},
             "roofline": {"bound": "hbm", "kernel": "k_x_products", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic("k_x_products<%d, %d" % (args.nx, {"coupled": 0, "uncoupled": 1, "qg": 2}[args.model]))
-                         if ctx.budgets_enabled else None,
+                         if (ctx.budgets_enabled and sim is None) else None,
                          "launches": launches, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
                          "step_canonical_bytes": step_bytes,
                          "step_achieved_GBs": step_bytes / (wall / args.steps) / 1e9,
-                         "step_frac_of_peak": step_bytes / (wall / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "step_frac_of_peak": step_bytes / (wall / args.steps) / 1e9 / (HBM_PEAK_GBS * (world if sim is not None else 1))},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, args.nx)

@@ -1,8 +1,9 @@
 """One process per GPU plumbing (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" on CPU).
 
-Round 1 shards only where the path needs no data exchange: independent replicas / ensemble members
-(BASELINE config 5: 64 UnCoupledModel members, no RCCL in the data path).  The slab-decomposed single
-simulation will add its all-to-all here.
+Two ways to use several GPUs: independent replicas / ensemble members (BASELINE config 5: 64 UnCoupledModel
+members, no RCCL in the data path; shard_members / aggregate_throughput below), and ONE simulation
+slab-decomposed over the ranks (niwqg_amd/slab.py), whose all-to-alls go through the
+process group made here.
 """
 import os
 
@@ -10,13 +11,13 @@ import os
 class Group(object):
     """Process-group facade that also works with world size 1 (no torch.distributed needed)."""
 
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, force=False):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
         self.device = None
-        if self.world > 1:
+        if self.world > 1 or (force and "MASTER_ADDR" in os.environ):
             import torch
             import torch.distributed as dist
             if backend is None:

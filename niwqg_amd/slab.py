@@ -113,20 +113,38 @@ class SlabRank(object):
 
 
 class TorchTransport(object):
-    """Real ranks: one SlabRank per process; collectives through torch.distributed (RCCL)."""
+    """Real ranks: one SlabRank per process; collectives through torch.distributed (RCCL).
 
-    def __init__(self, dist):
+    ``stage_via_host=True`` bounces every buffer through host memory so that a CPU-only backend (gloo) can carry
+    the collectives: that is how two processes sharing ONE GPU rehearse the multi-process path in the tests."""
+
+    def __init__(self, dist, stage_via_host=False):
         self.dist = dist
+        self.host = bool(stage_via_host)
 
     def exchange(self, ranks, g, to_y):
         r = ranks[0]
         if r.gx[g] is None:
             return
         send, recv = (r.gx[g], r.gy[g]) if to_y else (r.gy[g], r.gx[g])
+        if send.is_complex():                     # RCCL has no complex type: move (re, im) pairs as float64 rows
+            send, recv = r.torch.view_as_real(send), r.torch.view_as_real(recv)
+        if self.host:
+            hs = send.cpu()
+            hr = r.torch.empty_like(hs)
+            self.dist.all_to_all_single(hr, hs)
+            recv.copy_(hr)
+            return
         self.dist.all_to_all_single(recv, send)
 
     def allreduce(self, ranks, lo, hi):
-        self.dist.all_reduce(ranks[0].sums[lo:hi], op=self.dist.ReduceOp.SUM)
+        part = ranks[0].sums[lo:hi]
+        if self.host:
+            h = part.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+            part.copy_(h)
+            return
+        self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM)
 
 
 class VirtualTransport(object):

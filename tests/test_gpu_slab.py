@@ -83,3 +83,62 @@ def test_virtual_ranks_against_the_oracle_with_quirk_q2():
     assert rel(sim.gather_phih(), o.phih) < 1e-12
     qh = sim.gather_qh()
     assert rel(np.fft.irfft2(qh), o.q) < 1e-12
+
+
+TWO_PROCESS_WORKER = """
+import sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+from niwqg_amd.distributed import Group
+from niwqg_amd import _lib, slab
+from test_gpu_slab import setup_case, rel
+
+g = Group(backend="gloo")                      # both processes share GPU 0; the wire is host-staged gloo
+nx, nsteps = 256, 3
+model, o, dt, phys, q0, phi0 = setup_case("coupled", nx)
+ranks = slab.make_ranks(model, nx, o.kk, o.ll, o.filtr, dt, g.world, device=0, only_rank=g.rank, budgets=True, **phys)
+sim = slab.SlabSimulation(ranks, slab.TorchTransport(g.dist, stage_via_host=True))
+sim.set_q_spectrum(np.fft.rfft2(q0))
+sim.set_phi_spectrum(np.fft.fft2(phi0))
+ranks[0].budget_increments()
+sim.step(nsteps)
+sim.sync()
+inc = ranks[0].budget_increments()
+mine = [torch.from_numpy(ranks[0].download(0)), torch.from_numpy(ranks[0].download(1))]
+parts = [None] * g.world
+g.dist.all_gather_object(parts, (g.rank, mine[0].numpy(), mine[1].numpy(), inc))
+if g.rank == 0:
+    parts.sort(key=lambda t: t[0])
+    qh = np.concatenate([t[1] for t in parts], axis=1)
+    phih = np.concatenate([t[2] for t in parts], axis=1)
+    one = _lib.Context(model, nx, o.kk, o.ll, o.filtr, dt, budgets=True, **phys)
+    one.set_q(q0)
+    one.set_phi(phi0)
+    one.take_budget_increments()
+    one.step(nsteps)
+    assert rel(qh, one.field(_lib.F_QH)) < 1e-13, rel(qh, one.field(_lib.F_QH))
+    assert rel(phih, one.field(_lib.F_PHIH)) < 1e-13
+    inc1 = one.take_budget_increments()
+    for t in parts:
+        assert np.allclose(t[3], inc1, rtol=1e-10, atol=1e-30), (t[0], t[3], inc1)
+    print("two processes agree with one context")
+g.close()
+"""
+
+
+def test_two_processes_one_gpu_host_staged_collectives(tmp_path):
+    """The real multi-process driver (one SlabRank per process, TorchTransport) with two processes sharing the
+    one GPU of the test box; RCCL refuses two ranks on one device, so the collectives are staged through gloo."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two_proc.py"
+    script.write_text(TWO_PROCESS_WORKER % (root, os.path.join(root, "tests")))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "two processes agree with one context" in out.stdout

@@ -169,21 +169,35 @@ __device__ __forceinline__ void twiddle_apply(cd (&v)[R], cd w1, cd w4, cd w8) {
 
 // ---- radix plan -----------------------------------------------------------------------------
 __host__ __device__ constexpr int nq_min(int a, int b) { return a < b ? a : b; }
+// Radices are min(P, 16) except for one smaller "remainder" radix when N is not a power of it.  The remainder
+// goes last (fewest twiddled points) except for rows of 8192 and more, where it goes FIRST: the per-stage twiddle
+// tables of the row kernels grow with the product of the radices before a stage, and with the remainder last the
+// 8192-point table alone would not fit in LDS beside the 128 KB exchange.
+__host__ __device__ constexpr bool plan_rem_first(int N) { return N >= 8192; }
 __host__ __device__ constexpr int plan_radix(int N, int P, int stage) {
+  const int RM = nq_min(P, 16);
+  if (plan_rem_first(N)) {
+    int first = N;
+    while (first > RM) first /= RM;
+    return stage == 0 ? first : RM;
+  }
   int rem = N, R = 1;
   for (int s = 0; s <= stage; ++s) {
-    R = nq_min(rem, nq_min(P, 16));
+    R = nq_min(rem, RM);
     rem /= R;
   }
   return R;
 }
 __host__ __device__ constexpr int plan_stages(int N, int P) {
-  int rem = N, n = 0;
-  while (rem > 1) {
-    rem /= nq_min(rem, nq_min(P, 16));
-    ++n;
-  }
+  int n = 0;
+  for (int rem = N; rem > 1; ++n) rem /= plan_radix(N, P, n);
   return n;
+}
+// twiddle powers a stage needs from a table: w^1 | w^4 (radix >= 8) | w^8 (radix 16).  8192-point rows at 8
+// points per thread (1024 threads) have 18 KB less LDS than that takes: there w^4 is two squarings of w^1.
+__host__ __device__ constexpr bool plan_derive_w4(int N, int P) { return N >= 8192 && P <= 8; }
+__host__ __device__ constexpr int plan_tw_rows(int N, int P, int R) {
+  return plan_derive_w4(N, P) ? 1 : (R >= 16 ? 3 : (R >= 8 ? 2 : 1));
 }
 __host__ __device__ constexpr int plan_ns(int N, int P, int stage) {   // product of radices before `stage`
   int ns = 1;
@@ -255,12 +269,12 @@ struct WgFft {
   }
 
   // Alternative twiddle source for the row kernels: per-stage tables in LDS, entry jr of stage s holds
-  // w^1 | w^4 | w^8 for butterflies with jj % NS == jr (layout: [stage][3][NS]); built on the host
+  // w^1 | w^4 | w^8 for butterflies with jj % NS == jr (layout: [stage][plan_tw_rows][NS]); built on the host
   // (nq_lib.hip: build_stage_table), copied into LDS once per workgroup.  Costs no registers and no
   // VMEM inside the transforms.
   __host__ __device__ static constexpr int tw_off(int stage) {
     int o = 0;
-    for (int s = 1; s < stage; ++s) o += 3 * plan_ns(N, P, s);
+    for (int s = 1; s < stage; ++s) o += plan_tw_rows(N, P, plan_radix(N, P, s)) * plan_ns(N, P, s);
     return o;
   }
   static constexpr int TW_LDS_ELEMS = tw_off(STAGES);
@@ -285,8 +299,16 @@ struct WgFft {
     w1 = t[jr];
     w4 = cmake(1, 0);
     w8 = cmake(1, 0);
-    if constexpr (R >= 8) w4 = t[NS + jr];
-    if constexpr (R >= 16) w8 = t[2 * NS + jr];
+    if constexpr (plan_derive_w4(N, P)) {
+      static_assert(!plan_derive_w4(N, P) || R <= 8, "derived w^4 only for radix <= 8");
+      if constexpr (R >= 8) {
+        const cd w2 = cmul(w1, w1);
+        w4 = cmul(w2, w2);
+      }
+    } else {
+      if constexpr (R >= 8) w4 = t[NS + jr];
+      if constexpr (R >= 16) w8 = t[2 * NS + jr];
+    }
   }
 
   __device__ __forceinline__ static int lds_index(int p, int c) {

@@ -31,8 +31,13 @@ template <int S> struct YPlan {
 #define NQ_XP1 16    // points per thread in k_x_wavepv (fewer live fields: 16 points, two workgroups per CU)
 #endif
 // Row-kernel plan: PP points per thread, WG workgroups per CU the kernel is compiled for.
-template <int N, int PP = NQ_XP, int WG = 1> struct XPlanT {
-  static constexpr int P = (N >= 128) ? PP : 8;
+#ifndef NQ_XP_BIG
+#define NQ_XP_BIG 8   // points per thread for rows of 8192 points (one workgroup per CU: the exchange alone is 128 KB)
+#endif
+template <int N, int PP = NQ_XP, int WG_ = 1, int PBIG = NQ_XP_BIG> struct XPlanT {
+  __host__ __device__ static constexpr int pts(int n) { return n >= 8192 ? PBIG : (n >= 128 ? PP : 8); }
+  static constexpr int P = pts(N);
+  static constexpr int WG = (N >= 8192) ? 1 : WG_;
   static constexpr int T = N / P;
   static constexpr int C = (T >= 64) ? 1 : 64 / T;     // rows per workgroup (>= one wave)
   static constexpr int THREADS = C * T;
@@ -40,9 +45,10 @@ template <int N, int PP = NQ_XP, int WG = 1> struct XPlanT {
   typedef WgFft<N, P, C, true> F;
   // [exchange][stage twiddle table][per-row scratch words][reduction scratch]
   static constexpr size_t LDS_BYTES = (size_t)(F::LDS_ELEMS + F::TW_LDS_ELEMS) * sizeof(cd) + 16 * C + 512;
+  static_assert(LDS_BYTES <= 160 * 1024, "row plan exceeds the 160 KB of LDS of a CU");
 };
-template <int N> using XPlan = XPlanT<N, NQ_XP, 1>;
-template <int N> using XPlan1 = XPlanT<N, NQ_XP1, 2>;
+template <int N> using XPlan = XPlanT<N, NQ_XP, 1, NQ_XP_BIG>;
+template <int N> using XPlan1 = XPlanT<N, NQ_XP1, 2, 16>;
 
 extern __shared__ __attribute__((aligned(16))) unsigned char nq_smem[];
 

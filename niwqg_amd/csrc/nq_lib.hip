@@ -842,9 +842,6 @@ static int create_impl(const nq_params* p, const double* kk, const double* ll, c
   if (!p || !kk || !ll || !filtr || !contour || !out) NQ_FAIL((nq_ctx*)nullptr, -1, "nq_create: null argument");
   int S1, S2;
   if (!plan_for(p->nx, &S1, &S2)) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d unsupported (power of two in [64, 8192])", p->nx);
-  if (p->nx > 4096)
-    NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d: rows longer than 4096 need a split LDS exchange in the fused row "
-            "kernels (128 KB exchange + twiddle table exceed the 160 KB LDS); not built yet", p->nx);
   if (p->model < 0 || p->model > 2) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: unknown model %d", p->model);
   if (P < 1 || rank < 0 || rank >= P || (P & (P - 1)) || p->nx / P < 2 * CL ||
       (P > 1 && (p->nx / 2 + 1 + P - 1) / P >= 2048))
@@ -909,11 +906,12 @@ static int create_impl(const nq_params* p, const double* kk, const double* ll, c
     HIPCHK(c, hipMemcpyAsync(c->tw, twh.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
     // stage tables for the fused row kernels: [stage >= 1][w^1 | w^4 | w^8][jr < NS]
     for (int which = 0; which < 2; ++which) {
-      const int PP = (N >= 128) ? (which == 0 ? NQ_XP : NQ_XP1) : 8;
+      const int PP = which == 0 ? XPlan<8>::pts(N) : XPlan1<8>::pts(N);
       std::vector<double> st;
       for (int sidx = 1; sidx < plan_stages(N, PP); ++sidx) {
         const int R = plan_radix(N, PP, sidx), NS = plan_ns(N, PP, sidx);
-        for (int pw = 1; pw <= 8; pw *= (pw == 1 ? 4 : 2)) {          // powers 1, 4, 8
+        for (int pw = 1; pw <= 8; pw *= (pw == 1 ? 4 : 2)) {          // powers 1, 4, 8 as far as the radix needs
+          if ((pw == 4 && plan_tw_rows(N, PP, R) < 2) || (pw == 8 && plan_tw_rows(N, PP, R) < 3)) continue;
           for (int jr = 0; jr < NS; ++jr) {
             const long long m = ((long long)pw * jr * (N / (NS * R))) % N;
             st.push_back(twh[2 * m]);

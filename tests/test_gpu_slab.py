@@ -142,3 +142,51 @@ def test_two_processes_one_gpu_host_staged_collectives(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "two processes agree with one context" in out.stdout
+
+
+def test_config4_8192_on_8_virtual_ranks_against_the_oracle():
+    """BASELINE config 4 (CoupledModel 8192^2 slab-decomposed over 8 ranks), all 8 ranks on this one GPU.
+    Truth: the reference-pinned oracle at 128^2 on the same band-limited state (the step is exact at any resolution
+    that holds the band; see test_gpu_models.test_full_size_parity_through_resolution_independence)."""
+    from niwqg_amd import _lib, slab
+    from test_gpu_models import _band_limited_state, _low_modes
+    nx, nranks, nsteps = 8192, 8, 2
+    kw = notebook_kwargs(64, False)
+    kw.update(nx=128)
+    o = O.NIWQGOracle("coupled", **kw)
+    q0, phi0 = _band_limited_state(o.grid)
+    o.set_q(q0)
+    o.set_phi(phi0)
+    for _ in range(nsteps):
+        o._step_forward()
+    kw.update(nx=nx)
+    big = O.SpectralGrid(nx, L)
+    q1, phi1 = _band_limited_state(big)
+    phys = dict(U=kw["U"], f=kw["f"], kappa2=o.kappa2, nu=kw["nu"], nu4=kw["nu4"], mu=kw["mu"], nuw=kw["nuw"],
+                nu4w=kw["nu4w"], muw=kw["muw"])
+    filtr = np.ones((nx, nx))
+    ranks = slab.make_ranks(_lib.COUPLED, nx, big.kk, big.ll, filtr, kw["dt"], nranks, budgets=True, **phys)
+    sim = slab.SlabSimulation(ranks, slab.VirtualTransport())
+    sim.set_q_spectrum(np.fft.rfft2(q1))
+    sim.set_phi_spectrum(np.fft.fft2(phi1))
+    del q1, phi1
+    for r in ranks:
+        r.budget_increments()
+    sim.step(nsteps)
+    sim.sync()
+    x0, y0 = big.x.ravel()[0], big.y.ravel()[0]
+    ref = _low_modes(o.phih, o.kk, o.ll, o.grid.x.ravel()[0], o.grid.y.ravel()[0], 128)
+    got = _low_modes(sim.gather_phih(), big.kk, big.ll, x0, y0, nx)
+    assert np.abs(got - ref).max() < 1e-11 * np.abs(ref).max()
+    qh = sim.gather_qh()                                     # half spectrum (ny, nx/2+1): columns 0..12 of the band
+    M = 12
+    rows = np.r_[0:M + 1, nx - M:nx]
+    refq = _low_modes(o.qh, o.kk, o.ll, o.grid.x.ravel()[0], o.grid.y.ravel()[0], 128)[:, :M + 1]
+    gotq = qh[np.ix_(rows, np.arange(M + 1))] / nx ** 2 * np.exp(-1j * (big.kk[:M + 1][None, :] * x0
+                                                                           + big.ll[rows][:, None] * y0))
+    assert np.abs(gotq - refq).max() < 1e-11 * np.abs(refq).max()
+    inc = ranks[3].budget_increments()
+    o0 = O.NIWQGOracle("coupled", **dict(kw, nx=128))
+    o0.set_q(q0)
+    o0.set_phi(phi0)
+    assert np.allclose(inc, [o.Ke - o0.Ke, o.Pw - o0.Pw, o.Kw - o0.Kw], rtol=1e-8, atol=1e-30)

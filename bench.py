@@ -262,7 +262,7 @@ def main():
     if rank == 0:
         npts = float(args.nx) ** 2
         k_ms = kms / max(launches, 1)
-        k_bytes = (X_PRODUCTS_B_PER_PT[args.model] + (16 if ctx.budgets_enabled and args.model != "qg" else 0)) * npts
+        k_bytes = X_PRODUCTS_B_PER_PT[args.model] * npts
         if sim is not None:
             k_bytes /= world                       # each rank's launch covers nx/world rows
         achieved = k_bytes / (k_ms * 1e-3) / 1e9

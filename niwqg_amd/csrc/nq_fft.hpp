@@ -372,6 +372,83 @@ struct WgFft {
   __device__ __forceinline__ static void run(cd (&r)[P], int j, int c, cd* lds, const Src& twr) {
     stages_from<INV, 0, Src>(r, j, c, lds, twr);
   }
+
+  // ---- two independent transforms, stage by stage, through two exchange areas ----------------------
+  // The LDS stores of a stage are the expensive half of an exchange (ds_write_b128 moves 80 B/clk/CU against
+  // 256 B/clk for the reads) and a lone transform leaves them fully exposed: every wave finishes its butterflies
+  // at about the same time, then all of them store.  With two transforms in flight the stores of the first
+  // drain under the butterflies of the second, and one pair of barriers serves both.
+  template <int STAGE> struct StageTw {
+    static constexpr int NB = P / plan_radix(N, P, STAGE);
+    cd w1[NB], w4[NB], w8[NB];
+  };
+  template <int STAGE, typename Src>
+  __device__ __forceinline__ static void fetch_stage_tw(StageTw<STAGE>& t, int j, const Src& twr) {
+    constexpr int NS = plan_ns(N, P, STAGE);
+    if constexpr (NS > 1) {
+#pragma unroll
+      for (int b = 0; b < StageTw<STAGE>::NB; ++b) fetch_tw<STAGE>(twr, b, (j + b * T) % NS, t.w1[b], t.w4[b], t.w8[b]);
+    }
+  }
+  template <bool INV, int STAGE>
+  __device__ __forceinline__ static void butterflies(cd (&r)[P], int j, int c, cd* lds, const StageTw<STAGE>& tw) {
+    constexpr int R = plan_radix(N, P, STAGE);
+    constexpr int NS = plan_ns(N, P, STAGE);
+    constexpr int NB = P / R;
+    constexpr bool LAST = (STAGE == STAGES - 1);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      cd v[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) v[u] = r[b + u * NB];
+      const int jj = j + b * T;
+      const int jr = jj % NS;
+      if constexpr (NS > 1) twiddle_apply<R, INV>(v, tw.w1[b], tw.w4[b], tw.w8[b]);
+      Dft<R, INV>::run(v);
+      if (LAST) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) r[b + u * NB] = v[u];
+      } else {
+        const int pos = (jj / NS) * (NS * R) + jr;
+#pragma unroll
+        for (int u = 0; u < R; ++u) lds[lds_index(pos + u * NS, c)] = v[u];
+      }
+    }
+  }
+  __device__ __forceinline__ static void gather(cd (&r)[P], int j, int c, const cd* lds) {
+    if constexpr (LINE_MAJOR && T % 256 == 0) {
+      const cd* src = lds + lds_index(j, c);
+#pragma unroll
+      for (int t = 0; t < P; ++t) r[t] = src[t * T];
+    } else {
+#pragma unroll
+      for (int t = 0; t < P; ++t) r[t] = lds[lds_index(j + t * T, c)];
+    }
+  }
+  template <bool INV, int STAGE, typename Src>
+  __device__ __forceinline__ static void stages2_from(cd (&a)[P], cd (&b)[P], int j, int c, cd* lds_a, cd* lds_b,
+                                                      const Src& twr) {
+    if constexpr (STAGE < STAGES) {
+      // the stage's twiddles serve both transforms and are fetched BEFORE any store: LDS operations complete in
+      // order, so a table read issued after the stores of `a` would wait for them
+      StageTw<STAGE> tw;
+      fetch_stage_tw<STAGE>(tw, j, twr);
+      butterflies<INV, STAGE>(a, j, c, lds_a, tw);
+      butterflies<INV, STAGE>(b, j, c, lds_b, tw);
+      if constexpr (STAGE < STAGES - 1) {
+        wg_barrier();
+        gather(a, j, c, lds_a);
+        gather(b, j, c, lds_b);
+        wg_barrier();
+      }
+      stages2_from<INV, STAGE + 1, Src>(a, b, j, c, lds_a, lds_b, twr);
+    }
+  }
+  template <bool INV, typename Src>
+  __device__ __forceinline__ static void run2(cd (&a)[P], cd (&b)[P], int j, int c, cd* lds_a, cd* lds_b,
+                                              const Src& twr) {
+    stages2_from<INV, 0, Src>(a, b, j, c, lds_a, lds_b, twr);
+  }
 };
 
 }  // namespace nq

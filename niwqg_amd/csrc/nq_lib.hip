@@ -55,6 +55,7 @@ struct nq_ctx {
   std::vector<void*> allocs;
   // tables
   cd* tw = nullptr;
+  int num_cu = 256;
   cd *twx = nullptr, *twx1 = nullptr;   // per-stage twiddle tables of the two row-kernel plans (WgFft::tw_off layout)
   double *kk = nullptr, *ll = nullptr, *filt_h = nullptr, *filt_f = nullptr;
   cd* contour = nullptr;
@@ -80,14 +81,14 @@ struct nq_ctx {
     size_t elems = 0;
   } G[4];
   cd* Gs = nullptr;
-  MArr mUq, mVq, mJ, mR, mPhi, mPhiy, mLap, mDiss, mGx, mGy, mA, mB, mU, mP, mQ, mQw;
+  MArr mUq, mVq, mJ, mR, mPhi, mPhiy, mGx, mGy, mA, mB, mU, mP, mQ, mQw;
   // scratch for the generic transforms / downloads
   cd *scr_f0 = nullptr, *scr_f1 = nullptr, *scr_h0 = nullptr, *scr_h1 = nullptr;
   double* scr_r = nullptr;
   // in-step budget integrals (ref Kernel.py:319-322, :390-392)
-  bool bud = false, need_diss = false;
-  int nwx = 0, nww = 0, nwq = 0;                  // workgroups of the three kernels that emit partial sums
-  double *partX = nullptr, *partW = nullptr, *partQ = nullptr;   // [4 stages][workgroups][2 | 6 | 3]
+  bool bud = false;
+  int nww = 0, nwq = 0;                           // workgroups of the two kernels that emit partial sums
+  double *partW = nullptr, *partQ = nullptr;      // [4 stages][workgroups][NQ_PARTW | 3]
   double *part0W = nullptr, *part0Q = nullptr;    // partials of set_phi / set_q / nq_invert
   double *carryW = nullptr, *carryQ = nullptr;    // spectral sums of the state at the start of the next step
   double *gradS1 = nullptr, *acc = nullptr;       // stale-aware sum wv2|phih_grad|^2 ; Ke,Pw,Kw increments
@@ -256,8 +257,8 @@ __global__ void k_reduce_real_max(const double* __restrict__ a, size_t n, double
 
 // budget bookkeeping ----------------------------------------------------------------------------
 struct BudgetAcc {
-  int model, nwx, nww, nwq;
-  const double *partX, *partW, *partQ;
+  int model, nww, nwq;
+  const double *partW, *partQ;
   double *carryW, *carryQ, *gradS1, *acc;
   double dt, f, hslash, kappa2, nu, nu4, mu, nuw, nu4w, muw, M;
 };
@@ -284,7 +285,7 @@ __global__ void k_reduce_partials(const double* __restrict__ part, int nwg, int 
   }
 }
 
-// Stage sums: one workgroup per (stage, quantity); quantity 0-2: partQ, 3-8: partW, 9-10: partX.
+// Stage sums: one workgroup per (stage, quantity); quantity 0-2: partQ, 3-10: partW (S0..S3, GJ, XJ, GR, XR).
 // sums[stage][11]
 __global__ void k_budget_sums(BudgetAcc b, double* __restrict__ sums) {
   __shared__ double sh[16];
@@ -292,8 +293,7 @@ __global__ void k_budget_sums(BudgetAcc b, double* __restrict__ sums) {
   double t = 0.0;
   if (q < 3) t = block_total(b.partQ + (size_t)s * b.nwq * 3 + q, b.nwq, 3, sh);
   else if (b.model != NQ_MODEL_QG) {
-    if (q < 9) t = block_total(b.partW + (size_t)s * b.nww * 6 + (q - 3), b.nww, 6, sh);
-    else t = block_total(b.partX + (size_t)s * b.nwx * 2 + (q - 9), b.nwx, 2, sh);
+    t = block_total(b.partW + (size_t)s * b.nww * NQ_PARTW + (q - 3), b.nww, NQ_PARTW, sh);
   }
   if (threadIdx.x == 0) sums[s * 11 + q] = t;
 }
@@ -323,10 +323,10 @@ __global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums
     if (!qg) {
       const double lap2 = sw[s][2] / M2, glap2 = sw[s][3] / M2, phi2 = sw[s][0] / M2;
       const double grad2 = ((b.model == NQ_MODEL_COUPLED) ? sw[s][1] : b.gradS1[0]) / M2;
-      const double g1 = 0.25 * b.hslash * (sx[s][0] / M) / b.f;
+      const double g1 = 0.25 * b.hslash * (sx[s][0] / M2) / b.f;
       const double g2 = 0.5 * b.hslash * (sj[s][0] / M2) / b.f;
       const double x1 = -(sj[s][1] / M2) / b.f;
-      const double x2 = 0.5 * (sx[s][1] / M) / b.f;
+      const double x2 = 0.5 * (sx[s][1] / M2) / b.f;
       const double chi = (-0.5 * b.nu4w * glap2 - 0.5 * b.nuw * lap2 - 0.5 * b.muw * grad2) / b.kappa2;
       a = -b.nu4w * lap2 - b.nuw * grad2 - b.muw * phi2;
       k = -(g1 + g2) + (x1 + x2) + ep_psi;
@@ -534,31 +534,23 @@ static void launch_wavepv(nq_ctx* c) {
 #undef CASE_
   }
 }
-template <int MODE, bool BUD>
-static void launch_products_mb(nq_ctx* c, int stage) {
+template <int MODE>
+static void launch_products_m(nq_ctx* c) {
   const int vz = c->kernel_family ? 1 : 0;
-  BudgetX bx;
-  bx.Mlap = c->mLap;
-  bx.Mdiss = c->mDiss;
-  bx.has_diss = c->need_diss ? 1 : 0;
-  bx.nuw = c->p.nuw;
-  bx.muw = c->p.muw;
-  bx.part = BUD ? c->partX + (size_t)stage * c->nwx * 2 : nullptr;
   const MArr& gx = (MODE == MODE_UNCOUPLED) ? c->mGx : c->mPhi;
   const MArr& gy = (MODE == MODE_UNCOUPLED) ? c->mGy : c->mPhiy;
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE, BUD>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mJ, c->mR, c->twx, c->kk, vz, bx); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mJ, c->mR, c->twx, c->kk, vz); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
 }
-// stage < 0: no budget sums (API calls outside a step)
 static void launch_products(nq_ctx* c, int stage = -1) {
+  (void)stage;
   ProfScope ps(c, PK_PRODUCTS);
-  const bool b = c->bud && stage >= 0;
-  if (c->p.model == NQ_MODEL_COUPLED) { if (b) launch_products_mb<MODE_COUPLED, true>(c, stage); else launch_products_mb<MODE_COUPLED, false>(c, stage); }
-  else if (c->p.model == NQ_MODEL_UNCOUPLED) { if (b) launch_products_mb<MODE_UNCOUPLED, true>(c, stage); else launch_products_mb<MODE_UNCOUPLED, false>(c, stage); }
-  else launch_products_mb<MODE_QG, false>(c, stage);
+  if (c->p.model == NQ_MODEL_COUPLED) launch_products_m<MODE_COUPLED>(c);
+  else if (c->p.model == NQ_MODEL_UNCOUPLED) launch_products_m<MODE_UNCOUPLED>(c);
+  else launch_products_m<MODE_QG>(c);
 }
 
 static EtdArrays etd_arrays(EqState& e, int stage, int* out_slot) {
@@ -608,9 +600,6 @@ static BudgetW budget_w(nq_ctx* c, double* part, const cd* y_start) {
   BudgetW bw;
   bw.part = c->bud ? part : nullptr;
   bw.y_start = y_start;
-  bw.Hlap = c->mLap;
-  bw.Hdiss = c->mDiss;
-  bw.has_diss = c->need_diss ? 1 : 0;
   bw.nu4w = c->p.nu4w;
   bw.nuw = c->p.nuw;
   bw.muw = c->p.muw;
@@ -619,7 +608,7 @@ static BudgetW budget_w(nq_ctx* c, double* part, const cd* y_start) {
 template <int S>
 static void launch_sphi_s(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_start) {
   typedef YPlan<S> Y;
-  BudgetW bw = budget_w(c, c->partW + (size_t)stage * c->nww * 6, y_start);
+  BudgetW bw = budget_w(c, c->partW + (size_t)stage * c->nww * NQ_PARTW, y_start);
   hipLaunchKernelGGL((k_s_phi<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mJ, c->mR, ea, stage, geom_full(c), c->mPhi, c->mPhiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
 template <int S>
@@ -681,8 +670,8 @@ static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux, double* part,
 static BudgetAcc budget_acc(nq_ctx* c) {
   BudgetAcc b;
   b.model = c->p.model;
-  b.nwx = c->nwx; b.nww = c->nww; b.nwq = c->nwq;
-  b.partX = c->partX; b.partW = c->partW; b.partQ = c->partQ;
+  b.nww = c->nww; b.nwq = c->nwq;
+  b.partW = c->partW; b.partQ = c->partQ;
   b.carryW = c->carryW; b.carryQ = c->carryQ; b.gradS1 = c->gradS1; b.acc = c->acc;
   b.dt = c->p.dt; b.f = c->p.f; b.kappa2 = c->p.kappa2; b.hslash = c->p.f / c->p.kappa2;
   b.nu = c->p.nu; b.nu4 = c->p.nu4; b.mu = c->p.mu; b.nuw = c->p.nuw; b.nu4w = c->p.nu4w; b.muw = c->p.muw;
@@ -720,12 +709,7 @@ static void phase_update(nq_ctx* c, int s) {
     const cd* y_start = (s == 0) ? c->w.y[cur] : (s == 1 ? c->w.y[(cur + 1) % 3] : c->w.y[(cur + 2) % 3]);
     EtdArrays ew = etd_arrays(c->w, s, &wslot);
     launch_sphi(c, ew, s, y_start);
-    if (c->bud) {
-      if (c->need_diss) launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap, &c->mDiss});
-      else launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap});
-    } else {
-      launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
-    }
+    launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
   }
   if (c->p.model != NQ_MODEL_COUPLED) {
     // no wave feedback on psi: the inversion needs no row pass, it runs here on the spectral side
@@ -775,7 +759,7 @@ const char* nq_last_error(const nq_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 // ---- slab geometry (shared by nq_group_elems and the constructor) -----------------------------------
 struct SlabGeom {
   int N, P, Nloc, Wf, Wl, WhG, Ph;
-  bool waves, coupled, bud, diss;
+  bool waves, coupled, bud;
   int npitch[4];                 // row pitch of the four exchange groups
   int off[4][4];                 // column offset of each array inside its group's row
 };
@@ -792,15 +776,14 @@ static SlabGeom slab_geom(const nq_params* p, int P) {
   g.waves = p->model != NQ_MODEL_QG;
   g.coupled = p->model == NQ_MODEL_COUPLED;
   g.bud = p->budgets != 0;
-  g.diss = g.bud && g.waves && p->nu4w != 0.0;
   const int hs = g.Ph;                          // segment stride of a half-spectrum array inside a row
   memset(g.off, 0, sizeof(g.off));
   // G0: Muq, Mvq, [Mj, Mr]
   g.off[0][0] = 0; g.off[0][1] = hs; g.off[0][2] = 2 * hs; g.off[0][3] = 2 * hs + g.Wf;
   g.npitch[0] = 2 * hs + (g.waves ? 2 * g.Wf : 0);
-  // G1: Mphi, Mphiy, [Mlap, [Mdiss]]
+  // G1: Mphi, Mphiy
   for (int i = 0; i < 4; ++i) g.off[1][i] = i * g.Wf;
-  g.npitch[1] = g.waves ? (2 + (g.bud ? 1 : 0) + (g.diss ? 1 : 0)) * g.Wf : 0;
+  g.npitch[1] = g.waves ? 2 * g.Wf : 0;
   // G2: Ma, Mb
   g.off[2][0] = 0; g.off[2][1] = hs;
   g.npitch[2] = g.coupled ? 2 * hs : 0;
@@ -887,6 +870,10 @@ static int create_impl(const nq_params* p, const double* kk, const double* ll, c
   } while (0)
   auto setup = [&]() -> int {
     HIPCHK(c, hipSetDevice(device));
+    {
+      int ncu = 0;
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->num_cu = ncu;
+    }
     if (ext_stream) {
       c->stream = reinterpret_cast<hipStream_t>(ext_stream);
       c->own_stream = false;
@@ -981,7 +968,6 @@ static int create_impl(const nq_params* p, const double* kk, const double* ll, c
       hipLaunchKernelGGL(k_etdrk4_coeffs, grdf, blk, 0, c->stream, 1, N, c->Wf, c->Wf, c->kf0, c->p, c->kk, c->ll, c->filt_f, c->contour, c->w.coef[0], c->w.coef[1], c->w.coef[2], c->w.coef[3], c->w.coef[4], c->w.coef[5]);
     }
     c->bud = p->budgets != 0;
-    c->need_diss = sg.diss;
     // exchange groups: one buffer per side (the same buffer when P == 1); external (torch) buffers when given
     for (int gi = 0; gi < 4; ++gi) {
       c->G[gi].pitch = sg.npitch[gi];
@@ -1004,8 +990,6 @@ static int create_impl(const nq_params* p, const double* kk, const double* ll, c
     c->mR = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 3, false);
     c->mPhi = make_marr(sg, c->G[1].bx, c->G[1].by, 1, 0, false);
     c->mPhiy = make_marr(sg, c->G[1].bx, c->G[1].by, 1, 1, false);
-    c->mLap = make_marr(sg, c->G[1].bx, c->G[1].by, 1, 2, false);
-    c->mDiss = make_marr(sg, c->G[1].bx, c->G[1].by, 1, 3, false);
     c->mA = make_marr(sg, c->G[2].bx, c->G[2].by, 2, 0, true);
     c->mB = make_marr(sg, c->G[2].bx, c->G[2].by, 2, 1, true);
     c->mU = make_marr(sg, c->G[3].bx, c->G[3].by, 3, 0, true);
@@ -1020,13 +1004,6 @@ static int create_impl(const nq_params* p, const double* kk, const double* ll, c
       c->mGy = make_marr(sg, c->Gs, c->Gs, 1, 1, false);
     }
     if (c->bud) {
-      int xc = 1;
-      switch (N) {
-#define CASE_(n, a, b) case n: xc = XPlan<n>::C; break;
-        NQ_FOR_SIZES(CASE_)
-#undef CASE_
-      }
-      c->nwx = c->Nloc / xc;
       c->nww = (c->Wf / CL) * c->S2;
       c->nwq = ((c->Wh + CL - 1) / CL) * c->S2;
       if (c->nwq < 1) c->nwq = 1;
@@ -1046,9 +1023,8 @@ static int create_impl(const nq_params* p, const double* kk, const double* ll, c
       c->carryQ = c->bsums + 48;
       c->gradS1 = c->bsums + 51;
       if (c->kernel_family) {
-        ALLOC(c, c->partX, (size_t)4 * c->nwx * 2);
-        ALLOC(c, c->partW, (size_t)4 * c->nww * 6);
-        ALLOC(c, c->part0W, (size_t)c->nww * 6);
+        ALLOC(c, c->partW, (size_t)4 * c->nww * NQ_PARTW);
+        ALLOC(c, c->part0W, (size_t)c->nww * NQ_PARTW);
       }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1150,13 +1126,8 @@ int nq_set_phi(nq_ctx* c, const double* phi_host) {
   HIPCHK(c, hipMemcpyAsync(c->scr_f0, phi_host, sizeof(cd) * full, hipMemcpyHostToDevice, c->stream));
   fwd2d_full(c, c->scr_f0, c->w.y[c->w.cur], c->scr_f1);
   launch_emit_phi(c, c->w.y[c->w.cur]);
-  if (c->bud) {
-    if (c->need_diss) launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap, &c->mDiss});
-    else launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap});
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0W, c->nww, 6, 4, c->carryW);
-  } else {
-    launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
-  }
+  launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
+  if (c->bud) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0W, c->nww, NQ_PARTW, 4, c->carryW);
   c->have_phi = true;
   int rc = nq_refresh_grad_phi(c);
   if (rc) return rc;
@@ -1257,14 +1228,9 @@ int nq_phase(nq_ctx* c, int phase, int stage) {
     case NQ_PH_EMIT_PHI:
       if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
       launch_emit_phi(c, c->w.y[c->w.cur]);
-      if (c->bud) {
-        if (c->need_diss) launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap, &c->mDiss});
-        else launch_A_m(c, true, {&c->mPhi, &c->mPhiy, &c->mLap});
-        // local part of the carried sums; the caller all-reduces them through nq_carry_buffer
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0W, c->nww, 6, 4, c->carryW);
-      } else {
-        launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
-      }
+      launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
+      // local part of the carried sums; the caller all-reduces them (nq_reduce_buffer)
+      if (c->bud) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0W, c->nww, NQ_PARTW, 4, c->carryW);
       break;
     case NQ_PH_INVERT_NOW:
       phase_invert_y(c, c->q.y[c->q.cur], true, c->part0Q, nullptr);

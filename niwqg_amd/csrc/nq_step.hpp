@@ -230,22 +230,15 @@ k_x_wavepv(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, c
 }
 
 // ---- X2: all nonlinear products of one stage ------------------------------------------------
-// ref Kernel.py:471-486 (jacobian_psi_q), :457-469 (jacobian_psi_phi), :332 (refraction) and, with
-// BUD, the two budget terms that are triple products in physical space (gamma1, xi2; Kernel.py:691-700).
+// ref Kernel.py:471-486 (jacobian_psi_q), :457-469 (jacobian_psi_phi), :332 (refraction).  The two budget terms
+// that are triple products in physical space (gamma1, xi2; Kernel.py:691-700) are Parseval sums against the
+// refraction transform in k_s_phi: this kernel has no budget work and lap(phi) never comes to physical space.
 // MODE_QG: only Muq, Mvq.  MODE_UNCOUPLED: q_psi = q, phix/phiy from the (possibly stale) Mgx/Mgy.
 // Register plan: q, q_psi, u, v are reals (32 VGPRs each); complex working sets are 64.
-struct BudgetX {
-  MArr Mlap;          // T_y^-1[-wv2 phih] / M
-  MArr Mdiss;         // T_y^-1[-(nu4w wv4 + nuw wv2 + muw) phih] / M (has_diss), else diss = nuw lap(phi) - muw phi
-  int has_diss;
-  double nuw, muw;
-  double* part;       // [workgroup][2]: sum q_psi Im(conj(phi) lap(phi)), sum q_psi Re(diss conj(phi))
-};
-
-template <int N, int MODE, bool BUD>
+template <int N, int MODE>
 __global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
 k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy, MArr Muq, MArr Mvq, MArr Mj, MArr Mr,
-             const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq, BudgetX bx) {
+             const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq) {
   typedef XPlan<N> X;
   typedef typename X::F F;
   constexpr int P = X::P, T = X::T;
@@ -258,7 +251,6 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   typename XPlan<N>::F::TwLds twr;
   twr.base = twl;
   wg_barrier_all();
-  double* red = reinterpret_cast<double*>(nq_smem + X::LDS_BYTES - 512);
   cd w[P];
   double q[P], qpsi[P], u[P], v[P];
   // Software pipeline: the rows of the NEXT phase are requested before each transform and consumed after
@@ -279,7 +271,7 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   // (u, v) = ifft of (-il psi, ik psi): Mu already holds T_y^-1[-il psi], Mp holds T_y^-1[psi]
   NQ_PHASE_FENCE();
   hs_pack<N, P, T, F, true>(w, h2, j, c, lds, kk, true, v_zero_nyq != 0);
-  cd sp[P];          // spectral row of phi: kept for phix (Coupled) and for the budget's diss row
+  cd sp[P];          // spectral row of phi: kept for phix (Coupled)
   if (MODE != MODE_QG) {
     const XRow rp = xrow(Mphi, row);
 #pragma unroll
@@ -298,13 +290,13 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   NQ_PHASE_FENCE();
   unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow(Muq, row), xrow(Mvq, row));
   if (MODE == MODE_QG) return;
-  cd pre[P];         // prefetch buffer: Mlap (budgets), then Mgx (UnCoupled), then Mgy
+  cd pre[P];         // prefetch buffer: Mgy, in flight during the refraction transforms
   {
-    const XRow rl = xrow(bx.Mlap, row);
+    const XRow rgy = xrow(Mgy, row);
 #pragma unroll
     for (int t = 0; t < P; ++t) {
       w[t] = sp[t];
-      if (BUD) pre[t] = *rl.at(j + t * T);
+      pre[t] = *rgy.at(j + t * T);
     }
   }
   NQ_PHASE_FENCE();
@@ -313,24 +305,6 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   for (int t = 0; t < P; ++t) w[t] = cscale(w[t], qpsi[t]);  // refraction source phi * q_psi
   NQ_PHASE_FENCE();
   F::template run<false>(w, j, c, lds, twr);
-  if (BUD) {
-    // gamma1 ~ sum_x q_psi Im(conj(phi) lap phi), xi2 ~ sum_x q_psi Re(diss conj(phi))  (ref Kernel.py:691-700)
-    // by Parseval along the row: sum_x conj(r) g = sum_kx conj(R^[kx]) G[kx] with r = phi q_psi (just
-    // transformed, in w) and G the mixed-space row of g (already carries the 1/M of the inverse).
-    double acc[2] = {0.0, 0.0};
-    const XRow rd = xrow(bx.has_diss ? bx.Mdiss : bx.Mlap, row);
-#pragma unroll
-    for (int t = 0; t < P; ++t) {
-      const cd L = pre[t];
-      acc[0] += w[t].x * L.y - w[t].y * L.x;
-      cd G;
-      if (bx.has_diss) G = *rd.at(j + t * T);
-      else G = cmake(bx.nuw * L.x - bx.muw * sp[t].x, bx.nuw * L.y - bx.muw * sp[t].y);
-      acc[1] += w[t].x * G.x + w[t].y * G.y;
-    }
-    NQ_PHASE_FENCE();
-    block_sum_store<2>(acc, red, bx.part + 2 * (size_t)blockIdx.x);
-  }
   {
     const XRow rp = xrow(Mr, row);
 #pragma unroll
@@ -338,13 +312,12 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   }
   // advection u phix + v phiy: w <- u*phix, then w += v*phiy
   {
-    const XRow rgx = xrow(Mgx, row), rgy = xrow(Mgy, row);
+    const XRow rgx = xrow(Mgx, row);
 #pragma unroll
     for (int t = 0; t < P; ++t) {
       const int kx = j + t * T;
       const cd g = (MODE == MODE_COUPLED) ? sp[t] : *rgx.at(kx);
       w[t] = cscale(cmul_i(g), kk[kx]);
-      pre[t] = *rgy.at(kx);
     }
   }
   NQ_PHASE_FENCE();
@@ -495,20 +468,18 @@ k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __rest
 }
 
 // ---- Sw: nonlinear term + stage update of phi-hat, then first half of the inverse y transform -----
-// With budgets (bw.part != null) it also emits the y-half-transformed -wv2*phih (for lap(phi)) and the
+// With budgets (bw.part != null) it also emits the
 // Parseval sums of ref Kernel.py:629-633, :646-652, :698-699 (see oracle/reduced_pipeline.py).
 struct BudgetW {
-  double* part;        // [workgroup][6]: S0..S3 of the NEW phih, then GJ, XJ of this stage; null = off
-  const cd* y_start;   // phih at the start of this stage (what J was computed from)
-  MArr Hlap;
-  MArr Hdiss;          // used when has_diss (nu4w != 0)
-  int has_diss;
+  double* part;        // [workgroup][8]: S0..S3 of the NEW phih, then GJ, XJ, GR, XR of this stage; null = off
+  const cd* y_start;   // phih at the start of this stage (what J and R were computed from)
   double nu4w, nuw, muw;
 };
+constexpr int NQ_PARTW = 8;
 
-// a[], b[] hold y/M and i*l*y/M on return; budgets: sums over the new y and emission of lap / diss
+// a[], b[] hold y/M and i*l*y/M on return; budgets: sums over the new y
 template <int P, int T>
-__device__ __forceinline__ void phi_outputs(const cd (&y)[P], cd (&a)[P], cd (&b)[P], cd (&lap)[P], int l1, int S2,
+__device__ __forceinline__ void phi_outputs(const cd (&y)[P], cd (&a)[P], cd (&b)[P], int l1, int S2,
                                             int j, int kg, double invM, const double* __restrict__ kk,
                                             const double* __restrict__ ll, bool bud, double (&s)[4]) {
   const double kx = kk[kg];
@@ -525,7 +496,6 @@ __device__ __forceinline__ void phi_outputs(const cd (&y)[P], cd (&a)[P], cd (&b
       s[1] += wv2 * m2;
       s[2] += wv2 * wv2 * m2;
       s[3] += wv2 * wv2 * wv2 * m2;
-      lap[t] = cscale(y[t], -wv2 * invM);
     }
   }
 }
@@ -546,7 +516,7 @@ k_s_phi(MArr Hj, MArr Hr, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphi
   typename Y::F::Tw twr;
   Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
   double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
-  double* part = bud ? bw.part + 6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+  double* part = bud ? bw.part + NQ_PARTW * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
   cd a[P], b[P], y[P];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
@@ -556,20 +526,24 @@ k_s_phi(MArr Hj, MArr Hr, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphi
   }
   Y::F::template run<false>(a, j, c, lds, twr);
   Y::F::template run<false>(b, j, c, lds, twr);
-  double sj[2] = {0.0, 0.0};
+  double sj[4] = {0.0, 0.0, 0.0, 0.0};
   const double kx = kk[kg];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int l = l1 + S2 * (j + t * T);
     const size_t idx = (size_t)l * g.pitch_s + k;
     if (bud) {
-      // gamma2 ~ sum Re(conj(lap_h) J), xi1 ~ -sum Im(diss_h conj(J)) with lap_h = -wv2 ys, diss_h = -d ys
+      // gamma2 ~ sum Re(conj(lap_h) J), xi1 ~ -sum Im(diss_h conj(J)) with lap_h = -wv2 ys, diss_h = -d ys;
+      // gamma1 ~ mean(q_psi Im(conj(phi) lap phi)) = sum Im(conj(R) lap_h) / M^2 and
+      // xi2 ~ mean(q_psi Re(diss conj(phi))) = sum Re(conj(R) diss_h) / M^2, R = fft2(phi q_psi) (ref Kernel.py:691-700)
       const cd ys = bw.y_start[idx];
       const double ly = ll[l];
       const double wv2 = kx * kx + ly * ly;
       const double d = bw.nu4w * wv2 * wv2 + bw.nuw * wv2 + bw.muw;
       sj[0] += -wv2 * (ys.x * a[t].x + ys.y * a[t].y);
       sj[1] += -d * (ys.y * a[t].x - ys.x * a[t].y);
+      sj[2] += -wv2 * (b[t].x * ys.y - b[t].y * ys.x);
+      sj[3] += -d * (b[t].x * ys.x + b[t].y * ys.y);
     }
     cd J = a[t];
     if (l == 0 && kg == 0) J = cmake(0, 0);
@@ -578,8 +552,7 @@ k_s_phi(MArr Hj, MArr Hr, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphi
     y[t] = etd_update(ea, idx, Nl, stage);
   }
   double s4[4] = {0.0, 0.0, 0.0, 0.0};
-  cd lap[P];
-  phi_outputs<P, T>(y, a, b, lap, l1, S2, j, kg, invM, kk, ll, bud, s4);
+  phi_outputs<P, T>(y, a, b, l1, S2, j, kg, invM, kk, ll, bud, s4);
   Y::F::template run<true>(a, j, c, lds, twr);
   Y::F::template run<true>(b, j, c, lds, twr);
 #pragma unroll
@@ -589,26 +562,12 @@ k_s_phi(MArr Hj, MArr Hr, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphi
     Hphiy.ys[at] = b[t];
   }
   if (bud) {
-    Y::F::template run<true>(lap, j, c, lds, twr);
-#pragma unroll
-    for (int t = 0; t < P; ++t) bw.Hlap.ys[(size_t)(l1 * S1 + j + t * T) * bw.Hlap.pitch + k] = lap[t];
-    if (bw.has_diss) {
-#pragma unroll
-      for (int t = 0; t < P; ++t) {
-        const double ly = ll[l1 + S2 * (j + t * T)];
-        const double wv2 = kx * kx + ly * ly;
-        lap[t] = cscale(y[t], -(bw.nu4w * wv2 * wv2 + bw.nuw * wv2 + bw.muw) * invM);
-      }
-      Y::F::template run<true>(lap, j, c, lds, twr);
-#pragma unroll
-      for (int t = 0; t < P; ++t) bw.Hdiss.ys[(size_t)(l1 * S1 + j + t * T) * bw.Hdiss.pitch + k] = lap[t];
-    }
     block_sum_store<4>(s4, red, part);
-    block_sum_store<2>(sj, red, part + 4);
+    block_sum_store<4>(sj, red, part + 4);
   }
 }
 
-// emit-only variant (set_phi): phih -> Hphi, Hphiy (+ lap, diss, sums with budgets)
+// emit-only variant (set_phi): phih -> Hphi, Hphiy (+ sums with budgets)
 template <int S1>
 __global__ void __launch_bounds__(YPlan<S1>::THREADS)
 k_s_emit_phi(const cd* __restrict__ phih, YGeom g, MArr Hphi, MArr Hphiy, double invM,
@@ -625,11 +584,11 @@ k_s_emit_phi(const cd* __restrict__ phih, YGeom g, MArr Hphi, MArr Hphiy, double
   typename Y::F::Tw twr;
   Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
   double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
-  cd a[P], b[P], y[P], lap[P];
+  cd a[P], b[P], y[P];
 #pragma unroll
   for (int t = 0; t < P; ++t) y[t] = phih[(size_t)(l1 + S2 * (j + t * T)) * g.pitch_s + k];
   double s4[4] = {0.0, 0.0, 0.0, 0.0};
-  phi_outputs<P, T>(y, a, b, lap, l1, S2, j, kg, invM, kk, ll, bud, s4);
+  phi_outputs<P, T>(y, a, b, l1, S2, j, kg, invM, kk, ll, bud, s4);
   Y::F::template run<true>(a, j, c, lds, twr);
   Y::F::template run<true>(b, j, c, lds, twr);
 #pragma unroll
@@ -639,25 +598,10 @@ k_s_emit_phi(const cd* __restrict__ phih, YGeom g, MArr Hphi, MArr Hphiy, double
     Hphiy.ys[at] = b[t];
   }
   if (bud) {
-    const double kx = kk[kg];
-    Y::F::template run<true>(lap, j, c, lds, twr);
-#pragma unroll
-    for (int t = 0; t < P; ++t) bw.Hlap.ys[(size_t)(l1 * S1 + j + t * T) * bw.Hlap.pitch + k] = lap[t];
-    if (bw.has_diss) {
-#pragma unroll
-      for (int t = 0; t < P; ++t) {
-        const double ly = ll[l1 + S2 * (j + t * T)];
-        const double wv2 = kx * kx + ly * ly;
-        lap[t] = cscale(y[t], -(bw.nu4w * wv2 * wv2 + bw.nuw * wv2 + bw.muw) * invM);
-      }
-      Y::F::template run<true>(lap, j, c, lds, twr);
-#pragma unroll
-      for (int t = 0; t < P; ++t) bw.Hdiss.ys[(size_t)(l1 * S1 + j + t * T) * bw.Hdiss.pitch + k] = lap[t];
-    }
-    double* part = bw.part + 6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-    double z2[2] = {0.0, 0.0};
+    double* part = bw.part + NQ_PARTW * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    double z4[4] = {0.0, 0.0, 0.0, 0.0};
     block_sum_store<4>(s4, red, part);
-    block_sum_store<2>(z2, red, part + 4);
+    block_sum_store<4>(z4, red, part + 4);
   }
 }
 

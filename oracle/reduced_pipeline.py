@@ -209,21 +209,20 @@ class ReducedNIWQG:
         return Nq, Nw, Npass, rates
 
     def _budget_rates(self, J, R, qpsi):
-        """k, p, a of ref Kernel.py:319-322 with Parseval wherever both factors are linear in a
-        spectral field; only gamma1/xi2 (triple products) need the physical lap(phi)."""
+        """k, p, a of ref Kernel.py:319-322, every integral a Parseval sum.  gamma1 and xi2 are triple products in
+        physical space, but q_psi*phi is exactly the refraction source whose transform R the stage needs anyway:
+        mean(q_psi Im(conj(phi) lap phi)) = Im sum(conj(R) lap_h) / M^2 (same for diss), so neither lap(phi) nor
+        diss(phi) is ever brought to physical space."""
         n = self.nx
         M2 = float(n) ** 4
         g = self.phih_grad
         lapphi_h = -self.wv2 * self.phih
         lap2phi_h = self.wv2 ** 2 * self.phih
         diss_h = -self.nu4w * lap2phi_h + self.nuw * lapphi_h - self.muw * self.phih
-        lapphi = self._c2c_inv(lapphi_h)
-        diss = self._c2c_inv(diss_h) if self.nu4w != 0 else self.nuw * lapphi - self.muw * self.phi
-        divFw = 0.5 * self.hslash * (np.conj(self.phi) * lapphi).imag
-        gamma1 = (0.5 * qpsi * divFw).mean() / self.f
+        gamma1 = 0.25 * self.hslash * (np.conj(R) * lapphi_h).imag.sum() / M2 / self.f
         gamma2 = 0.5 * self.hslash * (np.conj(lapphi_h) * J).real.sum() / M2 / self.f
         xi1 = -((diss_h * np.conj(J)).imag.sum() / M2) / self.f
-        xi2 = (0.5 * (diss * np.conj(self.phi)).real * qpsi).mean() / self.f
+        xi2 = 0.5 * (np.conj(R) * diss_h).real.sum() / M2 / self.f
         # ep_psi (ref Kernel.py:635-640): all Parseval on the half spectrum
         ep_psi = (self.nu4 * hs_mean_product(self.qh, self.wv4_h * self.ph)
                   - self.nu * hs_mean_product(self.ph, -self.wv2_h * self.qh)

@@ -27,9 +27,10 @@ U0 = 0.1
 TE = 1.0 / (U0 * K0)
 
 # algorithmic bytes per grid point ("bytes"): SURVEY 8(d) canonical figure per step, and the
-# bytes one k_x_products launch must move (4 half-spectrum + 2 full inputs, 2 half + 2 full outputs)
+# bytes one k_x_products launch must move (4 half-spectrum + 2 full inputs, 2 half + 1 full outputs: the two phi
+# tendency sources of the canonical count leave the kernel as ONE array)
 CANONICAL_B_PER_PT_STEP = {"coupled": 3136, "uncoupled": 2240, "qg": 848}
-X_PRODUCTS_B_PER_PT = {"coupled": 4 * 8 + 2 * 16 + 2 * 8 + 2 * 16, "uncoupled": 3 * 8 + 3 * 16 + 2 * 8 + 2 * 16,
+X_PRODUCTS_B_PER_PT = {"coupled": 4 * 8 + 2 * 16 + 2 * 8 + 16, "uncoupled": 3 * 8 + 3 * 16 + 2 * 8 + 16,
                        "qg": 3 * 8 + 2 * 8}
 HBM_PEAK_GBS = 8000.0
 

@@ -55,7 +55,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char nq_smem[];
 // Sum NV per-thread values over the workgroup and let thread 0 store them at dst[0..NV) (one slot per
 // workgroup: deterministic, no atomics; a later kernel adds the slots up).  `scratch` = 512 B of LDS.
 template <int NV>
-__device__ __forceinline__ void block_sum_store(double (&vals)[NV], double* scratch, double* __restrict__ dst) {
+__device__ __forceinline__ void block_sum_thread0(double (&vals)[NV], double* scratch) {
   static_assert(NV <= 4, "scratch holds 16 waves x 4 values");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   const int live = (int)blockDim.x - (wave << 6);        // lanes of this wave that exist (blocks of 32)
@@ -80,8 +80,16 @@ __device__ __forceinline__ void block_sum_store(double (&vals)[NV], double* scra
     for (int i = 0; i < NV; ++i) {
       double x = 0.0;
       for (int w = 0; w < nw; ++w) x += scratch[w * NV + i];
-      dst[i] = x;
+      vals[i] = x;                                        // totals: valid in thread 0 only
     }
+  }
+}
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&vals)[NV], double* scratch, double* __restrict__ dst) {
+  block_sum_thread0<NV>(vals, scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dst[i] = vals[i];
   }
 }
 

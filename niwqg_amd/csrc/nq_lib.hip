@@ -73,7 +73,7 @@ struct nq_ctx {
   int Nloc = 0;          // local rows on the X side
   int Wf = 0, kf0 = 0;   // full-width planes: local columns, first global column
   int Wl = 0, kh0 = 0;   // half-spectrum planes: columns per rank, first global column of this rank
-  // exchange groups: G[0] X->Y {Muq,Mvq,Mj,Mr}, G[1] Y->X {Mphi,Mphiy,Mlap,Mdiss}, G[2] X->Y {Ma,Mb},
+  // exchange groups: G[0] X->Y {Muq,Mvq,Mw}, G[1] Y->X {Mphi,Mphiy}, G[2] X->Y {Ma,Mb},
   // G[3] Y->X {Mu,Mp,Mq,Mqw}; Gs = stale copy of G[1]'s X side (UnCoupled's frozen phix/phiy, quirk Q1)
   struct Group {
     cd *bx = nullptr, *by = nullptr;
@@ -81,7 +81,7 @@ struct nq_ctx {
     size_t elems = 0;
   } G[4];
   cd* Gs = nullptr;
-  MArr mUq, mVq, mJ, mR, mPhi, mPhiy, mGx, mGy, mA, mB, mU, mP, mQ, mQw;
+  MArr mUq, mVq, mW, mPhi, mPhiy, mGx, mGy, mA, mB, mU, mP, mQ, mQw;
   // scratch for the generic transforms / downloads
   cd *scr_f0 = nullptr, *scr_f1 = nullptr, *scr_h0 = nullptr, *scr_h1 = nullptr;
   double* scr_r = nullptr;
@@ -285,7 +285,7 @@ __global__ void k_reduce_partials(const double* __restrict__ part, int nwg, int 
   }
 }
 
-// Stage sums: one workgroup per (stage, quantity); quantity 0-2: partQ, 3-10: partW (S0..S3, GJ, XJ, GR, XR).
+// Stage sums: one workgroup per (stage, quantity); quantity 0-2: partQ, 3-8: partW (S0..S3, SG, SX), 9-10 unused.
 // sums[stage][11]
 __global__ void k_budget_sums(BudgetAcc b, double* __restrict__ sums) {
   __shared__ double sh[16];
@@ -293,7 +293,7 @@ __global__ void k_budget_sums(BudgetAcc b, double* __restrict__ sums) {
   double t = 0.0;
   if (q < 3) t = block_total(b.partQ + (size_t)s * b.nwq * 3 + q, b.nwq, 3, sh);
   else if (b.model != NQ_MODEL_QG) {
-    t = block_total(b.partW + (size_t)s * b.nww * NQ_PARTW + (q - 3), b.nww, NQ_PARTW, sh);
+    if (q < 3 + NQ_PARTW) t = block_total(b.partW + (size_t)s * b.nww * NQ_PARTW + (q - 3), b.nww, NQ_PARTW, sh);
   }
   if (threadIdx.x == 0) sums[s * 11 + q] = t;
 }
@@ -302,13 +302,12 @@ __global__ void k_budget_sums(BudgetAcc b, double* __restrict__ sums) {
 // QGModel.py:355-407).  Slot s of the spectral sums = state at the start of stage s.
 __global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double sw[5][4], sj[4][2], sq[5][3], sx[4][2];
+  double sw[5][4], sj[4][2], sq[5][3];
   const bool qg = b.model == NQ_MODEL_QG;
   for (int s = 0; s < 4; ++s) {
     for (int q = 0; q < 3; ++q) sq[qg ? s : s + 1][q] = sums[s * 11 + q];
     for (int q = 0; q < 4; ++q) sw[s + 1][q] = sums[s * 11 + 3 + q];
     for (int q = 0; q < 2; ++q) sj[s][q] = sums[s * 11 + 7 + q];
-    for (int q = 0; q < 2; ++q) sx[s][q] = sums[s * 11 + 9 + q];
   }
   const double M = b.M, M2 = b.M * b.M;
   if (!qg) {
@@ -323,14 +322,13 @@ __global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums
     if (!qg) {
       const double lap2 = sw[s][2] / M2, glap2 = sw[s][3] / M2, phi2 = sw[s][0] / M2;
       const double grad2 = ((b.model == NQ_MODEL_COUPLED) ? sw[s][1] : b.gradS1[0]) / M2;
-      const double g1 = 0.25 * b.hslash * (sx[s][0] / M2) / b.f;
-      const double g2 = 0.5 * b.hslash * (sj[s][0] / M2) / b.f;
-      const double x1 = -(sj[s][1] / M2) / b.f;
-      const double x2 = 0.5 * (sx[s][1] / M2) / b.f;
+      // sj[s] = {sum Re(conj(lap_h) W), sum Im(conj(diss_h) W)} with W the whole phi tendency (k_s_phi)
+      const double g12 = -0.5 * b.hslash * (sj[s][0] / M2) / b.f;      // gamma1 + gamma2
+      const double x12 = -(sj[s][1] / M2) / b.f;                        // xi1 + xi2
       const double chi = (-0.5 * b.nu4w * glap2 - 0.5 * b.nuw * lap2 - 0.5 * b.muw * grad2) / b.kappa2;
       a = -b.nu4w * lap2 - b.nuw * grad2 - b.muw * phi2;
-      k = -(g1 + g2) + (x1 + x2) + ep_psi;
-      p = g1 + g2 + chi;
+      k = -g12 + x12 + ep_psi;
+      p = g12 + chi;
     }
     K += wgt[s] * k;
     Pw += wgt[s] * p;
@@ -535,22 +533,22 @@ static void launch_wavepv(nq_ctx* c) {
   }
 }
 template <int MODE>
-static void launch_products_m(nq_ctx* c) {
+static void launch_products_m(nq_ctx* c, double cj, double cr) {
   const int vz = c->kernel_family ? 1 : 0;
   const MArr& gx = (MODE == MODE_UNCOUPLED) ? c->mGx : c->mPhi;
   const MArr& gy = (MODE == MODE_UNCOUPLED) ? c->mGy : c->mPhiy;
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mJ, c->mR, c->twx, c->kk, vz); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mW, c->twx, c->kk, vz, cj, cr); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
 }
-static void launch_products(nq_ctx* c, int stage = -1) {
-  (void)stage;
+// Mw <- cj * (u phix + v phiy) + i cr * phi q_psi; a step uses the phi tendency itself: cj = -1, cr = -1/2
+static void launch_products(nq_ctx* c, double cj = -1.0, double cr = -0.5) {
   ProfScope ps(c, PK_PRODUCTS);
-  if (c->p.model == NQ_MODEL_COUPLED) launch_products_m<MODE_COUPLED>(c);
-  else if (c->p.model == NQ_MODEL_UNCOUPLED) launch_products_m<MODE_UNCOUPLED>(c);
-  else launch_products_m<MODE_QG>(c);
+  if (c->p.model == NQ_MODEL_COUPLED) launch_products_m<MODE_COUPLED>(c, cj, cr);
+  else if (c->p.model == NQ_MODEL_UNCOUPLED) launch_products_m<MODE_UNCOUPLED>(c, cj, cr);
+  else launch_products_m<MODE_QG>(c, cj, cr);
 }
 
 static EtdArrays etd_arrays(EqState& e, int stage, int* out_slot) {
@@ -609,7 +607,7 @@ template <int S>
 static void launch_sphi_s(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_start) {
   typedef YPlan<S> Y;
   BudgetW bw = budget_w(c, c->partW + (size_t)stage * c->nww * NQ_PARTW, y_start);
-  hipLaunchKernelGGL((k_s_phi<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mJ, c->mR, ea, stage, geom_full(c), c->mPhi, c->mPhiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
+  hipLaunchKernelGGL((k_s_phi<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mW, c->mUq.ys + c->mUq.W, c->mUq.pitch, ea, stage, geom_full(c), c->mPhi, c->mPhiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
 template <int S>
 static void launch_emit_phi_s(nq_ctx* c, const cd* phih) {
@@ -695,11 +693,11 @@ static void phase_invert_y(nq_ctx* c, const cd* qh, bool store_aux, double* part
   if (c->p.model == NQ_MODEL_COUPLED) launch_A_m(c, true, {&c->mU, &c->mP, &c->mQ, &c->mQw});
   else launch_A_m(c, true, {&c->mU, &c->mP, &c->mQ});
 }
-static void phase_products(nq_ctx* c, int stage) { launch_products(c, stage); }
+static void phase_products(nq_ctx* c, int stage) { (void)stage; launch_products(c); }
 static void phase_update(nq_ctx* c, int s) {
   const bool waves = c->p.model != NQ_MODEL_QG;
   int qslot = 0, wslot = 0;
-  if (waves) launch_A_m(c, false, {&c->mJ, &c->mR});
+  if (waves) launch_A_m(c, false, {&c->mW});
   launch_A_m(c, false, {&c->mUq, &c->mVq});
   EtdArrays eq = etd_arrays(c->q, s, &qslot);
   launch_sq(c, eq, s);
@@ -778,9 +776,9 @@ static SlabGeom slab_geom(const nq_params* p, int P) {
   g.bud = p->budgets != 0;
   const int hs = g.Ph;                          // segment stride of a half-spectrum array inside a row
   memset(g.off, 0, sizeof(g.off));
-  // G0: Muq, Mvq, [Mj, Mr]
-  g.off[0][0] = 0; g.off[0][1] = hs; g.off[0][2] = 2 * hs; g.off[0][3] = 2 * hs + g.Wf;
-  g.npitch[0] = 2 * hs + (g.waves ? 2 * g.Wf : 0);
+  // G0: Muq, Mvq, [Mw]
+  g.off[0][0] = 0; g.off[0][1] = hs; g.off[0][2] = 2 * hs;
+  g.npitch[0] = 2 * hs + (g.waves ? g.Wf : 0);
   // G1: Mphi, Mphiy
   for (int i = 0; i < 4; ++i) g.off[1][i] = i * g.Wf;
   g.npitch[1] = g.waves ? 2 * g.Wf : 0;
@@ -986,8 +984,7 @@ static int create_impl(const nq_params* p, const double* kk, const double* ll, c
     }
     c->mUq = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 0, true);
     c->mVq = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 1, true);
-    c->mJ = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 2, false);
-    c->mR = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 3, false);
+    c->mW = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 2, false);
     c->mPhi = make_marr(sg, c->G[1].bx, c->G[1].by, 1, 0, false);
     c->mPhiy = make_marr(sg, c->G[1].bx, c->G[1].by, 1, 1, false);
     c->mA = make_marr(sg, c->G[2].bx, c->G[2].by, 2, 0, true);
@@ -1485,9 +1482,9 @@ int nq_jacobian_psi_phi(nq_ctx* c, double* out_cplx) {
   if (!c || !out_cplx) return -1;
   if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
   HIPCHK(c, hipSetDevice(c->device));
-  launch_products(c);
-  launch_A_m(c, false, {&c->mJ});
-  launch_B_p(c, false, c->mJ.ys, c->mJ.pitch, c->scr_f0, c->N, c->N, 1.0);
+  launch_products(c, 1.0, 0.0);                       // the Jacobian part alone
+  launch_A_m(c, false, {&c->mW});
+  launch_B_p(c, false, c->mW.ys, c->mW.pitch, c->scr_f0, c->N, c->N, 1.0);
   HIPCHK(c, hipMemcpyAsync(out_cplx, c->scr_f0, sizeof(cd) * (size_t)c->N * c->N, hipMemcpyDeviceToHost, c->stream));
   return nq_sync(c);
 }

@@ -1,9 +1,9 @@
 // Fused kernels of one ETDRK4 stage.  See DESIGN.md for the data flow; in short, per stage
 //
-//   X2  rows : Mu,Mp,Mq,Mqw,Mphi,Mphiy --x-ifft--> u,v,q,qw,phi,phix,phiy --products--x-fft--> Muq,Mvq,Mj,Mr
-//   A   (generic, in place) on Muq,Mvq,Mj,Mr
+//   X2  rows : Mu,Mp,Mq,Mqw,Mphi,Mphiy --x-ifft--> u,v,q,qw,phi,phix,phiy --products--x-fft--> Muq,Mvq,Mw
+//   A   (generic, in place) on Muq,Mvq,Mw
 //   Sq  tiles: B-fft of Muq,Mvq -> N_q -> ETDRK4 stage update of qh               (half spectrum)
-//   Sw  tiles: B-fft of Mj,Mr   -> N_phi -> ETDRK4 stage update of phih -> B-ifft -> Hphi,Hphiy
+//   Sw  tiles: B-fft of Mw      -> N_phi -> ETDRK4 stage update of phih -> B-ifft -> Hphi,Hphiy
 //   A^-1 on Hphi,Hphiy
 //   X1  rows : Mphi,Mphiy --x-ifft--> phi,phix,phiy --|phi|^2, J(phi*,phi)--x-fft--> Ma,Mb   (Coupled)
 //   A   on Ma,Mb
@@ -230,15 +230,15 @@ k_x_wavepv(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, c
 }
 
 // ---- X2: all nonlinear products of one stage ------------------------------------------------
-// ref Kernel.py:471-486 (jacobian_psi_q), :457-469 (jacobian_psi_phi), :332 (refraction).  The two budget terms
-// that are triple products in physical space (gamma1, xi2; Kernel.py:691-700) are Parseval sums against the
-// refraction transform in k_s_phi: this kernel has no budget work and lap(phi) never comes to physical space.
+// ref Kernel.py:471-486 (jacobian_psi_q), :457-469 (jacobian_psi_phi), :332 (refraction).  The budget terms
+// gamma1+gamma2 and xi1+xi2 (Kernel.py:691-700) are Parseval sums against the transformed phi tendency in k_s_phi:
+// this kernel has no budget work and lap(phi) never comes to physical space.
 // MODE_QG: only Muq, Mvq.  MODE_UNCOUPLED: q_psi = q, phix/phiy from the (possibly stale) Mgx/Mgy.
 // Register plan: q, q_psi, u, v are reals (32 VGPRs each); complex working sets are 64.
 template <int N, int MODE>
 __global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
-k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy, MArr Muq, MArr Mvq, MArr Mj, MArr Mr,
-             const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq) {
+k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy, MArr Muq, MArr Mvq, MArr Mw,
+             const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq, double cj, double cr) {
   typedef XPlan<N> X;
   typedef typename X::F F;
   constexpr int P = X::P, T = X::T;
@@ -290,7 +290,10 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   NQ_PHASE_FENCE();
   unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow(Muq, row), xrow(Mvq, row));
   if (MODE == MODE_QG) return;
-  cd pre[P];         // prefetch buffer: Mgy, in flight during the refraction transforms
+  // phi tendency source in ONE array: W = cj (u phix + v phiy) + i cr phi q_psi  (cj = -1, cr = -1/2 in a step:
+  // N_phi = F[W] except at [0,0], where the reference zeroes the Jacobian part only, ref Kernel.py:468 vs :332;
+  // the row sums of the Jacobian part travel in a padding column of Muq and are added back in k_s_phi)
+  cd pre[P];         // prefetch buffer: Mgy, in flight during the next two transforms
   {
     const XRow rgy = xrow(Mgy, row);
 #pragma unroll
@@ -301,16 +304,9 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   }
   NQ_PHASE_FENCE();
   F::template run<true>(w, j, c, lds, twr);
+  cd acc[P];
 #pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = cscale(w[t], qpsi[t]);  // refraction source phi * q_psi
-  NQ_PHASE_FENCE();
-  F::template run<false>(w, j, c, lds, twr);
-  {
-    const XRow rp = xrow(Mr, row);
-#pragma unroll
-    for (int t = 0; t < P; ++t) *rp.at(j + t * T) = w[t];
-  }
-  // advection u phix + v phiy: w <- u*phix, then w += v*phiy
+  for (int t = 0; t < P; ++t) acc[t] = cmake(-cr * qpsi[t] * w[t].y, cr * qpsi[t] * w[t].x);   // i cr phi q_psi
   {
     const XRow rgx = xrow(Mgx, row);
 #pragma unroll
@@ -326,15 +322,26 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   for (int t = 0; t < P; ++t) w[t] = cscale(w[t], u[t]);
   NQ_PHASE_FENCE();
   F::template run<true>(pre, j, c, lds, twr);
+  double js[2] = {0.0, 0.0};
 #pragma unroll
-  for (int t = 0; t < P; ++t) w[t] = cmake(w[t].x + pre[t].x * v[t], w[t].y + pre[t].y * v[t]);
-  NQ_PHASE_FENCE();
-  F::template run<false>(w, j, c, lds, twr);
-  {
-    const XRow rp = xrow(Mj, row);
-#pragma unroll
-    for (int t = 0; t < P; ++t) *rp.at(j + t * T) = w[t];
+  for (int t = 0; t < P; ++t) {
+    const cd J = cmake(w[t].x + pre[t].x * v[t], w[t].y + pre[t].y * v[t]);
+    js[0] += J.x;
+    js[1] += J.y;
+    acc[t] = cmake(acc[t].x + cj * J.x, acc[t].y + cj * J.y);
   }
+  NQ_PHASE_FENCE();
+  F::template run<false>(acc, j, c, lds, twr);
+  {
+    const XRow rp = xrow(Mw, row);
+#pragma unroll
+    for (int t = 0; t < P; ++t) *rp.at(j + t * T) = acc[t];
+  }
+  // sum of the Jacobian part over this workgroup's rows -> passenger slot of its first row (the slots of the
+  // other rows of a multi-row workgroup stay zero); column Muq.W of block 0 is padding of the half-spectrum row
+  NQ_PHASE_FENCE();
+  double* red = reinterpret_cast<double*>(nq_smem + X::LDS_BYTES - 512);
+  block_sum_store<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)blockIdx.x * X::C * Muq.pitch + Muq.W));
 }
 
 // ---- ETDRK4 stage update of one spectral element -----------------------------------------------
@@ -471,11 +478,11 @@ k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __rest
 // With budgets (bw.part != null) it also emits the
 // Parseval sums of ref Kernel.py:629-633, :646-652, :698-699 (see oracle/reduced_pipeline.py).
 struct BudgetW {
-  double* part;        // [workgroup][8]: S0..S3 of the NEW phih, then GJ, XJ, GR, XR of this stage; null = off
-  const cd* y_start;   // phih at the start of this stage (what J and R were computed from)
+  double* part;        // [workgroup][6]: S0..S3 of the NEW phih, then SG, SX of this stage; null = off
+  const cd* y_start;   // phih at the start of this stage (what the tendency was computed from)
   double nu4w, nuw, muw;
 };
-constexpr int NQ_PARTW = 8;
+constexpr int NQ_PARTW = 6;
 
 // a[], b[] hold y/M and i*l*y/M on return; budgets: sums over the new y
 template <int P, int T>
@@ -502,9 +509,9 @@ __device__ __forceinline__ void phi_outputs(const cd (&y)[P], cd (&a)[P], cd (&b
 
 template <int S1>
 __global__ void __launch_bounds__(YPlan<S1>::THREADS)
-k_s_phi(MArr Hj, MArr Hr, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphiy, double invM,
-        const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N,
-        BudgetW bw) {
+k_s_phi(MArr Hw, const cd* __restrict__ jpass, int jpitch, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphiy,
+        double invM, const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw,
+        int tw_step_N, BudgetW bw) {
   typedef YPlan<S1> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
@@ -519,36 +526,36 @@ k_s_phi(MArr Hj, MArr Hr, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphi
   double* part = bud ? bw.part + NQ_PARTW * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
   cd a[P], b[P], y[P];
 #pragma unroll
-  for (int t = 0; t < P; ++t) {
-    const size_t at = (size_t)(l1 * S1 + j + t * T) * Hj.pitch + k;
-    a[t] = Hj.ys[at];
-    b[t] = Hr.ys[at];
+  for (int t = 0; t < P; ++t) a[t] = Hw.ys[(size_t)(l1 * S1 + j + t * T) * Hw.pitch + k];
+  // [0,0]: the Jacobian part of the tendency is zeroed there (ref Kernel.py:468) -- add its domain sum back
+  double jfix[2] = {0.0, 0.0};
+  if (g.k0 == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    for (int yy = threadIdx.x; yy < N; yy += Y::THREADS) {
+      const cd z = jpass[(size_t)yy * jpitch];
+      jfix[0] += z.x;
+      jfix[1] += z.y;
+    }
+    block_sum_thread0<2>(jfix, red);
   }
   Y::F::template run<false>(a, j, c, lds, twr);
-  Y::F::template run<false>(b, j, c, lds, twr);
-  double sj[4] = {0.0, 0.0, 0.0, 0.0};
+  double sj[2] = {0.0, 0.0};
   const double kx = kk[kg];
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int l = l1 + S2 * (j + t * T);
     const size_t idx = (size_t)l * g.pitch_s + k;
     if (bud) {
-      // gamma2 ~ sum Re(conj(lap_h) J), xi1 ~ -sum Im(diss_h conj(J)) with lap_h = -wv2 ys, diss_h = -d ys;
-      // gamma1 ~ mean(q_psi Im(conj(phi) lap phi)) = sum Im(conj(R) lap_h) / M^2 and
-      // xi2 ~ mean(q_psi Re(diss conj(phi))) = sum Re(conj(R) diss_h) / M^2, R = fft2(phi q_psi) (ref Kernel.py:691-700)
+      // With W = F[-J - (i/2) phi q_psi] (un-zeroed), lap_h = -wv2 ys, diss_h = -d ys (ref Kernel.py:691-700):
+      //   gamma1 + gamma2 = -hslash/2 sum Re(conj(lap_h) W) / (M^2 f),   xi1 + xi2 = -sum Im(conj(diss_h) W) / (M^2 f)
       const cd ys = bw.y_start[idx];
       const double ly = ll[l];
       const double wv2 = kx * kx + ly * ly;
       const double d = bw.nu4w * wv2 * wv2 + bw.nuw * wv2 + bw.muw;
       sj[0] += -wv2 * (ys.x * a[t].x + ys.y * a[t].y);
-      sj[1] += -d * (ys.y * a[t].x - ys.x * a[t].y);
-      sj[2] += -wv2 * (b[t].x * ys.y - b[t].y * ys.x);
-      sj[3] += -d * (b[t].x * ys.x + b[t].y * ys.y);
+      sj[1] += -d * (ys.x * a[t].y - ys.y * a[t].x);
     }
-    cd J = a[t];
-    if (l == 0 && kg == 0) J = cmake(0, 0);
-    // N_phi = -J - 0.5 i R
-    const cd Nl = cmake(-J.x + 0.5 * b[t].y, -J.y - 0.5 * b[t].x);
+    cd Nl = a[t];                                       // N_phi = -J - 0.5 i R
+    if (l == 0 && kg == 0) Nl = cmake(Nl.x + jfix[0], Nl.y + jfix[1]);
     y[t] = etd_update(ea, idx, Nl, stage);
   }
   double s4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -563,7 +570,7 @@ k_s_phi(MArr Hj, MArr Hr, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphi
   }
   if (bud) {
     block_sum_store<4>(s4, red, part);
-    block_sum_store<4>(sj, red, part + 4);
+    block_sum_store<2>(sj, red, part + 4);
   }
 }
 
@@ -599,9 +606,9 @@ k_s_emit_phi(const cd* __restrict__ phih, YGeom g, MArr Hphi, MArr Hphiy, double
   }
   if (bud) {
     double* part = bw.part + NQ_PARTW * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-    double z4[4] = {0.0, 0.0, 0.0, 0.0};
+    double z2[2] = {0.0, 0.0};
     block_sum_store<4>(s4, red, part);
-    block_sum_store<4>(z4, red, part + 4);
+    block_sum_store<2>(z2, red, part + 4);
   }
 }
 

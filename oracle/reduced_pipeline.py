@@ -198,31 +198,30 @@ class ReducedNIWQG:
         Nq[0, 0] = 0.0
         Npass = self.il[n // 2, 1:n // 2] * F2[n // 2, 1:n // 2] * -1.0     # passenger source, row l=N/2
         Jphys = u * phix + v * phiy
-        J = self._c2c_fwd(Jphys)
-        R = self._c2c_fwd(self.phi * qpsi)
-        J0 = J.copy()
-        J0[0, 0] = 0.0
-        Nw = -J0 - 0.5j * R
+        # ONE transform for the whole phi tendency: N_phi = F[-J - (i/2) phi q_psi].  The reference zeroes
+        # jach[0,0] but not the refraction term (Kernel.py:468 vs :332): the domain sum of J is added back there.
+        Wn = self._c2c_fwd(-Jphys - 0.5j * self.phi * qpsi)
+        Nw = Wn.copy()
+        Nw[0, 0] += Jphys.sum()
         rates = None
         if want_budget:
-            rates = self._budget_rates(J, R, qpsi)
+            rates = self._budget_rates(Wn)
         return Nq, Nw, Npass, rates
 
-    def _budget_rates(self, J, R, qpsi):
-        """k, p, a of ref Kernel.py:319-322, every integral a Parseval sum.  gamma1 and xi2 are triple products in
-        physical space, but q_psi*phi is exactly the refraction source whose transform R the stage needs anyway:
-        mean(q_psi Im(conj(phi) lap phi)) = Im sum(conj(R) lap_h) / M^2 (same for diss), so neither lap(phi) nor
-        diss(phi) is ever brought to physical space."""
+    def _budget_rates(self, Wn):
+        """k, p, a of ref Kernel.py:319-322, every integral a Parseval sum.  gamma1 and xi2 are triple products
+        in physical space, but q_psi*phi is the refraction source, and the budgets only ever use gamma1+gamma2 and
+        xi1+xi2, which are projections of the WHOLE phi tendency Wn = F[-J - (i/2) phi q_psi] (un-zeroed at [0,0]):
+            gamma1 + gamma2 = -hslash/2 sum Re(conj(lap_h) Wn) / (M^2 f),   xi1 + xi2 = -sum Im(conj(diss_h) Wn) / (M^2 f)
+        so neither lap(phi), diss(phi), J nor R is needed on its own."""
         n = self.nx
         M2 = float(n) ** 4
         g = self.phih_grad
         lapphi_h = -self.wv2 * self.phih
         lap2phi_h = self.wv2 ** 2 * self.phih
         diss_h = -self.nu4w * lap2phi_h + self.nuw * lapphi_h - self.muw * self.phih
-        gamma1 = 0.25 * self.hslash * (np.conj(R) * lapphi_h).imag.sum() / M2 / self.f
-        gamma2 = 0.5 * self.hslash * (np.conj(lapphi_h) * J).real.sum() / M2 / self.f
-        xi1 = -((diss_h * np.conj(J)).imag.sum() / M2) / self.f
-        xi2 = 0.5 * (np.conj(R) * diss_h).real.sum() / M2 / self.f
+        gamma12 = -0.5 * self.hslash * (np.conj(lapphi_h) * Wn).real.sum() / M2 / self.f
+        xi12 = -(np.conj(diss_h) * Wn).imag.sum() / M2 / self.f
         # ep_psi (ref Kernel.py:635-640): all Parseval on the half spectrum
         ep_psi = (self.nu4 * hs_mean_product(self.qh, self.wv4_h * self.ph)
                   - self.nu * hs_mean_product(self.ph, -self.wv2_h * self.qh)
@@ -233,8 +232,8 @@ class ReducedNIWQG:
         phi2 = (np.abs(self.phih) ** 2).sum() / M2
         chi_phi = (-0.5 * self.nu4w * glap2 - 0.5 * self.nuw * lap2 - 0.5 * self.muw * grad2) / self.kappa2
         ep_phi = -self.nu4w * lap2 - self.nuw * grad2 - self.muw * phi2
-        k = -(gamma1 + gamma2) + (xi1 + xi2) + ep_psi
-        p = gamma1 + gamma2 + chi_phi
+        k = -gamma12 + xi12 + ep_psi
+        p = gamma12 + chi_phi
         return k, p, ep_phi
 
     def _etd(self, c, F, y0, y1, N, stage):

@@ -35,9 +35,9 @@ def test_coupled_reduced_equals_faithful(use_filter):
     assert rel(b.ph_full, a.ph) < 1e-12
     assert rel(b.qwh_full, a.qwh) < 1e-12
     assert np.allclose([b.Ke, b.Pw, b.Kw], [a.Ke, a.Pw, a.Kw], rtol=1e-9)
-    # 11 c2c-equivalents per stage in this model (the device shares phi, phix, phiy between the
-    # inversion and the next stage: 9; the budget integrals need none) instead of the reference's 26
-    assert b.n2d == 30 * 4 * 11 + 3
+    # 10 c2c-equivalents per stage in this model (the device shares phi, phix, phiy between the
+    # inversion and the next stage: 8; the budget integrals need none) instead of the reference's 26
+    assert b.n2d == 30 * 4 * 10 + 3
 
 
 def test_passenger_is_needed_for_exact_qh_without_filter():

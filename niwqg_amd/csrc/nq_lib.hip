@@ -345,6 +345,7 @@ __global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums
 
 // ---------------------------------------------------------------------------------------------
 // size dispatch
+#define M_SMALL(M) M(64, 8, 8) M(128, 8, 16) M(256, 16, 16) M(512, 16, 32) M(1024, 32, 32) M(2048, 32, 64) M(8192, 64, 128)
 #define NQ_FOR_SIZES(M) M(64, 8, 8) M(128, 8, 16) M(256, 16, 16) M(512, 16, 32) M(1024, 32, 32) M(2048, 32, 64) M(4096, 64, 64) M(8192, 64, 128)
 
 static bool plan_for(int N, int* S1, int* S2) {
@@ -528,7 +529,13 @@ static void launch_wavepv(nq_ctx* c) {
   ProfScope ps(c, PK_WAVEPV);
   switch (c->N) {
 #define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx1, c->kk); } break;
-    NQ_FOR_SIZES(CASE_)
+    case 4096: {                                      // long rows: two transforms in flight, no spills
+      typedef XPlan<4096> X;
+      const size_t ldsb = X::LDS_BYTES + X::F::LDS_ELEMS * sizeof(cd);
+      const int nb = c->Nloc / X::C, grid = nb < c->num_cu ? nb : c->num_cu;      // one persistent workgroup per CU
+      hipLaunchKernelGGL((k_x_wavepv2<4096>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx, c->kk, nb);
+    } break;
+    M_SMALL(CASE_)
 #undef CASE_
   }
 }
@@ -538,7 +545,9 @@ static void launch_products_m(nq_ctx* c, double cj, double cr) {
   const MArr& gx = (MODE == MODE_UNCOUPLED) ? c->mGx : c->mPhi;
   const MArr& gy = (MODE == MODE_UNCOUPLED) ? c->mGy : c->mPhiy;
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_products<n, MODE>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mW, c->twx, c->kk, vz, cj, cr); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; const int nb = c->Nloc / X::C; \
+    const int grid = (X::LDS_BYTES > 80 * 1024 && nb > c->num_cu) ? c->num_cu : nb;   /* one workgroup per CU: persistent */ \
+    hipLaunchKernelGGL((k_x_products<n, MODE>), dim3(grid), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mW, c->twx, c->kk, vz, cj, cr, nb); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }

@@ -229,6 +229,96 @@ k_x_wavepv(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, c
   unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, xrow(Ma, row), xrow(Mb, row), isb);
 }
 
+// Variant for long rows: 8 points per thread, ONE workgroup per CU, the two transforms that share an input (phi and
+// phix = ifft(ik phi)) in flight together (WgFft::run2: the LDS stores of one drain under the butterflies of the
+// other), phiy prefetched under them.  No spills (k_x_wavepv at 16 points per thread spills 32 VGPRs at 4096:
+// +0.33 GB of scratch traffic per launch, profiles/r01_pmc_summary.json).
+template <int N>
+__global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
+k_x_wavepv2(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, const double* __restrict__ kk,
+            int nblocks) {
+  typedef XPlan<N> X;
+  typedef typename X::F F;
+  constexpr int P = X::P, T = X::T;
+  const int j_tid = threadIdx.x % T, c_tid = threadIdx.x / T;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd* lds_b = lds + F::LDS_ELEMS;                       // second exchange area
+  cd* twl = lds_b + F::LDS_ELEMS;
+  for (int i = threadIdx.x; i < F::TW_LDS_ELEMS; i += X::THREADS) twl[i] = tw[i];
+  typename F::TwLds twr;
+  twr.base = twl;
+  wg_barrier_all();
+  // persistent: row blocks rb = blockIdx.x, +gridDim.x, ...; the next block's phi row is requested before the
+  // forward transform of this one, so its latency hides behind that transform and the stores
+  cd nxt[P];
+  {
+    const XRow r0 = xrow(Mphi, (size_t)blockIdx.x * X::C + c_tid);
+#pragma unroll
+    for (int t = 0; t < P; ++t) nxt[t] = *r0.at(j_tid + t * T);
+  }
+  for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+    // per-iteration copies the compiler cannot see through: otherwise every LDS / row address of the transforms is
+    // loop-invariant, gets hoisted out of the loop and spills
+    int j = j_tid, c = c_tid;
+    asm volatile("" : "+v"(j), "+v"(c));
+    const size_t row = (size_t)rb * X::C + c;
+    const bool more = rb + (int)gridDim.x < nblocks;
+    const XRow rphiy = xrow(Mphiy, row);
+    cd w[P], gx[P], py[P];
+    double a[P];
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const int kx = j + t * T;
+      w[t] = nxt[t];
+      gx[t] = cscale(cmul_i(w[t]), kk[kx]);
+    }
+#pragma unroll
+    for (int t = 0; t < P; ++t) py[t] = *rphiy.at(j + t * T);
+    NQ_PHASE_FENCE();
+    F::template run2<true>(w, gx, j, c, lds, lds_b, twr);
+    double ma = 0.0, mb = 0.0;
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      a[t] = w[t].x * w[t].x + w[t].y * w[t].y;
+      ma = fmax(ma, a[t]);
+    }
+    NQ_PHASE_FENCE();
+    F::template run<true>(py, j, c, lds, twr);
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const double b = -2.0 * (gx[t].x * py[t].y - gx[t].y * py[t].x);
+      mb = fmax(mb, fabs(b));
+      w[t] = cmake(a[t], b);
+    }
+    if (more) {
+      const XRow rn = xrow(Mphi, row + (size_t)gridDim.x * X::C);
+#pragma unroll
+      for (int t = 0; t < P; ++t) nxt[t] = *rn.at(j + t * T);
+    }
+    unsigned long long* mx = reinterpret_cast<unsigned long long*>(twl + F::TW_LDS_ELEMS) + 2 * c;
+    if (j == 0) {
+      mx[0] = 0ull;
+      mx[1] = 0ull;
+    }
+    wg_barrier();
+    atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
+    atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
+    wg_barrier();
+    ma = __longlong_as_double((long long)mx[0]);
+    mb = __longlong_as_double((long long)mx[1]);
+    int e = 0;
+    if (ma > 0.0 && mb > 0.0) e = ilogb(ma) - ilogb(mb);
+    e = e > 900 ? 900 : (e < -900 ? -900 : e);
+    const double sb = ldexp(1.0, e), isb = ldexp(1.0, -e);
+#pragma unroll
+    for (int t = 0; t < P; ++t) w[t].y *= sb;
+    NQ_PHASE_FENCE();
+    F::template run<false>(w, j, c, lds, twr);
+    NQ_PHASE_FENCE();
+    unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow(Ma, row), xrow(Mb, row), isb);
+  }
+}
+
 // ---- X2: all nonlinear products of one stage ------------------------------------------------
 // ref Kernel.py:471-486 (jacobian_psi_q), :457-469 (jacobian_psi_phi), :332 (refraction).  The budget terms
 // gamma1+gamma2 and xi1+xi2 (Kernel.py:691-700) are Parseval sums against the transformed phi tendency in k_s_phi:
@@ -238,12 +328,12 @@ k_x_wavepv(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, c
 template <int N, int MODE>
 __global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
 k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy, MArr Muq, MArr Mvq, MArr Mw,
-             const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq, double cj, double cr) {
+             const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq, double cj, double cr,
+             int nblocks) {
   typedef XPlan<N> X;
   typedef typename X::F F;
   constexpr int P = X::P, T = X::T;
-  const int j = threadIdx.x % T, c = threadIdx.x / T;
-  const size_t row = (size_t)blockIdx.x * X::C + c;
+  const int j_tid = threadIdx.x % T, c_tid = threadIdx.x / T;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
   // stage twiddles: table in LDS behind the exchange area (`tw` = host-built stage table here)
   cd* twl = lds + XPlan<N>::F::LDS_ELEMS;
@@ -251,13 +341,27 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   typename XPlan<N>::F::TwLds twr;
   twr.base = twl;
   wg_barrier_all();
-  cd w[P];
-  double q[P], qpsi[P], u[P], v[P];
   // Software pipeline: the rows of the NEXT phase are requested before each transform and consumed after
   // it (barriers inside the transforms no longer wait for global memory), so with one workgroup per CU
   // the HBM latency hides behind the FFTs.  Every mixed-space input is fetched exactly once.
-  HsRegs<P> h1, h2;
-  hs_load<N, P, T, MODE == MODE_COUPLED>(h1, xrow(Mq, row), xrow(MODE == MODE_COUPLED ? Mqw : Mq, row), j);
+  // The workgroup is persistent over row blocks rb = blockIdx.x, +gridDim.x, ...; the first inputs of its next block
+  // are requested before the last transform of the current one.
+  HsRegs<P> h1;
+  {
+    const size_t row0 = (size_t)blockIdx.x * X::C + c_tid;
+    hs_load<N, P, T, MODE == MODE_COUPLED>(h1, xrow(Mq, row0), xrow(MODE == MODE_COUPLED ? Mqw : Mq, row0), j_tid);
+  }
+  for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+  // per-iteration copies the compiler cannot see through: otherwise every LDS / row address of the transforms is
+  // loop-invariant, gets hoisted out of the loop and spills
+  int j = j_tid, c = c_tid;
+  asm volatile("" : "+v"(j), "+v"(c));
+  const size_t row = (size_t)rb * X::C + c;
+  const bool more = rb + (int)gridDim.x < nblocks;
+  const size_t row_next = more ? row + (size_t)gridDim.x * X::C : row;
+  cd w[P];
+  double q[P], qpsi[P], u[P], v[P];
+  HsRegs<P> h2;
   hs_load<N, P, T, true>(h2, xrow(Mu, row), xrow(Mp, row), j);
   NQ_PHASE_FENCE();
   hs_pack<N, P, T, F, MODE == MODE_COUPLED>(w, h1, j, c, lds, kk, false, false);
@@ -289,7 +393,10 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   F::template run<false>(w, j, c, lds, twr);
   NQ_PHASE_FENCE();
   unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow(Muq, row), xrow(Mvq, row));
-  if (MODE == MODE_QG) return;
+  if (MODE == MODE_QG) {
+    if (more) hs_load<N, P, T, false>(h1, xrow(Mq, row_next), xrow(Mq, row_next), j);
+    continue;
+  }
   // phi tendency source in ONE array: W = cj (u phix + v phiy) + i cr phi q_psi  (cj = -1, cr = -1/2 in a step:
   // N_phi = F[W] except at [0,0], where the reference zeroes the Jacobian part only, ref Kernel.py:468 vs :332;
   // the row sums of the Jacobian part travel in a padding column of Muq and are added back in k_s_phi)
@@ -332,6 +439,9 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   }
   NQ_PHASE_FENCE();
   F::template run<false>(acc, j, c, lds, twr);
+  NQ_PHASE_FENCE();
+  // first inputs of the next row block: requested before the stores so that they are not queued behind them
+  if (more) hs_load<N, P, T, MODE == MODE_COUPLED>(h1, xrow(Mq, row_next), xrow(MODE == MODE_COUPLED ? Mqw : Mq, row_next), j);
   {
     const XRow rp = xrow(Mw, row);
 #pragma unroll
@@ -341,7 +451,8 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   // other rows of a multi-row workgroup stay zero); column Muq.W of block 0 is padding of the half-spectrum row
   NQ_PHASE_FENCE();
   double* red = reinterpret_cast<double*>(nq_smem + X::LDS_BYTES - 512);
-  block_sum_store<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)blockIdx.x * X::C * Muq.pitch + Muq.W));
+  block_sum_store<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)rb * X::C * Muq.pitch + Muq.W));
+  }   // row blocks
 }
 
 // ---- ETDRK4 stage update of one spectral element -----------------------------------------------

@@ -546,7 +546,8 @@ static void launch_products_m(nq_ctx* c, double cj, double cr) {
   const MArr& gy = (MODE == MODE_UNCOUPLED) ? c->mGy : c->mPhiy;
   switch (c->N) {
 #define CASE_(n, a, b) case n: { typedef XPlan<n> X; const int nb = c->Nloc / X::C; \
-    const int grid = (X::LDS_BYTES > 80 * 1024 && nb > c->num_cu) ? c->num_cu : nb;   /* one workgroup per CU: persistent */ \
+    /* one workgroup fits per CU (LDS) and does not spill: persistent; 8192-point rows spill and do better with dynamic dispatch */ \
+    const int grid = (X::LDS_BYTES > 80 * 1024 && X::THREADS <= 512 && nb > c->num_cu) ? c->num_cu : nb; \
     hipLaunchKernelGGL((k_x_products<n, MODE>), dim3(grid), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mW, c->twx, c->kk, vz, cj, cr, nb); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_

@@ -111,6 +111,22 @@ int nq_jacobian_psi_q(nq_ctx* ctx, double* out_cplx);
 int nq_jacobian_psi_phi(nq_ctx* ctx, double* out_cplx);
 int nq_jacobian_phic_phi(nq_ctx* ctx, double* out_cplx);
 
+/* Diagnostics tick on the device: the raw sums from which every scalar of increment_diagnostics (Diagnostics.py:41-58;
+ * the 21 kernel lambdas Kernel.py:718-868 and the 3 class lambdas CoupledModel.py:115-136) follows without any plane
+ * leaving the GPU.  out: 32 doubles, M = nx*nx, H = Hermitian part on the two self-mirrored columns:
+ *   [0..3]  sum wv2^n |phih|^2, n = 0..3      (ke_niw, pe_niw, ep_phi, chi_phi; Kernel.py:604-611, :629-652)
+ *   [4,5]   phih[0,0]                         (cke_niw, pi; Kernel.py:701-706)
+ *   [6]     sum |H qh|^2          -> ens      [7] sum wv4 |qh|^2 -> chi_q        [8]  sum |qh|^2/wv2  -> ke_qg_q
+ *   [9]     sum |qwh|^2/wv2       -> ke_qg_w  [10] sum Re(conj(H qh) H qwh)/wv2 -> -ke_qg_qw
+ *   [11]    sum wv2 |ph|^2        -> ke_qg    [12..14] sum {wv4, wv2, 1} Re(conj(H ph) H qh) -> ep_psi (Kernel.py:635-640)
+ *   [15]    mean(q_psi)
+ *   [16..23] physical sums: q^2, q_psi^2, q_psi^3, (q_psi-mean)^2, ups^2, ups q_psi, q_psi Re(phi), q_psi Im(phi),
+ *            ups = |phi|^2 - mean|phi|^2     (conc_niw, skew, pi; Kernel.py:613-623, :701)
+ *   [24..27] sum {Re, Im}(conj(lap_h) J), {Re, Im}(conj(diss_h) J),  J = F[u phix + v phiy]        (gamma2, xi1)
+ *   [28..31] the same four with i F[phi q_psi] in place of J                                        (gamma1, xi2)
+ * Sums over the half spectrum carry weight 2 on the interior columns.  QGModel: entries [6..15] only.          */
+int nq_diagnostics(nq_ctx* ctx, double* out32);
+
 /* copy of one ETDRK4 coefficient plane (0:E 1:Eh 2:Q 3:f0 4:fab 5:fc) of equation eq (0:q 1:phi),
  * without the filter folded in; host layout as the reference's expch, expch_h, Qh, f0, fab, fc.      */
 int nq_get_coeff(nq_ctx* ctx, int eq, int which, double* out_cplx);

@@ -26,14 +26,11 @@ class Model(Kernel.Kernel):
         return jach
 
     def _calc_ke_qg_decomp(self):
-        """ref: niwqg/CoupledModel.py:99-113 (diagnostic tick, host arithmetic on downloaded spectra)"""
-        self.phq = -self.wv2i * self.qh
-        self.ke_qg_q = 0.5 * self.spec_var(self.wv * self.phq)
-        self.phw = self.wv2i * self.qwh
-        self.ke_qg_w = 0.5 * self.spec_var(self.wv * self.phw)
-        self.uq, self.vq = self.ifft(-self.il * self.phq).real, self.ifft(self.ik * self.phq).real
-        self.uw, self.vw = self.ifft(-self.il * self.phw).real, self.ifft(self.ik * self.phw).real
-        self.ke_qg_qw = (self.uq * self.uw).mean() + (self.vq * self.vw).mean()
+        """ref: niwqg/CoupledModel.py:99-113 from the half-spectrum sums of the device tick (Parseval)"""
+        s = self._dsums()
+        self.ke_qg_q = 0.5 * s[8] / self._M2
+        self.ke_qg_w = 0.5 * s[9] / self._M2
+        self.ke_qg_qw = -s[10] / self._M2
 
     def _initialize_class_diagnostics(self):
         """ref: niwqg/CoupledModel.py:115-136"""

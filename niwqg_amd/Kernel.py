@@ -125,6 +125,11 @@ class Kernel(object):
             return self.__dict__[name]
         if name in _DEVICE_FIELDS or name in ("qh", "ph", "qwh", "q_psi", "qw"):
             return self._field(name)
+        if name == "lapphi":             # fields the reference leaves behind after a diagnostics tick, on demand
+            return self.ifft(-self.wv2 * self.phih)
+        if name == "upsilon":
+            a2 = np.abs(self.phi) ** 2
+            return a2 - a2.mean()
         raise AttributeError(name)
 
     def _build_planes(self):
@@ -207,7 +212,7 @@ class Kernel(object):
     def set_phi(self, phi):
         """ref: niwqg/Kernel.py:538-551 -- does NOT re-invert (quirk Q2)"""
         self._ctx.set_phi(phi)
-        keep = {k: v for k, v in self._cache.items() if k not in ("phi", "phih", "phix", "phiy")}
+        keep = {k: v for k, v in self._cache.items() if k not in ("phi", "phih", "phix", "phiy", "_dsums")}
         keepu = {k: v for k, v in self._user.items() if k != "phi"}
         self._cache, self._user = keep, keepu
         self._user["phi"] = phi
@@ -327,69 +332,82 @@ class Kernel(object):
         self._ctx.refresh_grad_phi()
         self._cache.pop("phix", None)
         self._cache.pop("phiy", None)
-        return self._ctx.scalar(_lib.S_PE_NIW)
+        pe = self._ctx.scalar(_lib.S_PE_NIW)
+        self._grad2_mean = 4. * self.kappa2 * pe         # mean(|phix|^2 + |phiy|^2) of the refreshed gradients
+        return pe
 
     def _calc_cfl(self):
         """ref: niwqg/Kernel.py:660-662"""
         return self._ctx.scalar(_lib.S_CFL) * self.dt / self.dx      # max reduction on the device
 
+    # Everything below is evaluated from the 32 raw sums of ONE device pass (nq_diagnostics): no plane is
+    # downloaded at a diagnostics tick.  Index map: include/niwqg_amd.h.
+    def _dsums(self):
+        if "_dsums" not in self._cache:
+            self._cache["_dsums"] = self._ctx.diagnostic_sums()
+        return self._cache["_dsums"]
+
+    def _grad2(self, s):
+        """mean(|phix|^2 + |phiy|^2) of phix, phiy AS LAST REFRESHED (UnCoupled keeps stale ones: quirk Q1)"""
+        if self.model_id == _lib.UNCOUPLED and hasattr(self, "_grad2_mean"):
+            return self._grad2_mean
+        return s[1] / self._M2
+
+    @property
+    def _M2(self):
+        return (float(self.nx) * self.ny) ** 2
+
     def _calc_ens(self):
-        return 0.5 * (self.q ** 2).mean()
+        """ref: niwqg/Kernel.py:625-627 by Parseval"""
+        return 0.5 * self._dsums()[6] / self._M2
 
     def _calc_conc(self):
         """ref: niwqg/Kernel.py:613-619"""
-        a2 = np.abs(self.phi) ** 2
-        self.upsilon = a2 - a2.mean()
+        s, M = self._dsums(), float(self.nx) * self.ny
         with np.errstate(invalid="ignore", divide="ignore"):
-            return (self.upsilon * self.q_psi).mean() / self.upsilon.std() / self.q_psi.std()
+            return (s[21] / M) / np.sqrt(s[20] / M) / np.sqrt(s[19] / M)
 
     def _calc_skewness(self):
-        return (self.q_psi ** 3).mean() / (((self.q_psi ** 2).mean()) ** 1.5)
+        """ref: niwqg/Kernel.py:621-623"""
+        s, M = self._dsums(), float(self.nx) * self.ny
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return (s[18] / M) / ((s[17] / M) ** 1.5)
 
     def _calc_ep_phi(self):
         """ref: niwqg/Kernel.py:629-633"""
-        return (-self.nu4w * (np.abs(self.lapphi) ** 2).mean()
-                - self.nuw * (np.abs(self.phix) ** 2 + np.abs(self.phiy) ** 2).mean()
-                - self.muw * (np.abs(self.phi) ** 2).mean())
+        s = self._dsums()
+        return (-self.nu4w * s[2] - self.muw * s[0]) / self._M2 - self.nuw * self._grad2(s)
 
     def _calc_ep_psi(self):
         """ref: niwqg/Kernel.py:635-640"""
-        lap2psi = self.ifft(self.wv4 * self.ph).real
-        lapq = self.ifft(-self.wv2 * self.qh).real
-        return (self.nu4 * (self.q * lap2psi).mean() - self.nu * (self.p * lapq).mean()
-                + self.mu * (self.p * self.q).mean())
+        s = self._dsums()
+        return (self.nu4 * s[12] + self.nu * s[13] + self.mu * s[14]) / self._M2
 
     def _calc_chi_q(self):
-        return -self.nu4 * self.spec_var(self.wv2 * self.qh)
+        """ref: niwqg/Kernel.py:642-644"""
+        return -self.nu4 * self._dsums()[7] / self._M2
 
     def _calc_chi_phi(self):
         """ref: niwqg/Kernel.py:646-652"""
-        lphix = self.ifft(-self.ik * self.wv2 * self.phih)
-        lphiy = self.ifft(-self.il * self.wv2 * self.phih)
-        return (-0.5 * self.nu4w * (np.abs(lphix) ** 2 + np.abs(lphiy) ** 2).mean() / self.kappa2
-                - 0.5 * self.nuw * (np.abs(self.lapphi) ** 2).mean() / self.kappa2
-                - 0.5 * self.muw * (np.abs(self.phix) ** 2 + np.abs(self.phiy) ** 2).mean() / self.kappa2)
+        s = self._dsums()
+        return ((-0.5 * self.nu4w * s[3] - 0.5 * self.nuw * s[2]) / self._M2
+                - 0.5 * self.muw * self._grad2(s)) / self.kappa2
 
     def _calc_energy_conversion(self):
-        """Diagnostic-tick version of ref niwqg/Kernel.py:664-701 on downloaded fields (the in-step
-        budget rates are evaluated on the device)."""
-        u, v, phi, qpsi = self.u, self.v, self.phi, self.q_psi
-        J = u * self.phix + v * self.phiy
-        self.lapphi = self.ifft(-self.wv2 * self.phih)
-        lap2phi = self.ifft(self.wv4 * self.phih)
-        diss = -self.nu4w * lap2phi + self.nuw * self.lapphi - self.muw * phi
-        J_diss = -(diss * np.conj(J)).imag
-        L_diss = 0.5 * (diss * np.conj(phi)).real * qpsi
-        divFw = 0.5 * self.hslash * (np.conj(phi) * self.lapphi).imag
-        self.gamma1 = (0.5 * qpsi * divFw).mean() / self.f
-        self.gamma2 = 0.5 * self.hslash * ((np.conj(self.lapphi) * J).real).mean() / self.f
-        self.xi1 = J_diss.mean() / self.f
-        self.xi2 = L_diss.mean() / self.f
-        self.pi = (0.5 * phi.mean() * (qpsi * np.conj(phi)).mean()).imag
+        """Diagnostic-tick version of ref niwqg/Kernel.py:664-701: gamma1, gamma2, xi1, xi2 as projections of
+        F[u phix + v phiy] and F[phi q_psi] on lap_h and diss_h, pi from two domain means."""
+        s, M = self._dsums(), float(self.nx) * self.ny
+        M2f = self._M2 * self.f
+        self.gamma2 = 0.5 * self.hslash * s[24] / M2f
+        self.xi1 = s[27] / M2f
+        self.gamma1 = 0.25 * self.hslash * s[28] / M2f
+        self.xi2 = 0.5 * s[31] / M2f
+        self.pi = (0.5 * (complex(s[4], s[5]) / M) * (complex(s[22], -s[23]) / M)).imag
 
     def _calc_icke_niw(self):
-        self.ke_niw = self._calc_ke_niw()
-        self.cke_niw = 0.5 * (np.abs(self.phi.mean()) ** 2)
+        s = self._dsums()
+        self.ke_niw = 0.5 * s[0] / self._M2
+        self.cke_niw = 0.5 * (s[4] ** 2 + s[5] ** 2) / self._M2
         self.ike_niw = self.ke_niw - self.cke_niw
 
     # ------------------------------------------------------------------ diagnostics registry
@@ -406,7 +424,7 @@ class Kernel(object):
             ('Pw', 'NIW Potential Energy, from energy equation', r'm^2 s^{-2}', lambda s: s.Pw),
             ('Kw', 'NIW Kinetic Energy, from energy equation', r'm^2 s^{-2}', lambda s: s.Kw),
             ('ke_qg', 'Quasigeostrophic Kinetic Energy', r'm^2 s^{-2}', lambda s: s._calc_ke_qg()),
-            ('ens', 'Quasigeostrophic Potential Enstrophy', r's^{-2}', lambda s: 0.5 * (s.q ** 2).mean()),
+            ('ens', 'Quasigeostrophic Potential Enstrophy', r's^{-2}', lambda s: s._calc_ens()),
             ('ke_niw', 'Near-inertial Kinetic Energy', r'm^2 s^{-2}', lambda s: s.ke_niw),
             ('cke_niw', 'Kinetic Energy of Laterally Coherent Near-Inertial Waves', r'm^2 s^{-2}',
              lambda s: s.cke_niw),

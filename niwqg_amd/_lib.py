@@ -26,7 +26,7 @@ COUPLED, UNCOUPLED, QG = 0, 1, 2
 
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
            "nq_step", "nq_sync", "nq_get_field", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
-           "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_get_coeff",
+           "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_get_coeff", "nq_diagnostics",
            "nq_timer_start", "nq_timer_stop", "nq_profile_enable", "nq_profile_read", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
            "nq_reduce_buffer", "nq_device_bytes", "nq_stream"]
@@ -78,7 +78,8 @@ def lib():
     L.nq_last_error.restype = ctypes.c_char_p
     for name in ("nq_destroy", "nq_invert", "nq_refresh_grad_phi", "nq_sync", "nq_timer_start"):
         getattr(L, name).argtypes = [vp]
-    for name in ("nq_set_q", "nq_set_phi", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi"):
+    for name in ("nq_set_q", "nq_set_phi", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi",
+                 "nq_diagnostics"):
         getattr(L, name).argtypes = [vp, dp]
     for name in ("nq_fft2", "nq_ifft2", "nq_rfft2", "nq_irfft2"):
         getattr(L, name).argtypes = [vp, dp, dp]
@@ -198,6 +199,13 @@ class Context:
         v = ctypes.c_double()
         self._chk(self.L.nq_get_scalar(self.h, sid, ctypes.byref(v)), "nq_get_scalar(%d)" % sid)
         return v.value
+
+    def diagnostic_sums(self):
+        """The 32 raw sums of one diagnostics tick (include/niwqg_amd.h: nq_diagnostics); nothing but these 256
+        bytes leaves the GPU."""
+        out = np.zeros(32)
+        self._chk(self.L.nq_diagnostics(self.h, _dptr(out)), "nq_diagnostics")
+        return out
 
     def coeff(self, eq, which):
         n = self.nx

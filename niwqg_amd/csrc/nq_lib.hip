@@ -90,6 +90,7 @@ struct nq_ctx {
   int nww = 0, nwq = 0;                           // workgroups of the two kernels that emit partial sums
   double *partW = nullptr, *partQ = nullptr;      // [4 stages][workgroups][NQ_PARTW | 3]
   double *part0W = nullptr, *part0Q = nullptr;    // partials of set_phi / set_q / nq_invert
+  double *diag_part = nullptr, *diag_out = nullptr;   // diagnostics tick: workgroup partials, 32 reduced sums
   double *carryW = nullptr, *carryQ = nullptr;    // spectral sums of the state at the start of the next step
   double *gradS1 = nullptr, *acc = nullptr;       // stale-aware sum wv2|phih_grad|^2 ; Ke,Pw,Kw increments
   double* bsums = nullptr;                        // [4 stages][11] reduced sums of one step
@@ -253,6 +254,77 @@ __global__ void k_reduce_real_max(const double* __restrict__ a, size_t n, double
     __syncthreads();
   }
   if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(sh[0]));
+}
+
+// diagnostics tick: spectral sums -----------------------------------------------------------------
+// Deterministic: every block writes its partial sums (part[block][NQ]); k_reduce_partials adds them.
+template <int NQ>
+__device__ void diag_block_store(double (&v)[NQ], double* __restrict__ part) {
+  __shared__ double sh[4][NQ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    double x = v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if (lane == 0) sh[wave][i] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) part[(size_t)blockIdx.x * NQ + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+// phih (local columns [k0, k0+width) of the full plane): S_n = sum wv2^n |phih|^2, n = 0..3   (256 threads)
+__global__ void k_diag_phi(const cd* __restrict__ phih, int N, int width, int pitch, int k0,
+                           const double* __restrict__ kk, const double* __restrict__ ll, double* __restrict__ part) {
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  const size_t total = (size_t)N * width;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i / width), k = (int)(i - (size_t)l * width);
+    const cd z = phih[(size_t)l * pitch + k];
+    const double kx = kk[k0 + k], ly = ll[l];
+    const double wv2 = kx * kx + ly * ly, m2 = z.x * z.x + z.y * z.y;
+    v[0] += m2;
+    v[1] += wv2 * m2;
+    v[2] += wv2 * wv2 * m2;
+    v[3] += wv2 * wv2 * wv2 * m2;
+  }
+  diag_block_store<4>(v, part);
+}
+// half spectra qh, qwh (may be null), ph; nine sums (see nq_diagnostics).  On the two self-mirrored columns the sums
+// that stand for means of REAL fields use the Hermitian part H(l) = (X(l) + conj X(-l))/2 (what `.real` keeps).
+__global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, const cd* __restrict__ ph, int N,
+                         int width, int pitch, const double* __restrict__ kk, const double* __restrict__ ll,
+                         double* __restrict__ part) {
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const size_t total = (size_t)N * width;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i / width), k = (int)(i - (size_t)l * width);
+    const size_t idx = (size_t)l * pitch + k;
+    const cd q = qh[idx], w = qwh ? qwh[idx] : cmake(0, 0), p = ph[idx];
+    cd hq = q, hw = w, hp = p;
+    double wt = 2.0;
+    if (k == 0 || k == N / 2) {
+      wt = 1.0;
+      const size_t im = (size_t)((N - l) % N) * pitch + k;
+      const cd qm = qh[im], wm = qwh ? qwh[im] : cmake(0, 0), pm = ph[im];
+      hq = cmake(0.5 * (q.x + qm.x), 0.5 * (q.y - qm.y));
+      hw = cmake(0.5 * (w.x + wm.x), 0.5 * (w.y - wm.y));
+      hp = cmake(0.5 * (p.x + pm.x), 0.5 * (p.y - pm.y));
+    }
+    const double kx = kk[k], ly = ll[l];
+    const double wv2 = kx * kx + ly * ly, wv4 = wv2 * wv2, wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
+    const double q2 = q.x * q.x + q.y * q.y;
+    v[0] += wt * (hq.x * hq.x + hq.y * hq.y);                     // sum |H q|^2            -> ens
+    v[1] += wt * wv4 * q2;                                        // sum wv4 |q|^2          -> chi_q
+    v[2] += wt * wv2i * q2;                                       // sum |q|^2 / wv2        -> ke_qg_q
+    v[3] += wt * wv2i * (w.x * w.x + w.y * w.y);                  // sum |qw|^2 / wv2       -> ke_qg_w
+    v[4] += wt * wv2i * (hq.x * hw.x + hq.y * hw.y);              // sum Re(conj q qw)/wv2  -> ke_qg_qw
+    v[5] += (l == 0 && k == 0) ? 0.0 : wt * wv2 * (p.x * p.x + p.y * p.y);   // -> ke_qg
+    const double pq = hp.x * hq.x + hp.y * hq.y;                  // Re(conj(psi) q)
+    v[6] += wt * wv4 * pq;                                        // -> mean(q lap2 psi)
+    v[7] += wt * wv2 * pq;                                        // -> -mean(psi lap q)
+    v[8] += wt * pq;                                              // -> mean(psi q)
+  }
+  diag_block_store<9>(v, part);
 }
 
 // budget bookkeeping ----------------------------------------------------------------------------
@@ -760,6 +832,35 @@ static void do_step(nq_ctx* c) {      // P == 1
 }
 
 // ---------------------------------------------------------------------------------------------
+// diagnostics tick launches
+template <int S>
+static void launch_project_s(nq_ctx* c, double* part) {
+  typedef YPlan<S> Y;
+  hipLaunchKernelGGL((k_s_project<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mW,
+                     (const cd*)c->w.y[c->w.cur], geom_full(c), c->kk, c->ll, c->tw, 1, c->p.nu4w, c->p.nuw, c->p.muw, part);
+}
+static void launch_project(nq_ctx* c, double* part) {
+#define CALL_(s) launch_project_s<s>(c, part)
+  NQ_S1_SWITCH(c, CALL_)
+#undef CALL_
+}
+template <int MODE>
+static void launch_xdiag_m(nq_ctx* c, double qbar, double abar, double* part) {
+  switch (c->N) {
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_diag<n, MODE>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mQ, c->mQw, c->mPhi, c->twx, c->kk, qbar, abar, part); } break;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+  }
+}
+static int xdiag_blocks(const nq_ctx* c) {
+  switch (c->N) {
+#define CASE_(n, a, b) case n: return c->Nloc / XPlan<n>::C;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+  }
+  return 0;
+}
+
 extern "C" {
 
 const char* nq_last_error(const nq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
@@ -1498,6 +1599,69 @@ int nq_jacobian_psi_phi(nq_ctx* c, double* out_cplx) {
   HIPCHK(c, hipMemcpyAsync(out_cplx, c->scr_f0, sizeof(cd) * (size_t)c->N * c->N, hipMemcpyDeviceToHost, c->stream));
   return nq_sync(c);
 }
+// ---- diagnostics tick on the device (ref Diagnostics.py:41-58, Kernel.py:613-706, :718-868, CoupledModel.py:99-136) --
+int nq_diagnostics(nq_ctx* c, double* out) {
+  NQ_SINGLE_RANK(c, "nq_diagnostics");
+  if (!c || !out) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = c->N, NB = 1024;
+  const double M = (double)N * N;
+  const bool waves = c->kernel_family;
+  if (waves && !c->have_phi) NQ_FAIL(c, -4, "nq_diagnostics: set_phi has not been called");
+  const int nxb = xdiag_blocks(c), nww = (c->Wf / CL) * c->S2;
+  if (!c->diag_part) {
+    size_t need = (size_t)NB * 9;
+    if ((size_t)nxb * 8 > need) need = (size_t)nxb * 8;
+    if ((size_t)nww * 4 > need) need = (size_t)nww * 4;
+    ALLOC(c, c->diag_part, need);
+    ALLOC(c, c->diag_out, (size_t)32);
+  }
+  double* d = c->diag_out;
+  HIPCHK(c, hipMemsetAsync(d, 0, sizeof(double) * 32, c->stream));
+  const cd* qh = c->q.y[c->q.cur];
+  if (c->dual) {                                      // physical space sees the mean of the two copies
+    hipLaunchKernelGGL(k_avg_interior, dim3((c->Wh + 63) / 64, N), dim3(64), 0, c->stream, qh, (const cd*)c->q2.y[c->q2.cur], c->scr_f1, c->Wh, c->Ph, N);
+    qh = c->scr_f1;
+  }
+  const cd* phih = waves ? c->w.y[c->w.cur] : nullptr;
+  // spectral sums: [0,4) S0..S3, [4,6) phih[0,0], [6,15) the nine half-spectrum sums, [15] Re(qh - qwh)[0,0]
+  if (waves) {
+    hipLaunchKernelGGL(k_diag_phi, dim3(NB), dim3(256), 0, c->stream, phih, N, c->Wf, c->Wf, c->kf0, c->kk, c->ll, c->diag_part);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, NB, 4, 4, d);
+    HIPCHK(c, hipMemcpyAsync(d + 4, phih, sizeof(cd), hipMemcpyDeviceToDevice, c->stream));
+  }
+  hipLaunchKernelGGL(k_diag_q, dim3(NB), dim3(256), 0, c->stream, qh, (const cd*)(c->p.model == NQ_MODEL_COUPLED ? c->qwh : nullptr), (const cd*)c->ph, N, c->Wh, c->Ph, c->kk, c->ll, c->diag_part);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, NB, 9, 9, d + 6);
+  double h[32];
+  HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));
+  cd q00 = make_double2(0.0, 0.0), w00 = make_double2(0.0, 0.0);
+  HIPCHK(c, hipMemcpyAsync(&q00, qh, sizeof(cd), hipMemcpyDeviceToHost, c->stream));
+  if (c->p.model == NQ_MODEL_COUPLED) HIPCHK(c, hipMemcpyAsync(&w00, c->qwh, sizeof(cd), hipMemcpyDeviceToHost, c->stream));
+  {
+    const int rc = nq_sync(c);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < 15; ++i) out[i] = h[i];
+  for (int i = 15; i < 32; ++i) out[i] = 0.0;
+  const double qbar = (q00.x - w00.x) / M, abar = h[0] / (M * M);
+  out[15] = qbar;
+  if (!waves) return 0;
+  // physical-space statistics: [16,24)
+  if (c->p.model == NQ_MODEL_COUPLED) launch_xdiag_m<MODE_COUPLED>(c, qbar, abar, c->diag_part);
+  else launch_xdiag_m<MODE_UNCOUPLED>(c, qbar, abar, c->diag_part);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, nxb, 8, 8, d + 16);
+  // projections of F[u phix + v phiy] ([24,28)) and of i F[phi q_psi] ([28,32)) on lap_h and diss_h; u, v, q_psi are
+  // those of the last inversion, phix / phiy as last refreshed (UnCoupled: quirk Q1), like ref Kernel.py:680-700
+  for (int which = 0; which < 2; ++which) {
+    launch_products(c, which == 0 ? 1.0 : 0.0, which == 0 ? 0.0 : 1.0);
+    launch_A_m(c, false, {&c->mW});
+    launch_project(c, c->diag_part);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, nww, 4, 4, d + 24 + 4 * which);
+  }
+  HIPCHK(c, hipMemcpyAsync(out + 16, d + 16, sizeof(double) * 16, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+
 int nq_jacobian_phic_phi(nq_ctx* c, double* out_cplx) {
   // out: half-spectrum plane F[Re i(phix* phiy - phiy* phix)]
   NQ_SINGLE_RANK(c, "nq_jacobian_phic_phi");

@@ -455,6 +455,107 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   }   // row blocks
 }
 
+// ---- diagnostics tick: physical-space statistics (ref Kernel.py:613-623 conc, skew; :701 pi) ----------------
+// One row block: q, q_psi from the (q, qw) half-spectrum pair, phi from its mixed-space row; eight sums per
+// workgroup -> part[workgroup][8]:
+//   sum q^2, sum q_psi^2, sum q_psi^3, sum (q_psi - qbar)^2, sum ups^2, sum ups q_psi, sum q_psi Re phi, sum q_psi Im phi
+// with ups = |phi|^2 - abar (abar = mean |phi|^2 and qbar = mean q_psi come from the spectral sums: centring BEFORE
+// squaring, as the reference does, keeps std(ups) meaningful for nearly uniform waves).
+template <int N, int MODE>
+__global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
+k_x_diag(MArr Mq, MArr Mqw, MArr Mphi, const cd* __restrict__ tw, const double* __restrict__ kk, double qbar,
+         double abar, double* __restrict__ part) {
+  typedef XPlan<N> X;
+  typedef typename X::F F;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const size_t row = (size_t)blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd* twl = lds + F::LDS_ELEMS;
+  for (int i = threadIdx.x; i < F::TW_LDS_ELEMS; i += X::THREADS) twl[i] = tw[i];
+  typename F::TwLds twr;
+  twr.base = twl;
+  wg_barrier_all();
+  double* red = reinterpret_cast<double*>(nq_smem + X::LDS_BYTES - 512);
+  cd w[P];
+  HsRegs<P> h1;
+  hs_load<N, P, T, MODE == MODE_COUPLED>(h1, xrow(Mq, row), xrow(MODE == MODE_COUPLED ? Mqw : Mq, row), j);
+  NQ_PHASE_FENCE();
+  hs_pack<N, P, T, F, MODE == MODE_COUPLED>(w, h1, j, c, lds, kk, false, false);
+  NQ_PHASE_FENCE();
+  F::template run<true>(w, j, c, lds, twr);
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  double qpsi[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const double q = w[t].x;
+    qpsi[t] = (MODE == MODE_COUPLED) ? w[t].x - w[t].y : w[t].x;
+    const double qc = qpsi[t] - qbar;
+    s1[0] += q * q;
+    s1[1] += qpsi[t] * qpsi[t];
+    s1[2] += qpsi[t] * qpsi[t] * qpsi[t];
+    s1[3] += qc * qc;
+  }
+  {
+    const XRow rp = xrow(Mphi, row);
+#pragma unroll
+    for (int t = 0; t < P; ++t) w[t] = *rp.at(j + t * T);
+  }
+  NQ_PHASE_FENCE();
+  F::template run<true>(w, j, c, lds, twr);
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const double ups = w[t].x * w[t].x + w[t].y * w[t].y - abar;
+    s2[0] += ups * ups;
+    s2[1] += ups * qpsi[t];
+    s2[2] += qpsi[t] * w[t].x;
+    s2[3] += qpsi[t] * w[t].y;
+  }
+  NQ_PHASE_FENCE();
+  block_sum_store<4>(s1, red, part + 8 * (size_t)blockIdx.x);
+  block_sum_store<4>(s2, red, part + 8 * (size_t)blockIdx.x + 4);
+}
+
+// ---- diagnostics tick: projections of one transformed mixed-space plane on lap_h and diss_h ------------
+// a = B-fft of Hw (Hw already went through the A sub-pass).  part[workgroup][4] =
+//   sum Re(conj(lap_h) a), sum Im(conj(lap_h) a), sum Re(conj(diss_h) a), sum Im(conj(diss_h) a)
+// with lap_h = -wv2 phih, diss_h = -(nu4w wv4 + nuw wv2 + muw) phih: gamma1, gamma2, xi1, xi2 of ref Kernel.py:691-700.
+template <int S1>
+__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+k_s_project(MArr Hw, const cd* __restrict__ phih, YGeom g, const double* __restrict__ kk, const double* __restrict__ ll,
+            const cd* __restrict__ tw, int tw_step_N, double nu4w, double nuw, double muw, double* __restrict__ part) {
+  typedef YPlan<S1> Y;
+  constexpr int P = Y::P, T = Y::T;
+  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
+  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int kg = g.k0 + k, S2 = g.S2;
+  const int N = S1 * S2;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename Y::F::Tw twr;
+  Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
+  double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
+  cd a[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) a[t] = Hw.ys[(size_t)(l1 * S1 + j + t * T) * Hw.pitch + k];
+  Y::F::template run<false>(a, j, c, lds, twr);
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  const double kx = kk[kg];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int l = l1 + S2 * (j + t * T);
+    const cd ys = phih[(size_t)l * g.pitch_s + k];
+    const double ly = ll[l];
+    const double wv2 = kx * kx + ly * ly;
+    const double d = nu4w * wv2 * wv2 + nuw * wv2 + muw;
+    const double re = ys.x * a[t].x + ys.y * a[t].y, im = ys.x * a[t].y - ys.y * a[t].x;   // conj(ys) * a
+    s[0] += -wv2 * re;
+    s[1] += -wv2 * im;
+    s[2] += -d * re;
+    s[3] += -d * im;
+  }
+  block_sum_store<4>(s, red, part + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+}
+
 // ---- ETDRK4 stage update of one spectral element -----------------------------------------------
 // ref Kernel.py:327,:347,:364,:381-382 (q) and :333,:351,:368,:386-387 (phi).  The filter is folded
 // into the coefficient planes (Ef = E*filtr ...), which is the same arithmetic up to rounding.

@@ -412,3 +412,33 @@ def test_full_size_parity_through_resolution_independence(nx):
     band = np.zeros(nx, bool)
     band[np.r_[0:65, nx - 64:nx]] = True
     assert qh[~band][:, ~band].max() < 1e-13 * qh.max()
+
+
+@pytest.mark.parametrize("kind", ["coupled", "uncoupled"])
+@pytest.mark.parametrize("use_filter", [True, False])
+def test_device_diagnostics_tick_against_oracle(kind, use_filter):
+    """increment_diagnostics (ref Diagnostics.py:41-58) evaluated from the 32 device sums of nq_diagnostics: every
+    registered scalar, every tick, against the reference-pinned oracle; all dissipation parameters non-zero so that
+    no term drops out; UnCoupled exercises the stale phix/phiy of quirk Q1 inside gamma_a / xi_r."""
+    nx = 64
+    kw = notebook_kwargs(nx, use_filter, tdiags=1)
+    kw.update(nu4w=3e9, muw=1e-7, mu=2e-8)
+    o = O.NIWQGOracle(kind, **kw)
+    m = getattr(models(), "CoupledModel" if kind == "coupled" else "UnCoupledModel").Model(**kw)
+    q0 = O.lamb_dipole(o.grid, U=U0, R=2 * np.pi / K0)
+    phi0 = 0.2 * O.wave_packet(o.grid, k=2 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2) + 0.05
+    for x in (o, m):
+        x.set_q(q0)
+        x.set_phi(phi0)
+    for _ in range(8):
+        o._step_forward()
+    steps(m, 8)
+    names = list(o.diagnostics)
+    assert set(names) <= set(m.diagnostics)
+    loose = {"ep_psi": 1e-7, "conc_niw": 1e-8}
+    absolute = {"skew": 1e-12, "conc_niw": 1e-10}      # O(1) normalised moments: zero by symmetry for the dipole
+    for name in names:
+        got, ref = np.asarray(m.diagnostics[name]['value']), o.diag(name)
+        assert got.shape == ref.shape, name
+        assert np.allclose(got, ref, rtol=loose.get(name, 1e-9), atol=absolute.get(name, 1e-30)), (name, got, ref)
+    assert rel(m.phi, o.phi) < 1e-12 and rel(m.q, o.q) < 1e-12          # the tick left the state alone

@@ -18,3 +18,10 @@ for name, cls in sorted(ctx.KERNEL_CLASSES.items(), key=lambda kv: kv[1]):
     print("%-12s %4d launches/step  %8.1f us/launch  %7.3f ms/step" % (name, n // steps, 1e3 * ms / max(n, 1), ms / steps))
     tot += ms / steps
 print("sum %.3f ms/step" % tot)
+import time
+ctx.sync()
+ctx.diagnostic_sums()
+t0 = time.perf_counter()
+for _ in range(5):
+    ctx.diagnostic_sums()
+print("diagnostics tick (nq_diagnostics, 32 sums, blocking): %.3f ms" % ((time.perf_counter() - t0) / 5 * 1e3))

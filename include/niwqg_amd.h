@@ -22,7 +22,8 @@ extern "C" {
 
 typedef struct nq_ctx nq_ctx;
 
-enum { NQ_MODEL_COUPLED = 0, NQ_MODEL_UNCOUPLED = 1, NQ_MODEL_QG = 2 };
+enum { NQ_MODEL_COUPLED = 0, NQ_MODEL_UNCOUPLED = 1, NQ_MODEL_QG = 2,
+       NQ_MODEL_YBJ = 3 /* niwqg/YBJModel.py: steady psi, nq_step advances phi only (YBJModel.py:52-87); single rank */ };
 
 /* field ids for nq_get_field */
 enum {

@@ -349,7 +349,7 @@ class Kernel(object):
 
     def _grad2(self, s):
         """mean(|phix|^2 + |phiy|^2) of phix, phiy AS LAST REFRESHED (UnCoupled keeps stale ones: quirk Q1)"""
-        if self.model_id == _lib.UNCOUPLED and hasattr(self, "_grad2_mean"):
+        if self.model_id in (_lib.UNCOUPLED, _lib.YBJ) and hasattr(self, "_grad2_mean"):
             return self._grad2_mean
         return s[1] / self._M2
 

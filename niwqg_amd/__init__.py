@@ -15,3 +15,4 @@ from . import Kernel   # noqa: F401
 from . import CoupledModel   # noqa: F401
 from . import UnCoupledModel   # noqa: F401
 from . import QGModel   # noqa: F401
+from . import YBJModel   # noqa: F401

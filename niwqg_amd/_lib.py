@@ -20,7 +20,7 @@ SRC = os.path.join(HERE, "csrc", "nq_lib.hip")
 HEADERS = [os.path.join(HERE, "csrc", h) for h in ("nq_fft.hpp", "nq_generic.hpp", "nq_step.hpp")] + [
     os.path.join(os.path.dirname(HERE), "include", "niwqg_amd.h")]
 
-COUPLED, UNCOUPLED, QG = 0, 1, 2
+COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
 (F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY, F_QH_MINUS) = range(14)
 (S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL) = range(7)
 

@@ -98,6 +98,7 @@ struct nq_ctx {
   std::vector<hipEvent_t> prof_ev;               // pairs
   size_t prof_used = 0;
   bool have_q = false, have_phi = false;
+  bool ybj = false;      // niwqg.YBJModel: UnCoupled layouts, only phi is stepped (stage graph in do_step_ybj)
 };
 
 template <typename Tp>
@@ -612,10 +613,10 @@ static void launch_wavepv(nq_ctx* c) {
   }
 }
 template <int MODE>
-static void launch_products_m(nq_ctx* c, double cj, double cr) {
+static void launch_products_m(nq_ctx* c, double cj, double cr, bool fresh_grad) {
   const int vz = c->kernel_family ? 1 : 0;
-  const MArr& gx = (MODE == MODE_UNCOUPLED) ? c->mGx : c->mPhi;
-  const MArr& gy = (MODE == MODE_UNCOUPLED) ? c->mGy : c->mPhiy;
+  const MArr& gx = (MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGx : c->mPhi;
+  const MArr& gy = (MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGy : c->mPhiy;
   switch (c->N) {
 #define CASE_(n, a, b) case n: { typedef XPlan<n> X; const int nb = c->Nloc / X::C; \
     /* one workgroup fits per CU (LDS) and does not spill: persistent; 8192-point rows spill and do better with dynamic dispatch */ \
@@ -626,11 +627,12 @@ static void launch_products_m(nq_ctx* c, double cj, double cr) {
   }
 }
 // Mw <- cj * (u phix + v phiy) + i cr * phi q_psi; a step uses the phi tendency itself: cj = -1, cr = -1/2
-static void launch_products(nq_ctx* c, double cj = -1.0, double cr = -0.5) {
+// fresh_grad (UnCoupled layouts only): phix, phiy from the rows of Mphi, Mphiy instead of the frozen copy
+static void launch_products(nq_ctx* c, double cj = -1.0, double cr = -0.5, bool fresh_grad = false) {
   ProfScope ps(c, PK_PRODUCTS);
-  if (c->p.model == NQ_MODEL_COUPLED) launch_products_m<MODE_COUPLED>(c, cj, cr);
-  else if (c->p.model == NQ_MODEL_UNCOUPLED) launch_products_m<MODE_UNCOUPLED>(c, cj, cr);
-  else launch_products_m<MODE_QG>(c, cj, cr);
+  if (c->p.model == NQ_MODEL_COUPLED) launch_products_m<MODE_COUPLED>(c, cj, cr, false);
+  else if (c->p.model == NQ_MODEL_UNCOUPLED) launch_products_m<MODE_UNCOUPLED>(c, cj, cr, fresh_grad);
+  else launch_products_m<MODE_QG>(c, cj, cr, false);
 }
 
 static EtdArrays etd_arrays(EqState& e, int stage, int* out_slot) {
@@ -686,10 +688,11 @@ static BudgetW budget_w(nq_ctx* c, double* part, const cd* y_start) {
   return bw;
 }
 template <int S>
-static void launch_sphi_s(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_start) {
+static void launch_sphi_s(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_start, const MArr& ophi, const MArr& ophiy) {
   typedef YPlan<S> Y;
   BudgetW bw = budget_w(c, c->partW + (size_t)stage * c->nww * NQ_PARTW, y_start);
-  hipLaunchKernelGGL((k_s_phi<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mW, c->mUq.ys + c->mUq.W, c->mUq.pitch, ea, stage, geom_full(c), c->mPhi, c->mPhiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
+  const cd* jpass = c->ybj ? nullptr : c->mUq.ys + c->mUq.W;     // YBJModel.jacobian_psi_phi keeps [0,0] (YBJModel.py:123-133)
+  hipLaunchKernelGGL((k_s_phi<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mW, jpass, c->mUq.pitch, ea, stage, geom_full(c), ophi, ophiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
 template <int S>
 static void launch_emit_phi_s(nq_ctx* c, const cd* phih) {
@@ -723,9 +726,12 @@ static void launch_sq(nq_ctx* c, const EtdArrays& ea, int stage) {
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
-static void launch_sphi(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_start) {
+static void launch_sphi(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_start, const MArr* ophi = nullptr,
+                        const MArr* ophiy = nullptr) {
   ProfScope ps(c, PK_SPHI);
-#define CALL_(s) launch_sphi_s<s>(c, ea, stage, y_start)
+  const MArr& o1 = ophi ? *ophi : c->mPhi;
+  const MArr& o2 = ophiy ? *ophiy : c->mPhiy;
+#define CALL_(s) launch_sphi_s<s>(c, ea, stage, y_start, o1, o2)
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
@@ -818,7 +824,32 @@ static void do_invert_now(nq_ctx* c) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0Q, c->nwq, 3, 3, c->carryQ);
 }
 
+// niwqg.YBJModel._step_etdrk4 (YBJModel.py:52-87): psi, u, v, q are steady; phix, phiy are refreshed from the current
+// phih before every stage, but the refraction factor phi only after the step.  Two G1-shaped buffers do it without a
+// copy: A = G[1] holds phi, phiy of the start-of-step state (products read phi from it in all four stages, and the
+// gradients in stage 0); B = Gs receives the stage results 0..2 and feeds the gradients of stages 1..3; the final
+// state goes back to A, so B is left with the gradients of the stage-2 result -- exactly the stale phix, phiy the
+// reference leaves behind (they matter to the next diagnostics tick only).
+static void do_step_ybj(nq_ctx* c) {
+  for (int s = 0; s < 4; ++s) {
+    launch_products(c, -1.0, -0.5, s == 0);
+    launch_A_m(c, false, {&c->mW});
+    int wslot = 0;
+    const int cur = c->w.cur;
+    const cd* y_start = (s == 0) ? c->w.y[cur] : (s == 1 ? c->w.y[(cur + 1) % 3] : c->w.y[(cur + 2) % 3]);
+    EtdArrays ew = etd_arrays(c->w, s, &wslot);
+    if (s < 3) {
+      launch_sphi(c, ew, s, y_start, &c->mGx, &c->mGy);
+      launch_A_m(c, true, {&c->mGx, &c->mGy});
+    } else {
+      launch_sphi(c, ew, s, y_start);
+      launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
+    }
+  }
+}
+
 static void do_step(nq_ctx* c) {      // P == 1
+  if (c->ybj) return do_step_ybj(c);
   for (int s = 0; s < 4; ++s) {
     phase_products(c, s);
     phase_update(c, s);
@@ -928,10 +959,19 @@ static MArr make_marr(const SlabGeom& g, cd* bx, cd* by, int group, int idx, boo
   return m;
 }
 
-static int create_impl(const nq_params* p, const double* kk, const double* ll, const double* filtr,
+static int create_impl(const nq_params* p_in, const double* kk, const double* ll, const double* filtr,
                        const double* contour, int device, int P, int rank, void* const* ext, void* ext_stream,
                        nq_ctx** out) {
-  if (!p || !kk || !ll || !filtr || !contour || !out) NQ_FAIL((nq_ctx*)nullptr, -1, "nq_create: null argument");
+  if (!p_in || !kk || !ll || !filtr || !contour || !out) NQ_FAIL((nq_ctx*)nullptr, -1, "nq_create: null argument");
+  // YBJModel = UnCoupled layouts and kernels with its own stage graph; its step accumulates no budgets
+  nq_params pp = *p_in;
+  const bool ybj = pp.model == NQ_MODEL_YBJ;
+  if (ybj) {
+    if (P != 1) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create_slab: YBJModel is single-rank only");
+    pp.model = NQ_MODEL_UNCOUPLED;
+    pp.budgets = 0;
+  }
+  const nq_params* p = &pp;
   int S1, S2;
   if (!plan_for(p->nx, &S1, &S2)) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d unsupported (power of two in [64, 8192])", p->nx);
   if (p->model < 0 || p->model > 2) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: unknown model %d", p->model);
@@ -945,6 +985,7 @@ static int create_impl(const nq_params* p, const double* kk, const double* ll, c
   nq_ctx* c = new nq_ctx();
   const SlabGeom sg = slab_geom(p, P);
   c->p = *p;
+  c->ybj = ybj;
   c->N = p->nx;
   c->S1 = S1;
   c->S2 = S2;
@@ -1326,6 +1367,7 @@ int nq_download_spectral(nq_ctx* c, int which, double* host) {
 //   NQ_PH_BUDGET_FINISH    RK-weighted accumulation from the (reduced) sums
 int nq_phase(nq_ctx* c, int phase, int stage) {
   if (!c) return -1;
+  if (c->ybj) NQ_FAIL(c, -4, "nq_phase: YBJModel is single-rank only");
   if (stage < 0 || stage > 3) NQ_FAIL(c, -1, "nq_phase: stage %d", stage);
   HIPCHK(c, hipSetDevice(c->device));
   switch (phase) {

@@ -741,7 +741,7 @@ k_s_phi(MArr Hw, const cd* __restrict__ jpass, int jpitch, EtdArrays ea, int sta
   for (int t = 0; t < P; ++t) a[t] = Hw.ys[(size_t)(l1 * S1 + j + t * T) * Hw.pitch + k];
   // [0,0]: the Jacobian part of the tendency is zeroed there (ref Kernel.py:468) -- add its domain sum back
   double jfix[2] = {0.0, 0.0};
-  if (g.k0 == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (jpass != nullptr && g.k0 == 0 && blockIdx.x == 0 && blockIdx.y == 0) {   // jpass == null: YBJModel keeps [0,0]
     for (int yy = threadIdx.x; yy < N; yy += Y::THREADS) {
       const cd z = jpass[(size_t)yy * jpitch];
       jfix[0] += z.x;

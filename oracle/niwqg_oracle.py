@@ -145,15 +145,15 @@ def wave_packet(g: SpectralGrid, k=10, l=0, R=1.0, x0=0.0, y0=0.0) -> np.ndarray
 class NIWQGOracle:
     """Restatement of ``niwqg.Kernel.Kernel`` + ``CoupledModel`` / ``UnCoupledModel``.
 
-    ``kind`` is "coupled" or "uncoupled".  Attribute names follow the reference so
-    that parity tests read like the reference's own tests.
+    ``kind`` is "coupled", "uncoupled" or "ybj" (``niwqg.YBJModel``: steady psi, only phi is stepped).
+    Attribute names follow the reference so that parity tests read like the reference's own tests.
     """
 
     def __init__(self, kind="coupled", nx=128, ny=None, L=5e5, dt=10000.0, twrite=1000.0,
                  tmax=250000.0, use_filter=True, cflmax=0.8, U=0.0, f=1e-4, N=0.01,
                  m=0.025, g=9.81, nu4=0, nu4w=0, nu=20, nuw=50.0, mu=0, muw=0,
                  dealias=False, tdiags=10, coeff_chunk=64):
-        assert kind in ("coupled", "uncoupled")
+        assert kind in ("coupled", "uncoupled", "ybj")
         self.kind = kind
         # ref: niwqg/Kernel.py:100-137 (parameter bookkeeping; ny ignored)
         self.nx = self.ny = nx
@@ -227,6 +227,9 @@ class NIWQGOracle:
             self.p = self.pv + self.pw
             self.ph = self.fft(self.p)
             self.q = self.ifft(self.qh).real
+        elif self.kind == "ybj":
+            # ref: niwqg/YBJModel.py:141-146 (purely spectral; p and q are left alone)
+            self.ph = -self.wv2i * self.qh
         else:
             # ref: niwqg/UnCoupledModel.py:54-64  (phix/phiy NOT refreshed: quirk Q1)
             self.p = self.ifft(-(self.wv2i * self.qh)).real
@@ -254,7 +257,8 @@ class NIWQGOracle:
     def jacobian_psi_phi(self):
         """ref: niwqg/Kernel.py:457-469."""
         jh = self.fft(self.u * self.phix + self.v * self.phiy)
-        jh[0, 0] = 0
+        if self.kind != "ybj":          # niwqg/YBJModel.py:123-133 does NOT zero [0,0]
+            jh[0, 0] = 0
         return jh
 
     # ---- initial state (ref: niwqg/Kernel.py:520-551) -------------------------
@@ -352,7 +356,36 @@ class NIWQGOracle:
         self._invert()
         self._calc_rel_vorticity()
 
+    def _step_etdrk4_ybj(self):
+        """ref: niwqg/YBJModel.py:52-87.  Only phi is stepped; phix/phiy are refreshed from the current phih before
+        every stage but ``self.phi`` (the refraction factor) only after the step, and u, v, q_psi stay those of
+        set_q (or of the last diagnostics tick, which recomputes the same values); no budget accumulation."""
+        cw, F = self.coef_w, self.filtr
+
+        def grad():
+            self.phix, self.phiy = self.ifft(self.ik * self.phih), self.ifft(self.il * self.phih)
+
+        self.phih0 = self.phih.copy()
+        grad()
+        N0w = self._nonlinear_w()
+        self.phih = (cw["Eh"] * self.phih0 + N0w * cw["Q"]) * F
+        self.phih1 = self.phih.copy()
+        grad()
+        Naw = self._nonlinear_w()
+        self.phih = (cw["Eh"] * self.phih0 + Naw * cw["Q"]) * F
+        grad()
+        Nbw = self._nonlinear_w()
+        self.phih = (cw["Eh"] * self.phih1 + (2.0 * Nbw - N0w) * cw["Q"]) * F
+        self._calc_rel_vorticity()
+        grad()
+        Ncw = self._nonlinear_w()
+        self.phih = (cw["E"] * self.phih0 + N0w * cw["f0"] + 2.0 * (Naw + Nbw) * cw["fab"]
+                     + Ncw * cw["fc"]) * F
+        self.phi = self.ifft(self.phih)
+
     def _step_etdrk4(self):
+        if self.kind == "ybj":
+            return self._step_etdrk4_ybj()
         cq, cw, F = self.coef_q, self.coef_w, self.filtr
         rates = []
         # stage 1 (ref :319-339)

@@ -17,6 +17,7 @@ Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
   g4_quirks_64.npz        UnCoupledModel tdiags dependence (Q1), set order (Q2)
   g6_notebook_diags.npz   diagnostics time series of the 128^2 notebook run (400 steps)
   g7_checksums.npz        scalar checksums at 256^2 / 512^2
+  g8_ybj_64.npz           YBJModel (steady psi): trajectory, diagnostics series, stale phix/phiy
 """
 import os
 import sys
@@ -28,7 +29,7 @@ import numpy as np
 sys.modules.setdefault("h5py", types.ModuleType("h5py"))
 sys.path.insert(0, "/root/reference")
 
-from niwqg import CoupledModel, UnCoupledModel, QGModel      # noqa: E402
+from niwqg import CoupledModel, UnCoupledModel, QGModel, YBJModel      # noqa: E402
 from niwqg import InitialConditions as ic                    # noqa: E402
 
 logging.getLogger("niwqg.Kernel").setLevel(logging.ERROR)
@@ -218,6 +219,34 @@ def g6():
 
 
 # ---------------------------------------------------------------- G7
+def g8():
+    """YBJModel 64^2 (niwqg/YBJModel.py): dipole + wave packet on a uniform wave, 20 steps, tdiags=1 and tdiags=inf."""
+    nx, nsteps = 64, 20
+    out = {}
+    for tag, td in (("td1", 1), ("tdinf", 10 ** 9)):
+        for use_filter in (True, False):
+            kw = notebook_kwargs(nx, use_filter, nsteps, tdiags=td)
+            kw.update(nu4w=3e9, muw=1e-7)
+            m = YBJModel.Model(**kw)
+            q0 = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+            phi0 = 0.2 * ic.WavePacket(m, k=2 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2) + 0.05
+            m.set_q(q0)
+            m.set_phi(phi0)
+            m.run()
+            assert m.tc == nsteps
+            key = "%s_%s" % (tag, "filter" if use_filter else "nofilter")
+            out["phi_" + key] = m.phi
+            out["phih_" + key] = m.phih
+            out["phix_" + key] = m.phix
+            out["phiy_" + key] = m.phiy
+            out["scalars_" + key] = np.array([m.Ke, m.Pw, m.Kw, m._calc_ke_niw(), m._calc_ke_qg()])
+            if td == 1:
+                for name, d in m.diagnostics.items():
+                    out["diag_%s_%s" % (name, key)] = np.asarray(d["value"], dtype=float)
+            out["q0"], out["phi0"] = q0, phi0
+    save("g8_ybj_64.npz", **out)
+
+
 def g7():
     out = {}
     for nx in (256, 512):
@@ -233,6 +262,6 @@ def g7():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8"]
     for w in which:
         globals()[w]()

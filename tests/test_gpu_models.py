@@ -442,3 +442,28 @@ def test_device_diagnostics_tick_against_oracle(kind, use_filter):
         assert got.shape == ref.shape, name
         assert np.allclose(got, ref, rtol=loose.get(name, 1e-9), atol=absolute.get(name, 1e-30)), (name, got, ref)
     assert rel(m.phi, o.phi) < 1e-12 and rel(m.q, o.q) < 1e-12          # the tick left the state alone
+
+
+@pytest.mark.parametrize("td_tag,td", [("td1", 1), ("tdinf", 10 ** 9)])
+@pytest.mark.parametrize("use_filter", [True, False])
+def test_ybj_model_against_the_reference(golden, td_tag, td, use_filter):
+    """niwqg.YBJModel through the reference itself (golden g8): trajectory, the stale phix/phiy a step leaves behind,
+    untouched budget accumulators, and every diagnostics series with tdiags=1 (device tick)."""
+    g = golden("g8_ybj_64.npz")
+    key = "%s_%s" % (td_tag, "filter" if use_filter else "nofilter")
+    kw = notebook_kwargs(64, use_filter, tdiags=td)
+    kw.update(nu4w=3e9, muw=1e-7)
+    m = models().YBJModel.Model(**kw)
+    m.set_q(g["q0"])
+    m.set_phi(g["phi0"])
+    m.tmax = 19.5 * m.dt
+    m.run()
+    assert m.tc == 20
+    assert rel(m.phi, g["phi_" + key]) < 1e-12 and rel(m.phih, g["phih_" + key]) < 1e-12
+    assert rel(m.phix, g["phix_" + key]) < 1e-12 and rel(m.phiy, g["phiy_" + key]) < 1e-12
+    assert np.allclose([m.Ke, m.Pw, m.Kw, m._calc_ke_niw(), m._calc_ke_qg()], g["scalars_" + key], rtol=1e-11)
+    if td == 1:
+        for name in m.diagnostics:
+            ref = g["diag_%s_%s" % (name, key)]
+            got = np.asarray(m.diagnostics[name]['value'])
+            assert np.allclose(got, ref, rtol=1e-8, atol=1e-12 if name in ("skew", "conc_niw") else 1e-30), name

@@ -193,3 +193,25 @@ def test_checksums_256_512(golden):
     ok = np.isclose(c, ref, rtol=1e-10, atol=1e-24)
     ok[2] = abs(c[2] - ref[2]) < 1e-20          # mean(q) is roundoff around zero
     assert ok.all(), (c, ref)
+
+
+def test_ybj_oracle_matches_reference(golden):
+    """niwqg/YBJModel.py through the reference itself (g8): trajectory, the stale phix/phiy left by stage 4, the
+    (untouched) budget accumulators and every diagnostics series with tdiags=1."""
+    g = golden("g8_ybj_64.npz")
+    for td_tag, td in (("td1", 1), ("tdinf", 10 ** 9)):
+        for use_filter in (True, False):
+            key = "%s_%s" % (td_tag, "filter" if use_filter else "nofilter")
+            kw = notebook_kwargs(64, use_filter, tdiags=td)
+            kw.update(nu4w=3e9, muw=1e-7)
+            o = O.NIWQGOracle("ybj", **kw)
+            o.set_q(g["q0"])
+            o.set_phi(g["phi0"])
+            steps(o, 20)
+            assert rel(o.phi, g["phi_" + key]) < 1e-13 and rel(o.phih, g["phih_" + key]) < 1e-13
+            assert rel(o.phix, g["phix_" + key]) < 1e-13 and rel(o.phiy, g["phiy_" + key]) < 1e-13
+            assert np.allclose([o.Ke, o.Pw, o.Kw, o._calc_ke_niw(), o._calc_ke_qg()], g["scalars_" + key], rtol=1e-12)
+            if td == 1:
+                for name in o.diagnostics:
+                    ref = g["diag_%s_%s" % (name, key)]
+                    assert np.allclose(o.diag(name), ref, rtol=1e-9, atol=1e-13 if name in ("skew", "conc_niw") else 1e-30), name

@@ -18,6 +18,7 @@ Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
   g6_notebook_diags.npz   diagnostics time series of the 128^2 notebook run (400 steps)
   g7_checksums.npz        scalar checksums at 256^2 / 512^2
   g8_ybj_64.npz           YBJModel (steady psi): trajectory, diagnostics series, stale phix/phiy
+  g9_initial_conditions_64.npz   all five generators of niwqg/InitialConditions.py (seeded)
 """
 import os
 import sys
@@ -261,7 +262,21 @@ def g7():
     save("g7_checksums.npz", **out)
 
 
+def g9():
+    """niwqg/InitialConditions.py on a 64^2 CoupledModel grid; numpy's global RNG seeded before each random field."""
+    m = CoupledModel.Model(**notebook_kwargs(64, True, 1))
+    out = {}
+    np.random.seed(11)
+    out["mcwilliams"] = ic.McWilliams1984(m, k0=6 * 2 * np.pi / L, E=0.5 * U0 ** 2)
+    np.random.seed(12)
+    out["danioux"] = ic.Danioux2015(m, k0=8 * 2 * np.pi / L, E=0.5 * U0 ** 2)
+    out["lamb"] = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+    out["packet"] = ic.WavePacket(m, k=3 * K0, l=K0, R=L / 6, x0=L / 3, y0=L / 2)
+    out["plane"] = ic.PlaneWave(m, k=3 * K0, l=2 * K0, phase=0.3)
+    save("g9_initial_conditions_64.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

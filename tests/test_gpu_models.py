@@ -467,3 +467,18 @@ def test_ybj_model_against_the_reference(golden, td_tag, td, use_filter):
             ref = g["diag_%s_%s" % (name, key)]
             got = np.asarray(m.diagnostics[name]['value'])
             assert np.allclose(got, ref, rtol=1e-8, atol=1e-12 if name in ("skew", "conc_niw") else 1e-30), name
+
+
+def test_initial_condition_generators_against_the_reference(golden):
+    """niwqg/InitialConditions.py:4-169 (golden g9, produced by the reference with the same seeds); the two random
+    fields go through the device FFT seam (model.fft / model.ifft)."""
+    from niwqg_amd import InitialConditions as ic
+    g = golden("g9_initial_conditions_64.npz")
+    m = models().CoupledModel.Model(**notebook_kwargs(64, True))
+    np.random.seed(11)
+    assert rel(ic.McWilliams1984(m, k0=6 * 2 * np.pi / L, E=0.5 * U0 ** 2), g["mcwilliams"]) < 1e-13
+    np.random.seed(12)
+    assert rel(ic.Danioux2015(m, k0=8 * 2 * np.pi / L, E=0.5 * U0 ** 2), g["danioux"]) < 1e-13
+    assert np.array_equal(ic.LambDipole(m, U=U0, R=2 * np.pi / K0), g["lamb"])
+    assert rel(ic.WavePacket(m, k=3 * K0, l=K0, R=L / 6, x0=L / 3, y0=L / 2), g["packet"]) < 1e-15
+    assert rel(ic.PlaneWave(m, k=3 * K0, l=2 * K0, phase=0.3), g["plane"]) < 1e-15

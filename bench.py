@@ -162,6 +162,38 @@ def cpu_baseline(model, nx_target, budget_s=20.0):
             "measured_steps_per_s_at_sample": sps, "sample_nx": nx, "host_cores_available": os.cpu_count()}
 
 
+def bench_ensemble(args, grp, rank, world, local_rank):
+    """BASELINE config 5: members sharded over the ranks, every member its own context and stream."""
+    import torch
+    from niwqg_amd import ensemble
+    from niwqg_amd.distributed import aggregate_throughput
+    nx = 1024 if args.nx == 4096 else args.nx
+    ens = ensemble.Ensemble(lambda j: ensemble.config5_member(j, nx=nx, device=local_rank), args.members * world, rank, world)
+    ens.step(args.warmup)
+    grp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ens.step(args.steps)
+    grp.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    sps, wall = aggregate_throughput(grp, args.steps * len(ens.members), wall)
+    if rank == 0:
+        npts = float(nx) ** 2
+        print(json.dumps({
+            "metric": "member-steps/sec, ensemble of independent UnCoupledModel %d^2 members (BASELINE config 5)" % nx,
+            "value": sps, "unit": "member-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d x UnCoupledModel %d^2 fp64, %d members per GPU, ETDRK4, filter on, budgets on"
+                                   % (args.members * world, nx, args.members),
+                       "parallelism": "members sharded over ranks, one HIP stream per member, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "whole step", "achieved": CANONICAL_B_PER_PT_STEP["uncoupled"] * npts * sps / 1e9,
+                         "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": CANONICAL_B_PER_PT_STEP["uncoupled"] * npts * sps / 1e9 / (HBM_PEAK_GBS * world), "traffic": None}}))
+    grp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +203,8 @@ def main():
     ap.add_argument("--model", default="coupled", choices=["coupled", "uncoupled", "qg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-slab", action="store_true", help="use the slab path (and its collectives) even with one rank")
+    ap.add_argument("--members", type=int, default=0, help="BASELINE config 5 instead of the headline: this many "
+                    "independent UnCoupledModel 1024^2 members PER GPU (8 in the config), no collective")
     ap.add_argument("--replicas", action="store_true", help="with --gpus N > 1: N independent replicas instead of one "
                                                             "slab-decomposed simulation")
     args = ap.parse_args()
@@ -180,6 +214,9 @@ def main():
     grp = Group(force=args.force_slab)   # nccl (= RCCL) when launched with WORLD_SIZE > 1
     rank, world, local_rank = grp.rank, grp.world, grp.local_rank
     torch.cuda.set_device(local_rank)
+
+    if args.members > 0:
+        return bench_ensemble(args, grp, rank, world, local_rank)
 
     mode = "single GPU"
     slab_error = None

@@ -482,3 +482,20 @@ def test_initial_condition_generators_against_the_reference(golden):
     assert np.array_equal(ic.LambDipole(m, U=U0, R=2 * np.pi / K0), g["lamb"])
     assert rel(ic.WavePacket(m, k=3 * K0, l=K0, R=L / 6, x0=L / 3, y0=L / 2), g["packet"]) < 1e-15
     assert rel(ic.PlaneWave(m, k=3 * K0, l=2 * K0, phase=0.3), g["plane"]) < 1e-15
+
+
+def test_ensemble_members_equal_individually_stepped_models():
+    """BASELINE config 5 runner: members queued on separate streams give exactly what each gives on its own, and the
+    member ids are sharded over ranks without overlap."""
+    from niwqg_amd import ensemble
+    ens = ensemble.Ensemble(lambda j: ensemble.config5_member(j, nx=128), 5, rank=1, world=2)
+    assert ens.ids == [3, 4]
+    assert ensemble.Ensemble(lambda j: j, 5, rank=0, world=2).ids == [0, 1, 2]
+    ens.step(6)
+    for j, m in zip(ens.ids, ens.members):
+        solo = ensemble.config5_member(j, nx=128)
+        steps(solo, 6)
+        assert m.tc == 6 and m.t == solo.t
+        assert np.array_equal(m.phi, solo.phi) and np.array_equal(m.q, solo.q)
+        assert np.allclose([m.Ke, m.Pw, m.Kw], [solo.Ke, solo.Pw, solo.Kw], rtol=1e-14)   # batched increments: last bit
+    assert ens.member_steps() == 12

@@ -501,14 +501,14 @@ class NIWQGOracle:
 # barotropic QG model on the half spectrum (rfft2)
 # --------------------------------------------------------------------------
 class QGOracle:
-    """Restatement of ``niwqg.QGModel.Model`` with ``passive_scalar=False``.
+    """Restatement of ``niwqg.QGModel.Model``, with or without its passive scalar.
 
-    ref: niwqg/QGModel.py:65-140 (constructor), :328-407 (step), :469-505.
+    ref: niwqg/QGModel.py:65-140 (constructor), :328-407 (step), :469-505, :522-534 (set_c), :595-604, :724-737.
     """
 
     def __init__(self, nx=128, ny=None, L=5e5, dt=10000.0, twrite=1000, tmax=250000.0,
                  use_filter=True, U=0.0, nu4=5e9, nu=0, mu=0, beta=0, dealias=False,
-                 tdiags=10, coeff_chunk=64):
+                 tdiags=10, coeff_chunk=64, passive_scalar=False, nu4c=5e9, nuc=0, muc=0):
         self.nx = self.ny = nx
         self.L = self.W = L
         self.dt, self.twrite, self.tmax, self.tdiags = dt, twrite, tmax, tdiags
@@ -528,6 +528,12 @@ class QGOracle:
         c += -nu4 * self.wv4 - nu * self.wv2 - mu - 1j * self.k * U
         c += beta * self.ik * self.wv2i
         self.coef_q = etdrk4_tables(c, dt, coeff_chunk)
+        self.passive_scalar, self.nu4c, self.nuc, self.muc = passive_scalar, nu4c, nuc, muc
+        if passive_scalar:          # ref: niwqg/QGModel.py:446-466 (no mean-flow or beta term in this operator)
+            cc = np.zeros(self.qh.shape, complex)
+            cc += -nu4c * self.wv4 - nuc * self.wv2 - muc
+            self.coef_c = etdrk4_tables(cc, dt, coeff_chunk)
+        self.C2, self.gradC2, self.cvar, self.Gamma_c = 0.0, 0.0, 0.0, 0.0
         self.t = 0
         self.tc = 0
         self.cflmax = 0.5           # ref: niwqg/QGModel.py:135
@@ -553,6 +559,30 @@ class QGOracle:
         self.u, self.v = self.ifft(-self.il * self.ph), self.ifft(self.ik * self.ph)
         q = self.ifft(self.qh)
         return self.ik * self.fft(self.u * q) + self.il * self.fft(self.v * q)
+
+    def jacobian_psi_c(self):       # ref: niwqg/QGModel.py:483-495 (u, v of the last jacobian_psi_q)
+        self.c = self.ifft(self.ch)
+        return self.ik * self.fft(self.u * self.c) + self.il * self.fft(self.v * self.c)
+
+    def set_c(self, c):             # ref: niwqg/QGModel.py:522-534
+        self.c = c
+        self.ch = self.fft(self.c)
+        self.cvar = self.spec_var(self.ch)
+
+    def _calc_derived_fields(self):     # ref: niwqg/QGModel.py:724-737
+        if self.passive_scalar:
+            self.C2 = self.spec_var(self.ch)
+            self.gradC2 = self.spec_var(self.wv * self.ch)
+            self.lapc = self.ifft(-self.wv2 * self.ch)
+            self.Gamma_c = 2 * (self.lapc * self.ifft(self.jacobian_psi_c())).mean()
+
+    def _calc_ep_c(self):           # ref: niwqg/QGModel.py:595-598 (nu, not nuc, multiplies gradC2 there)
+        return -2 * self.nu4c * (self.lapc ** 2).mean() - 2 * self.nu * self.gradC2 - 2 * self.muc * self.C2
+
+    def _calc_chi_c(self):          # ref: niwqg/QGModel.py:600-604
+        lap2c = self.ifft(self.wv4 * self.ch)
+        return (2 * self.nu4c * (lap2c * self.lapc).mean() - 2 * self.nu * (self.lapc ** 2).mean()
+                - 2 * self.muc * self.gradC2)
 
     def _invert(self):              # ref: niwqg/QGModel.py:497-505
         self.ph = -self.wv2i * self.qh
@@ -583,32 +613,65 @@ class QGOracle:
 
     def _step_etdrk4(self):         # ref: niwqg/QGModel.py:328-407
         c, F = self.coef_q, self.filtr
+        ps = self.passive_scalar
+        cc = self.coef_c if ps else None
         self.qh0 = self.qh.copy()
         N0 = -self.jacobian_psi_q()
         self.qh = (c["Eh"] * self.qh0 + N0 * c["Q"]) * F
         self.qh1 = self.qh.copy()
+        if ps:                      # the scalar is advected by the u, v that jacobian_psi_q just computed
+            self.ch0 = self.ch.copy()
+            M0 = -self.jacobian_psi_c()
+            self.ch = (cc["Eh"] * self.ch0 + M0 * cc["Q"]) * F
+            self.ch1 = self.ch.copy()
+            self._calc_derived_fields()
+            c1 = self._calc_ep_c()
         self._invert()
         k1 = self._calc_ep_psi()
         Na = -self.jacobian_psi_q()
         self.qh = (c["Eh"] * self.qh0 + Na * c["Q"]) * F
+        if ps:
+            Ma = -self.jacobian_psi_c()
+            self.ch = (cc["Eh"] * self.ch0 + Ma * cc["Q"]) * F
+            self._calc_derived_fields()
+            c2 = self._calc_ep_c()
         self._invert()
         k2 = self._calc_ep_psi()
         Nb = -self.jacobian_psi_q()
         self.qh = (c["Eh"] * self.qh1 + (2.0 * Nb - N0) * c["Q"]) * F
+        if ps:
+            Mb = -self.jacobian_psi_c()
+            self.ch = (cc["Eh"] * self.ch1 + (2.0 * Mb - M0) * cc["Q"]) * F
+            self._calc_derived_fields()
+            c3 = self._calc_ep_c()
         self._invert()
         k3 = self._calc_ep_psi()
         Nc = -self.jacobian_psi_q()
         self.qh = (c["E"] * self.qh0 + N0 * c["f0"] + 2.0 * (Na + Nb) * c["fab"]
                    + Nc * c["fc"]) * F
+        if ps:
+            Mc = -self.jacobian_psi_c()
+            self.ch = (cc["E"] * self.ch0 + M0 * cc["f0"] + 2.0 * (Ma + Mb) * cc["fab"]
+                       + Mc * cc["fc"]) * F
+            self._calc_derived_fields()
+            c4 = self._calc_ep_c()
+            self.cvar += self.dt * (c1 + 2 * (c2 + c3) + c4) / 6.0
         self._invert()
         self.q = self.ifft(self.qh)
+        if ps:
+            self.c = self.ifft(self.ch)
         k4 = self._calc_ep_psi()
         self.Ke += self.dt * (k1 + 2 * (k2 + k3) + k4) / 6.0
 
-    def _diagnostic_values(self):   # ref: niwqg/QGModel.py:632-737 (passive scalar off)
-        return [("time", self.t), ("ke_qg", self._calc_ke_qg()), ("Ke", self.Ke),
+    def _diagnostic_values(self):   # ref: niwqg/QGModel.py:632-737
+        self._calc_derived_fields()
+        vals = [("time", self.t), ("ke_qg", self._calc_ke_qg()), ("Ke", self.Ke),
                 ("ens", 0.5 * (self.q ** 2).mean()), ("ep_psi", self._calc_ep_psi()),
                 ("chi_q", self._calc_chi_q())]
+        if self.passive_scalar:
+            vals += [("C2", self.C2), ("cvar", self.cvar), ("gradC2", self.gradC2), ("Gamma_c", self.Gamma_c),
+                     ("ep_c", self._calc_ep_c()), ("chi_c", self._calc_chi_c())]
+        return vals
 
     def _increment_diagnostics(self):
         if not (self.tc % self.tdiags):

@@ -19,6 +19,7 @@ Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
   g7_checksums.npz        scalar checksums at 256^2 / 512^2
   g8_ybj_64.npz           YBJModel (steady psi): trajectory, diagnostics series, stale phix/phiy
   g9_initial_conditions_64.npz   all five generators of niwqg/InitialConditions.py (seeded)
+  g10_qg_passive_64.npz   QGModel with passive_scalar=True: trajectory of q and c, cvar, diagnostics series
 """
 import os
 import sys
@@ -276,7 +277,33 @@ def g9():
     save("g9_initial_conditions_64.npz", **out)
 
 
+def g10():
+    """QGModel 64^2 with its passive scalar (niwqg/QGModel.py:345-404, :483-495, :522-534, :595-604, :724-737)."""
+    nx, nsteps = 64, 20
+    dt = 0.05 * TE * 128 / nx / 2
+    out = {}
+    for use_filter in (True, False):
+        m = QGModel.Model(L=L, nx=nx, tmax=(nsteps - 0.5) * dt, dt=dt, twrite=10 ** 9, nu4=7.5e8 * 16, nu=5.0,
+                          mu=1e-8, use_filter=use_filter, U=-U0, tdiags=1, beta=2e-11, passive_scalar=True,
+                          nu4c=3e9, nuc=2.0, muc=1e-8, save_to_disk=False)
+        q0 = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+        c0 = np.sin(2 * np.pi * 3 * m.x / L) * np.cos(2 * np.pi * 2 * m.y / L) + 0.3
+        m.set_q(q0)
+        m.set_c(c0)
+        m.run()
+        assert m.tc == nsteps
+        key = "filter" if use_filter else "nofilter"
+        out["dt"] = dt
+        out["q0"], out["c0"] = q0, c0
+        out["q_" + key], out["qh_" + key] = m.q, m.qh
+        out["c_" + key], out["ch_" + key] = m.c, m.ch
+        out["scalars_" + key] = np.array([m.Ke, m.cvar, m.C2, m.gradC2])
+        for name, d in m.diagnostics.items():
+            out["diag_%s_%s" % (name, key)] = np.asarray(d["value"], dtype=float)
+    save("g10_qg_passive_64.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

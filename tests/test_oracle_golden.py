@@ -215,3 +215,21 @@ def test_ybj_oracle_matches_reference(golden):
                 for name in o.diagnostics:
                     ref = g["diag_%s_%s" % (name, key)]
                     assert np.allclose(o.diag(name), ref, rtol=1e-9, atol=1e-13 if name in ("skew", "conc_niw") else 1e-30), name
+
+
+def test_qg_passive_scalar_oracle_matches_reference(golden):
+    """QGModel with passive_scalar=True through the reference itself (g10)."""
+    g = golden("g10_qg_passive_64.npz")
+    for use_filter in (True, False):
+        key = "filter" if use_filter else "nofilter"
+        o = O.QGOracle(L=L, nx=64, tmax=1e30, dt=float(g["dt"]), twrite=10 ** 9, nu4=7.5e8 * 16, nu=5.0, mu=1e-8,
+                       use_filter=use_filter, U=-U0, tdiags=1, beta=2e-11, passive_scalar=True, nu4c=3e9, nuc=2.0,
+                       muc=1e-8)
+        o.set_q(g["q0"])
+        o.set_c(g["c0"])
+        steps(o, 20)
+        assert rel(o.q, g["q_" + key]) < 1e-12 and rel(o.c, g["c_" + key]) < 1e-13
+        assert rel(o.ch, g["ch_" + key]) < 1e-13
+        assert np.allclose([o.Ke, o.cvar, o.C2, o.gradC2], g["scalars_" + key], rtol=1e-11)
+        for name in o.diagnostics:
+            assert np.allclose(o.diag(name), g["diag_%s_%s" % (name, key)], rtol=1e-9, atol=1e-30), name

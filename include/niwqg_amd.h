@@ -40,13 +40,19 @@ enum {
   NQ_F_QWH = 10,   /* cplx spectral      qwh                                  CoupledModel.py:86-88            */
   NQ_F_PHIX = 11,  /* cplx               phix (as last refreshed: quirk Q1)   Kernel.py:610                    */
   NQ_F_PHIY = 12,  /* cplx               phiy                                                                   */
-  NQ_F_QH_MINUS = 13 /* cplx half spectrum conj(qh(-l,-k)), k = 0..nx/2 (dual_q contexts only)                  */
+  NQ_F_QH_MINUS = 13,/* cplx half spectrum conj(qh(-l,-k)), k = 0..nx/2 (dual_q contexts only)                  */
+  NQ_F_C = 14,       /* real (ny,nx)       c      passive scalar of QGModel     QGModel.py:403-404               */
+  NQ_F_CH = 15,      /* cplx (ny,nx/2+1)   ch                                                                     */
+  NQ_F_QH_STAGE4 = 16 /* cplx half spectrum qh at which the LAST step evaluated its fourth stage: the u, v that QGModel's
+                         jacobian_psi_c sees at a diagnostics tick are still those (QGModel.py:375, :483-495, :727-731) */
 };
 
 /* scalar ids for nq_get_scalar */
 enum {
   NQ_S_KE = 0, NQ_S_PW = 1, NQ_S_KW = 2,   /* INCREMENT of the budget accumulators Ke, Pw, Kw since the last
-                                              read (reading resets it)             Kernel.py:390-392 */
+                                              read (reading resets it)             Kernel.py:390-392;
+                                              QGModel with passive scalar: NQ_S_PW is the increment of cvar
+                                              (QGModel.py:394)                                        */
   NQ_S_KE_QG = 3,                          /* _calc_ke_qg()                        Kernel.py:600-602 */
   NQ_S_KE_NIW = 4,                         /* _calc_ke_niw()                       Kernel.py:604-606 */
   NQ_S_PE_NIW = 5,                         /* _calc_pe_niw() (no side effect here) Kernel.py:608-611 */
@@ -67,6 +73,8 @@ typedef struct nq_params {
   double nu, nu4, mu;       /* q equation   Kernel.py:417-418 / QGModel.py:426-428              */
   double nuw, nu4w, muw;    /* phi equation Kernel.py:440-442                                   */
   double beta;        /* QGModel only                                                           */
+  int passive_scalar; /* QGModel only: 1 = also step the passive scalar c (QGModel.py:345-404)  */
+  double nu4c, nuc, muc;    /* its linear operator -nu4c wv4 - nuc wv2 - muc (QGModel.py:446-454)      */
 } nq_params;
 
 /* Kernel.__init__ / QGModel.__init__ (Kernel.py:139-152): builds grid-dependent tables on the device.
@@ -82,6 +90,8 @@ const char* nq_last_error(const nq_ctx* ctx);     /* ctx may be NULL: last globa
 
 /* Kernel.set_q (Kernel.py:520-535) / QGModel.set_q (QGModel.py:507-520) */
 int nq_set_q(nq_ctx* ctx, const double* q_host);
+/* QGModel.set_c (QGModel.py:522-534): real (ny,nx); call after nq_set_q */
+int nq_set_c(nq_ctx* ctx, const double* c_host);
 /* Kernel.set_phi (Kernel.py:538-551): phi_host is complex (ny,nx) */
 int nq_set_phi(nq_ctx* ctx, const double* phi_host);
 /* CoupledModel._invert + _calc_rel_vorticity (CoupledModel.py:75-97,:145-152), UnCoupledModel._invert

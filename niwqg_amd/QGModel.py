@@ -1,7 +1,9 @@
 """Barotropic QG model on the half spectrum, on the MI355X stepper.
 
-Drop-in for ``niwqg.QGModel.Model`` with ``passive_scalar=False`` (ref: niwqg/QGModel.py:10-737):
-spectral arrays have shape (ny, nx//2+1), ``fft``/``ifft`` have rfft2/irfft2 semantics.
+Drop-in for ``niwqg.QGModel.Model`` (ref: niwqg/QGModel.py:10-737), with or without its passive scalar:
+spectral arrays have shape (ny, nx//2+1), ``fft``/``ifft`` have rfft2/irfft2 semantics.  The scalar c is stepped by
+the same kernels as q (it travels through the row kernel paired with q in one complex transform) with its own linear
+operator; ``cvar`` accumulates on the device like ``Ke`` (QGModel.py:350-394, including its use of nu for gradC2).
 """
 import logging
 
@@ -31,8 +33,6 @@ class Model(object):
         self.save_to_disk, self.overwrite, self.tsnaps, self.path = save_to_disk, overwrite, tsave_snapshots, path
         self.use_filter = use_filter
         self.use_mkl, self.nthreads = use_mkl, nthreads
-        if passive_scalar:
-            raise NotImplementedError("passive_scalar=True is not on the accelerated path yet (SURVEY 8f, rank 2)")
         if save_to_disk:
             raise NotImplementedError("save_to_disk: HDF5 output is outside the accelerated path (SURVEY 8f)")
         if dealias and not use_filter:
@@ -42,7 +42,8 @@ class Model(object):
         self._initialize_grid()
         self._initialize_filter()
         self._ctx = _lib.Context(_lib.QG, nx, self.kk, self.ll, self.filtr, dt, U=U, nu=nu, nu4=nu4, mu=mu,
-                                 beta=beta, budgets=budgets, device=device)
+                                 beta=beta, budgets=budgets, device=device, passive_scalar=passive_scalar,
+                                 nu4c=nu4c, nuc=nuc, muc=muc)
         self._cache, self._user = {}, {}
         self.t, self.tc = 0, 0
         self.cflmax = .5
@@ -87,6 +88,8 @@ class Model(object):
             d["wv2i"][nz] = d["wv2"][nz] ** -1
             return d[name]
         fields = {"q": _lib.F_Q, "qh": _lib.F_QH, "p": _lib.F_P, "ph": _lib.F_PH, "u": _lib.F_U, "v": _lib.F_V}
+        if self.__dict__.get("passive_scalar"):
+            fields.update(c=_lib.F_C, ch=_lib.F_CH)
         if name in fields:
             if name in self._user:
                 return self._user[name]
@@ -130,6 +133,29 @@ class Model(object):
             self._ctx.scalar(_lib.S_KE)             # drop increments that belong to the old state
         self.Ke = self._calc_ke_qg()
 
+    def set_c(self, c):
+        """ref: niwqg/QGModel.py:522-534"""
+        if not self.passive_scalar:
+            raise RuntimeError("set_c: the model was built with passive_scalar=False")
+        self._ctx.set_c(c)
+        self._dirty()
+        self._user["c"] = c
+        if self._ctx.budgets_enabled:
+            self._ctx.scalar(_lib.S_PW)             # drop increments that belong to the old state
+        self.cvar = self.spec_var(self.ch)
+
+    def jacobian_psi_c(self):
+        """ik F[u c] + il F[v c] (ref: niwqg/QGModel.py:483-495); diagnostics ticks only -- inside a step the row
+        kernel forms these products next to those of q."""
+        if getattr(self, "_stepped", False):
+            # the reference's u, v at a tick are those of the last jacobian_psi_q call, i.e. of the state at which
+            # the step evaluated its fourth stage, not of the new state (QGModel.py:375 vs :396)
+            ph4 = -self.wv2i * self._ctx.field(_lib.F_QH_STAGE4)
+            u, v = self.ifft(-self.il * ph4), self.ifft(self.ik * ph4)
+        else:
+            u, v = self.u, self.v
+        return self.ik * self.fft(u * self.c) + self.il * self.fft(v * self.c)
+
     def _invert(self):
         self._ctx.invert()
         self._cache.pop("ph", None)
@@ -154,8 +180,11 @@ class Model(object):
 
     def _after_steps(self):
         self._dirty()
+        self._stepped = True
         if self._ctx.budgets_enabled:
             self.Ke += self._ctx.scalar(_lib.S_KE)
+            if self.passive_scalar:
+                self.cvar += self._ctx.scalar(_lib.S_PW)        # ref: niwqg/QGModel.py:394
 
     def _step_forward(self):
         self._step_etdrk4()
@@ -226,11 +255,24 @@ class Model(object):
     def _calc_cfl(self):
         return self._ctx.scalar(_lib.S_CFL) * self.dt / self.dx      # max reduction on the device
 
+    def _calc_ep_c(self):
+        """ref: niwqg/QGModel.py:595-598 (nu, not nuc, multiplies gradC2 there)"""
+        return -2 * self.nu4c * (self.lapc ** 2).mean() - 2 * self.nu * self.gradC2 - 2 * self.muc * self.C2
+
+    def _calc_chi_c(self):
+        """ref: niwqg/QGModel.py:600-604"""
+        if not self.passive_scalar:
+            return 0.0
+        lap2c = self.ifft(self.wv4 * self.ch)
+        return (2 * self.nu4c * (lap2c * self.lapc).mean() - 2 * self.nu * (self.lapc ** 2).mean()
+                - 2 * self.muc * self.gradC2)
+
     def _initialize_diagnostics(self):
         """ref: niwqg/QGModel.py:632-722 (the passive-scalar entries report zeros, as the reference
         does when passive_scalar=False, QGModel.py:734-737)"""
         self.diagnostics = dict()
         self.C2, self.gradC2, self.cvar, self.Gamma_c = 0., 0., 0., 0.
+        self.lapc = np.array([0.])
         table = [
             ('time', 'Time', 'seconds', lambda s: s.t),
             ('ke_qg', 'Quasigeostrophic Kinetic Energy', r'm^2 s^{-2}', lambda s: s._calc_ke_qg()),
@@ -244,9 +286,19 @@ class Model(object):
             ('gradC2', 'Gradient of Passive tracer variance', r'[scalar]^2 / m^2', lambda s: s.gradC2),
             ('Gamma_c', 'Rate of generation of passive tracer gradient variance', r'[scalar]^2 / (m^2 s)',
              lambda s: s.Gamma_c),
+            ('ep_c', 'The dissipation of tracer variance', r'$s^{-3}$', lambda s: s._calc_ep_c()),
+            ('chi_c', 'The dissipation of tracer gradient variance', r'$s^{-3}$', lambda s: s._calc_chi_c()),
         ]
         for name, desc, units, fn in table:
             add_diagnostic(self, name, description=desc, units=units, types='scalar', function=fn)
 
     def _calc_derived_fields(self):
-        pass
+        """ref: niwqg/QGModel.py:724-737 (diagnostics ticks; host arithmetic on the downloaded scalar spectrum)"""
+        if self.passive_scalar:
+            self.C2 = self.spec_var(self.ch)
+            self.gradC2 = self.spec_var(self.wv * self.ch)
+            self.lapc = self.ifft(-self.wv2 * self.ch)
+            self.Gamma_c = 2 * (self.lapc * self.ifft(self.jacobian_psi_c())).mean()
+        else:
+            self.C2, self.gradC2, self.cvar, self.Gamma_c = 0., 0., 0., 0.
+            self.lapc = np.array([0.])

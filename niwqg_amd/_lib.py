@@ -21,10 +21,10 @@ HEADERS = [os.path.join(HERE, "csrc", h) for h in ("nq_fft.hpp", "nq_generic.hpp
     os.path.join(os.path.dirname(HERE), "include", "niwqg_amd.h")]
 
 COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
-(F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY, F_QH_MINUS) = range(14)
+(F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY, F_QH_MINUS, F_C, F_CH, F_QH_STAGE4) = range(17)
 (S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL) = range(7)
 
-EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
+EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
            "nq_step", "nq_sync", "nq_get_field", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
            "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_get_coeff", "nq_diagnostics",
            "nq_timer_start", "nq_timer_stop", "nq_profile_enable", "nq_profile_read", "nq_group_elems", "nq_create_slab",
@@ -37,7 +37,9 @@ class Params(ctypes.Structure):
                 ("dual_q", ctypes.c_int), ("dt", ctypes.c_double), ("U", ctypes.c_double),
                 ("f", ctypes.c_double), ("kappa2", ctypes.c_double), ("nu", ctypes.c_double),
                 ("nu4", ctypes.c_double), ("mu", ctypes.c_double), ("nuw", ctypes.c_double),
-                ("nu4w", ctypes.c_double), ("muw", ctypes.c_double), ("beta", ctypes.c_double)]
+                ("nu4w", ctypes.c_double), ("muw", ctypes.c_double), ("beta", ctypes.c_double),
+                ("passive_scalar", ctypes.c_int), ("nu4c", ctypes.c_double), ("nuc", ctypes.c_double),
+                ("muc", ctypes.c_double)]
 
 
 def needs_build():
@@ -78,7 +80,7 @@ def lib():
     L.nq_last_error.restype = ctypes.c_char_p
     for name in ("nq_destroy", "nq_invert", "nq_refresh_grad_phi", "nq_sync", "nq_timer_start"):
         getattr(L, name).argtypes = [vp]
-    for name in ("nq_set_q", "nq_set_phi", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi",
+    for name in ("nq_set_q", "nq_set_c", "nq_set_phi", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi",
                  "nq_diagnostics"):
         getattr(L, name).argtypes = [vp, dp]
     for name in ("nq_fft2", "nq_ifft2", "nq_rfft2", "nq_irfft2"):
@@ -117,13 +119,15 @@ class Context:
     """Thin object wrapper over nq_ctx; all arrays in and out are numpy."""
 
     def __init__(self, model, nx, kk, ll, filtr, dt, U=0.0, f=1e-4, kappa2=1.0, nu=0.0, nu4=0.0, mu=0.0,
-                 nuw=0.0, nu4w=0.0, muw=0.0, beta=0.0, budgets=True, device=0, dual_q=False):
+                 nuw=0.0, nu4w=0.0, muw=0.0, beta=0.0, budgets=True, device=0, dual_q=False, passive_scalar=False,
+                 nu4c=0.0, nuc=0.0, muc=0.0):
         self.L = lib()
         self.model, self.nx = model, int(nx)
         self.nk = nx if model != QG else nx // 2 + 1
         self.dual_q = bool(dual_q) and model != QG
         p = Params(model=model, nx=nx, budgets=int(bool(budgets)), dual_q=int(self.dual_q), dt=dt, U=U, f=f, kappa2=kappa2,
-                   nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw, beta=beta)
+                   nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw, beta=beta,
+                   passive_scalar=int(bool(passive_scalar) and model == QG), nu4c=nu4c, nuc=nuc, muc=muc)
         kk = np.ascontiguousarray(kk, dtype=np.float64)
         ll = np.ascontiguousarray(ll, dtype=np.float64)
         filtr = np.ascontiguousarray(filtr, dtype=np.float64)
@@ -163,6 +167,11 @@ class Context:
         assert q.shape == (self.nx, self.nx)
         self._chk(self.L.nq_set_q(self.h, _dptr(q)), "nq_set_q")
 
+    def set_c(self, c):
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        assert c.shape == (self.nx, self.nx)
+        self._chk(self.L.nq_set_c(self.h, _dptr(c)), "nq_set_c")
+
     def set_phi(self, phi):
         phi = np.ascontiguousarray(phi, dtype=np.complex128)
         assert phi.shape == (self.nx, self.nx)
@@ -181,8 +190,8 @@ class Context:
         self._chk(self.L.nq_sync(self.h), "nq_sync")
 
     # --- reads
-    _REAL = (F_Q, F_P, F_U, F_V, F_QPSI, F_QW)
-    _HALF = (F_QH, F_PH, F_QWH, F_QH_MINUS)
+    _REAL = (F_Q, F_P, F_U, F_V, F_QPSI, F_QW, F_C)
+    _HALF = (F_QH, F_PH, F_QWH, F_QH_MINUS, F_CH, F_QH_STAGE4)
 
     def field(self, fid):
         n, h = self.nx, self.nx // 2 + 1

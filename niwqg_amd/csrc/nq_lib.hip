@@ -98,7 +98,10 @@ struct nq_ctx {
   std::vector<hipEvent_t> prof_ev;               // pairs
   size_t prof_used = 0;
   bool have_q = false, have_phi = false;
-  bool ybj = false;      // niwqg.YBJModel: UnCoupled layouts, only phi is stepped (stage graph in do_step_ybj)
+  bool ybj = false;
+  bool passive = false;  // QGModel with its passive scalar: state cq, spectrum emitted through the qw slots of G3 / G0
+  EqState cq;
+  MArr mUc, mVc;      // niwqg.YBJModel: UnCoupled layouts, only phi is stepped (stage graph in do_step_ybj)
 };
 
 template <typename Tp>
@@ -119,7 +122,7 @@ static int dev_alloc(nq_ctx* c, Tp** out, size_t count) {
 
 // ---------------------------------------------------------------------------------------------
 // ETDRK4 coefficient planes on the device (ref Kernel.py:417-454, QGModel.py:426-443).
-// eq 0: q (Kernel family), 1: phi, 2: q (QGModel, with beta).  One thread per spectral element.
+// eq 0: q (Kernel family), 1: phi, 2: q (QGModel, with beta), 3: QGModel's passive scalar.  One thread per element.
 __device__ __forceinline__ cd cexp_d(cd z) {
   double s, c;
   sincos(z.y, &s, &c);
@@ -144,6 +147,8 @@ __global__ void k_etdrk4_coeffs(int eq, int N, int width, int pitch, int k0, nq_
     c = cmake(-p.nu4 * wv4 - p.nu * wv2 - p.mu, -kx * p.U);
   } else if (eq == 1) {
     c = cmake(-p.nu4w * wv4 - p.nuw * wv2 - p.muw, -kx * p.U - 0.5 * p.f * (wv2 / p.kappa2));
+  } else if (eq == 3) {       // QGModel's passive scalar: no mean-flow or beta term (ref QGModel.py:446-454)
+    c = cmake(-p.nu4c * wv4 - p.nuc * wv2 - p.muc, 0.0);
   } else {
     const double wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
     c = cmake(-p.nu4 * wv4 - p.nu * wv2 - p.mu, -kx * p.U + p.beta * kx * wv2i);
@@ -330,7 +335,8 @@ __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, 
 
 // budget bookkeeping ----------------------------------------------------------------------------
 struct BudgetAcc {
-  int model, nww, nwq;
+  int model, nww, nwq, nqs;     // nqs: doubles per workgroup in partQ (6 with QGModel's passive scalar)
+  double nu4c, muc;
   const double *partW, *partQ;
   double *carryW, *carryQ, *gradS1, *acc;
   double dt, f, hslash, kappa2, nu, nu4, mu, nuw, nu4w, muw, M;
@@ -364,8 +370,10 @@ __global__ void k_budget_sums(BudgetAcc b, double* __restrict__ sums) {
   __shared__ double sh[16];
   const int s = blockIdx.x / 11, q = blockIdx.x % 11;
   double t = 0.0;
-  if (q < 3) t = block_total(b.partQ + (size_t)s * b.nwq * 3 + q, b.nwq, 3, sh);
-  else if (b.model != NQ_MODEL_QG) {
+  if (q < 3) t = block_total(b.partQ + (size_t)s * b.nwq * b.nqs + q, b.nwq, b.nqs, sh);
+  else if (b.model == NQ_MODEL_QG) {
+    if (b.nqs == 6 && q < 6) t = block_total(b.partQ + (size_t)s * b.nwq * 6 + q, b.nwq, 6, sh);   // |c|^2 sums
+  } else {
     if (q < 3 + NQ_PARTW) t = block_total(b.partW + (size_t)s * b.nww * NQ_PARTW + (q - 3), b.nww, NQ_PARTW, sh);
   }
   if (threadIdx.x == 0) sums[s * 11 + q] = t;
@@ -406,6 +414,14 @@ __global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums
     K += wgt[s] * k;
     Pw += wgt[s] * p;
     A += wgt[s] * a;
+  }
+  if (qg && b.nqs == 6) {
+    // cvar += dt (c1 + 2 c2 + 2 c3 + c4) / 6 with c_s = ep_c after the stage-s update (ref QGModel.py:350-394, :595-598;
+    // the reference multiplies gradC2 by nu, not nuc)
+    for (int s = 0; s < 4; ++s) {
+      const double* sc = sums + s * 11 + 3;
+      Pw += wgt[s] * (-2.0 * b.nu4c * sc[2] - 2.0 * b.nu * sc[1] - 2.0 * b.muc * sc[0]) / M2;
+    }
   }
   b.acc[0] += b.dt * K / 6.0;
   b.acc[1] += b.dt * Pw / 6.0;
@@ -615,8 +631,8 @@ static void launch_wavepv(nq_ctx* c) {
 template <int MODE>
 static void launch_products_m(nq_ctx* c, double cj, double cr, bool fresh_grad) {
   const int vz = c->kernel_family ? 1 : 0;
-  const MArr& gx = (MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGx : c->mPhi;
-  const MArr& gy = (MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGy : c->mPhiy;
+  const MArr& gx = (MODE == MODE_QGC) ? c->mUc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGx : c->mPhi);
+  const MArr& gy = (MODE == MODE_QGC) ? c->mVc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGy : c->mPhiy);
   switch (c->N) {
 #define CASE_(n, a, b) case n: { typedef XPlan<n> X; const int nb = c->Nloc / X::C; \
     /* one workgroup fits per CU (LDS) and does not spill: persistent; 8192-point rows spill and do better with dynamic dispatch */ \
@@ -632,6 +648,7 @@ static void launch_products(nq_ctx* c, double cj = -1.0, double cr = -0.5, bool 
   ProfScope ps(c, PK_PRODUCTS);
   if (c->p.model == NQ_MODEL_COUPLED) launch_products_m<MODE_COUPLED>(c, cj, cr, false);
   else if (c->p.model == NQ_MODEL_UNCOUPLED) launch_products_m<MODE_UNCOUPLED>(c, cj, cr, fresh_grad);
+  else if (c->passive) launch_products_m<MODE_QGC>(c, cj, cr, false);
   else launch_products_m<MODE_QG>(c, cj, cr, false);
 }
 
@@ -655,7 +672,7 @@ static EtdArrays etd_arrays(EqState& e, int stage, int* out_slot) {
 }
 
 template <int S>
-static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage) {
+static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage, const MArr& huq, const MArr& hvq) {
   typedef YPlan<S> Y;
   DualQ dq;
   EtdArrays eap = ea;
@@ -675,8 +692,8 @@ static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage) {
   const YGeom g = geom_half(c);
   if (g.width <= 0) return;
   const dim3 grid((g.width + CL - 1) / CL, c->S2), block(Y::THREADS);
-  if (c->dual) hipLaunchKernelGGL((k_s_q<S, true>), grid, block, Y::LDS_BYTES, c->stream, c->mUq, c->mVq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq);
-  else hipLaunchKernelGGL((k_s_q<S, false>), grid, block, Y::LDS_BYTES, c->stream, c->mUq, c->mVq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq);
+  if (c->dual) hipLaunchKernelGGL((k_s_q<S, true>), grid, block, Y::LDS_BYTES, c->stream, huq, hvq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq);
+  else hipLaunchKernelGGL((k_s_q<S, false>), grid, block, Y::LDS_BYTES, c->stream, huq, hvq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq);
 }
 static BudgetW budget_w(nq_ctx* c, double* part, const cd* y_start) {
   BudgetW bw;
@@ -701,7 +718,7 @@ static void launch_emit_phi_s(nq_ctx* c, const cd* phih) {
   hipLaunchKernelGGL((k_s_emit_phi<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, phih, geom_full(c), c->mPhi, c->mPhiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
 template <int S, int MODE>
-static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud) {
+static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud, const cd* c_hat = nullptr) {
   typedef YPlan<S> Y;
   // the second copy lives in the same rotating slot as qh
   const cd* qh_minus = nullptr;
@@ -710,7 +727,7 @@ static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux, double* pa
       if (c->q.y[i] == qh) qh_minus = c->q2.y[i];
   const YGeom g = geom_half(c);
   if (g.width <= 0) return;
-  hipLaunchKernelGGL((k_s_invert<S, MODE>), dim3((g.width + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mA, c->mB, qh, c->filt_h, c->mU, c->mP, c->mQ, c->mQw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, g, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->tw, 1, c->bud ? part : nullptr, q_bud, qh_minus, c->dual ? c->filt_m : nullptr);
+  hipLaunchKernelGGL((k_s_invert<S, MODE>), dim3((g.width + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mA, c->mB, qh, c->filt_h, c->mU, c->mP, c->mQ, c->mQw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, g, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->tw, 1, c->bud ? part : nullptr, q_bud, qh_minus, c->dual ? c->filt_m : nullptr, c_hat);
 }
 #define NQ_S1_SWITCH(c, CALL)         \
   switch ((c)->S1) {                  \
@@ -720,9 +737,11 @@ static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux, double* pa
     case 64: CALL(64); break;         \
   }
 
-static void launch_sq(nq_ctx* c, const EtdArrays& ea, int stage) {
+static void launch_sq(nq_ctx* c, const EtdArrays& ea, int stage, const MArr* huq = nullptr, const MArr* hvq = nullptr) {
   ProfScope ps(c, PK_SQ);
-#define CALL_(s) launch_sq_s<s>(c, ea, stage)
+  const MArr& a1 = huq ? *huq : c->mUq;
+  const MArr& a2 = hvq ? *hvq : c->mVq;
+#define CALL_(s) launch_sq_s<s>(c, ea, stage, a1, a2)
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
@@ -740,9 +759,13 @@ static void launch_emit_phi(nq_ctx* c, const cd* phih) {
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
-static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud) {
+static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud, const cd* c_hat = nullptr) {
   ProfScope ps(c, PK_INVERT);
-  if (c->p.model == NQ_MODEL_COUPLED) {
+  if (c->passive) {
+#define CALL_(s) launch_invert_sm<s, MODE_QGC>(c, qh, store_aux, part, q_bud, c_hat)
+    NQ_S1_SWITCH(c, CALL_)
+#undef CALL_
+  } else if (c->p.model == NQ_MODEL_COUPLED) {
 #define CALL_(s) launch_invert_sm<s, MODE_COUPLED>(c, qh, store_aux, part, q_bud)
     NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
@@ -756,7 +779,8 @@ static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux, double* part,
 static BudgetAcc budget_acc(nq_ctx* c) {
   BudgetAcc b;
   b.model = c->p.model;
-  b.nww = c->nww; b.nwq = c->nwq;
+  b.nww = c->nww; b.nwq = c->nwq; b.nqs = c->passive ? 6 : 3;
+  b.nu4c = c->p.nu4c; b.muc = c->p.muc;
   b.partW = c->partW; b.partQ = c->partQ;
   b.carryW = c->carryW; b.carryQ = c->carryQ; b.gradS1 = c->gradS1; b.acc = c->acc;
   b.dt = c->p.dt; b.f = c->p.f; b.kappa2 = c->p.kappa2; b.hslash = c->p.f / c->p.kappa2;
@@ -775,10 +799,10 @@ static const cd* stage_qh_out(nq_ctx* c, int stage) {
   const int cur = c->q.cur;
   return c->q.y[(stage == 0) ? (cur + 1) % 3 : (stage == 3 ? cur : (cur + 2) % 3)];
 }
-static void phase_invert_y(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud) {
+static void phase_invert_y(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud, const cd* c_hat = nullptr) {
   if (c->p.model == NQ_MODEL_COUPLED) launch_A_m(c, false, {&c->mA, &c->mB});
-  launch_invert(c, qh, store_aux, part, q_bud);
-  if (c->p.model == NQ_MODEL_COUPLED) launch_A_m(c, true, {&c->mU, &c->mP, &c->mQ, &c->mQw});
+  launch_invert(c, qh, store_aux, part, q_bud, c_hat);
+  if (c->p.model == NQ_MODEL_COUPLED || c->passive) launch_A_m(c, true, {&c->mU, &c->mP, &c->mQ, &c->mQw});
   else launch_A_m(c, true, {&c->mU, &c->mP, &c->mQ});
 }
 static void phase_products(nq_ctx* c, int stage) { (void)stage; launch_products(c); }
@@ -786,9 +810,15 @@ static void phase_update(nq_ctx* c, int s) {
   const bool waves = c->p.model != NQ_MODEL_QG;
   int qslot = 0, wslot = 0;
   if (waves) launch_A_m(c, false, {&c->mW});
-  launch_A_m(c, false, {&c->mUq, &c->mVq});
+  if (c->passive) launch_A_m(c, false, {&c->mUq, &c->mVq, &c->mUc, &c->mVc});
+  else launch_A_m(c, false, {&c->mUq, &c->mVq});
   EtdArrays eq = etd_arrays(c->q, s, &qslot);
   launch_sq(c, eq, s);
+  int cslot = 0;
+  if (c->passive) {           // same update with the scalar's operator and its own products (ref QGModel.py:345-392)
+    EtdArrays ec = etd_arrays(c->cq, s, &cslot);
+    launch_sq(c, ec, s, &c->mUc, &c->mVc);
+  }
   if (waves) {
     // phih at the start of this stage: y(t_n), stage-0 result, stage-1 result, stage-2 result
     const int cur = c->w.cur;
@@ -801,7 +831,8 @@ static void phase_update(nq_ctx* c, int s) {
     // no wave feedback on psi: the inversion needs no row pass, it runs here on the spectral side
     // QGModel evaluates ep_psi after each stage's inversion with the start-of-step q (QGModel.py:355,:401)
     const cd* q_bud = (!c->kernel_family && s < 3) ? c->q.y[c->q.cur] : nullptr;
-    phase_invert_y(c, c->q.y[qslot], s == 3, c->partQ + (size_t)s * c->nwq * 3, q_bud);
+    const int nqs = c->passive ? 6 : 3;
+    phase_invert_y(c, c->q.y[qslot], s == 3, c->partQ + (size_t)s * c->nwq * nqs, q_bud, c->passive ? c->cq.y[cslot] : nullptr);
   }
 }
 static void phase_wavepv(nq_ctx* c) { launch_wavepv(c); }
@@ -819,7 +850,7 @@ static void phase_budget_finish(nq_ctx* c) {
 // the next step's slot 0.
 static void do_invert_now(nq_ctx* c) {
   if (c->p.model == NQ_MODEL_COUPLED) launch_wavepv(c);
-  phase_invert_y(c, c->q.y[c->q.cur], true, c->part0Q, nullptr);
+  phase_invert_y(c, c->q.y[c->q.cur], true, c->part0Q, nullptr, c->passive ? c->cq.y[c->cq.cur] : nullptr);
   if (c->bud && c->kernel_family)
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0Q, c->nwq, 3, 3, c->carryQ);
 }
@@ -899,7 +930,7 @@ const char* nq_last_error(const nq_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 // ---- slab geometry (shared by nq_group_elems and the constructor) -----------------------------------
 struct SlabGeom {
   int N, P, Nloc, Wf, Wl, WhG, Ph;
-  bool waves, coupled, bud;
+  bool waves, coupled, bud, passive;
   int npitch[4];                 // row pitch of the four exchange groups
   int off[4][4];                 // column offset of each array inside its group's row
 };
@@ -916,11 +947,12 @@ static SlabGeom slab_geom(const nq_params* p, int P) {
   g.waves = p->model != NQ_MODEL_QG;
   g.coupled = p->model == NQ_MODEL_COUPLED;
   g.bud = p->budgets != 0;
+  g.passive = p->model == NQ_MODEL_QG && p->passive_scalar != 0;
   const int hs = g.Ph;                          // segment stride of a half-spectrum array inside a row
   memset(g.off, 0, sizeof(g.off));
-  // G0: Muq, Mvq, [Mw]
-  g.off[0][0] = 0; g.off[0][1] = hs; g.off[0][2] = 2 * hs;
-  g.npitch[0] = 2 * hs + (g.waves ? g.Wf : 0);
+  // G0: Muq, Mvq, [Mw | Muc, Mvc]
+  g.off[0][0] = 0; g.off[0][1] = hs; g.off[0][2] = 2 * hs; g.off[0][3] = 3 * hs;
+  g.npitch[0] = 2 * hs + (g.waves ? g.Wf : 0) + (g.passive ? 2 * hs : 0);
   // G1: Mphi, Mphiy
   for (int i = 0; i < 4; ++i) g.off[1][i] = i * g.Wf;
   g.npitch[1] = g.waves ? 2 * g.Wf : 0;
@@ -929,7 +961,7 @@ static SlabGeom slab_geom(const nq_params* p, int P) {
   g.npitch[2] = g.coupled ? 2 * hs : 0;
   // G3: Mu, Mp, Mq, [Mqw]
   for (int i = 0; i < 4; ++i) g.off[3][i] = i * hs;
-  g.npitch[3] = (g.coupled ? 4 : 3) * hs;
+  g.npitch[3] = ((g.coupled || g.passive) ? 4 : 3) * hs;
   return g;
 }
 
@@ -986,6 +1018,7 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
   const SlabGeom sg = slab_geom(p, P);
   c->p = *p;
   c->ybj = ybj;
+  c->passive = sg.passive;
   c->N = p->nx;
   c->S1 = S1;
   c->S2 = S2;
@@ -1084,6 +1117,14 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
     dim3 blk(64), grdh((c->Wh + 63) / 64, N), grdf((c->Wf + 63) / 64, N);
     if (c->Wh > 0)
       hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, c->kernel_family ? 0 : 2, N, c->Wh, c->Ph, c->kh0, c->p, c->kk, c->ll, c->filt_h, c->contour, c->q.coef[0], c->q.coef[1], c->q.coef[2], c->q.coef[3], c->q.coef[4], c->q.coef[5]);
+    if (sg.passive) {
+      for (int i = 0; i < 3; ++i) ALLOC(c, c->cq.y[i], half);
+      ALLOC(c, c->cq.fn0, half);
+      ALLOC(c, c->cq.fna, half);
+      for (int i = 0; i < 6; ++i) ALLOC(c, c->cq.coef[i], half);
+      if (c->Wh > 0)
+        hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, 3, N, c->Wh, c->Ph, c->kh0, c->p, c->kk, c->ll, c->filt_h, c->contour, c->cq.coef[0], c->cq.coef[1], c->cq.coef[2], c->cq.coef[3], c->cq.coef[4], c->cq.coef[5]);
+    }
     c->dual = c->kernel_family && p->dual_q != 0;
     if (c->dual) {
       for (int i = 0; i < 3; ++i) ALLOC(c, c->q2.y[i], half);
@@ -1145,6 +1186,10 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
     c->mP = make_marr(sg, c->G[3].bx, c->G[3].by, 3, 1, true);
     c->mQ = make_marr(sg, c->G[3].bx, c->G[3].by, 3, 2, true);
     c->mQw = make_marr(sg, c->G[3].bx, c->G[3].by, 3, 3, true);
+    if (sg.passive) {
+      c->mUc = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 2, true);
+      c->mVc = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 3, true);
+    }
     c->mGx = c->mPhi;
     c->mGy = c->mPhiy;
     if (c->p.model == NQ_MODEL_UNCOUPLED) {        // frozen copy of the X side of G1 (quirk Q1)
@@ -1156,8 +1201,8 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
       c->nww = (c->Wf / CL) * c->S2;
       c->nwq = ((c->Wh + CL - 1) / CL) * c->S2;
       if (c->nwq < 1) c->nwq = 1;
-      ALLOC(c, c->partQ, (size_t)4 * c->nwq * 3);
-      ALLOC(c, c->part0Q, (size_t)c->nwq * 3);
+      ALLOC(c, c->partQ, (size_t)4 * c->nwq * (sg.passive ? 6 : 3));
+      ALLOC(c, c->part0Q, (size_t)c->nwq * (sg.passive ? 6 : 3));
       ALLOC(c, c->acc, (size_t)4);
       // everything that has to be summed over ranks lives in one 64-double block (external when the caller
       // does the all-reduce): [0,44) stage sums of a step, [44,48) carried phi sums, [48,51) carried q sums,
@@ -1263,6 +1308,18 @@ int nq_set_q(nq_ctx* c, const double* q_host) {
   if (c->dual) HIPCHK(c, hipMemcpyAsync(c->q2.y[c->q2.cur], c->q.y[c->q.cur], sizeof(cd) * (size_t)c->N * c->Ph, hipMemcpyDeviceToDevice, c->stream));
   do_invert_now(c);
   c->have_q = true;
+  return nq_sync(c);
+}
+
+int nq_set_c(nq_ctx* c, const double* c_host) {
+  if (!c || !c_host) return -1;
+  NQ_SINGLE_RANK(c, "nq_set_c");
+  if (!c->passive) NQ_FAIL(c, -4, "nq_set_c: this context has no passive scalar");
+  const size_t full = (size_t)c->N * c->N;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->scr_r, c_host, sizeof(double) * full, hipMemcpyHostToDevice, c->stream));
+  fwd2d_half(c, c->scr_r, c->cq.y[c->cq.cur], c->scr_h0);
+  do_invert_now(c);                 // re-emits u, psi, q and the scalar's mixed-space rows
   return nq_sync(c);
 }
 
@@ -1479,6 +1536,13 @@ int nq_get_field(nq_ctx* c, int id, double* host) {
       if (!c->dual) NQ_FAIL(c, -4, "NQ_F_QH_MINUS needs a dual_q context");
       return get_half_spec(c, c->q2.y[c->q2.cur], host);
     case NQ_F_PH: return get_half_spec(c, c->ph, host);
+    case NQ_F_CH:
+      if (!c->passive) NQ_FAIL(c, -4, "no passive scalar in this context");
+      return get_half_spec(c, c->cq.y[c->cq.cur], host);
+    case NQ_F_QH_STAGE4: return get_half_spec(c, c->q.y[(c->q.cur + 2) % 3], host);
+    case NQ_F_C:
+      if (!c->passive) NQ_FAIL(c, -4, "no passive scalar in this context");
+      return get_real_from_half(c, c->cq.y[c->cq.cur], 0, host);
     case NQ_F_QWH:
       if (c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qwh exists only in the coupled model");
       return get_half_spec(c, c->qwh, host);

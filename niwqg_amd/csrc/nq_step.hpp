@@ -17,7 +17,8 @@
 
 namespace nq {
 
-enum { MODE_COUPLED = 0, MODE_UNCOUPLED = 1, MODE_QG = 2 };
+enum { MODE_COUPLED = 0, MODE_UNCOUPLED = 1, MODE_QG = 2,
+       MODE_QGC = 3 /* QGModel with its passive scalar c (ref QGModel.py:345-404, :483-495): c rides in the qw slots */ };
 
 // ---- slab decomposition: layouts --------------------------------------------
 // With P ranks, physical / mixed-space rows are split by y (N/P local rows, "X side") and spectral /
@@ -323,7 +324,8 @@ k_x_wavepv2(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, 
 // ref Kernel.py:471-486 (jacobian_psi_q), :457-469 (jacobian_psi_phi), :332 (refraction).  The budget terms
 // gamma1+gamma2 and xi1+xi2 (Kernel.py:691-700) are Parseval sums against the transformed phi tendency in k_s_phi:
 // this kernel has no budget work and lap(phi) never comes to physical space.
-// MODE_QG: only Muq, Mvq.  MODE_UNCOUPLED: q_psi = q, phix/phiy from the (possibly stale) Mgx/Mgy.
+// MODE_QG: only Muq, Mvq.  MODE_QGC: the passive scalar c arrives paired with q (Mqw slot) and the products u c, v c leave
+// through Mgx, Mgy (= the Muc, Mvc half-spectrum arrays).  MODE_UNCOUPLED: q_psi = q, phix/phiy from the (possibly stale) Mgx/Mgy.
 // Register plan: q, q_psi, u, v are reals (32 VGPRs each); complex working sets are 64.
 template <int N, int MODE>
 __global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
@@ -346,10 +348,12 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   // the HBM latency hides behind the FFTs.  Every mixed-space input is fetched exactly once.
   // The workgroup is persistent over row blocks rb = blockIdx.x, +gridDim.x, ...; the first inputs of its next block
   // are requested before the last transform of the current one.
+  constexpr bool PAIRQ = (MODE == MODE_COUPLED || MODE == MODE_QGC);     // q travels paired with qw (or with c)
+  constexpr bool ONLYQ = (MODE == MODE_QG || MODE == MODE_QGC);           // no wave field
   HsRegs<P> h1;
   {
     const size_t row0 = (size_t)blockIdx.x * X::C + c_tid;
-    hs_load<N, P, T, MODE == MODE_COUPLED>(h1, xrow(Mq, row0), xrow(MODE == MODE_COUPLED ? Mqw : Mq, row0), j_tid);
+    hs_load<N, P, T, PAIRQ>(h1, xrow(Mq, row0), xrow(PAIRQ ? Mqw : Mq, row0), j_tid);
   }
   for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
   // per-iteration copies the compiler cannot see through: otherwise every LDS / row address of the transforms is
@@ -364,19 +368,51 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   HsRegs<P> h2;
   hs_load<N, P, T, true>(h2, xrow(Mu, row), xrow(Mp, row), j);
   NQ_PHASE_FENCE();
-  hs_pack<N, P, T, F, MODE == MODE_COUPLED>(w, h1, j, c, lds, kk, false, false);
+  double c_unscale = 1.0;
+  if constexpr (MODE == MODE_QGC) {
+    // q and the passive scalar share one complex transform, but c has arbitrary units (|c| ~ 1 against |q| ~ 1e-5 in
+    // the reference's examples): the roundoff of the larger would swamp the smaller (2e-11 in q after 20 steps).
+    // Rescale c per row by a power of two, exactly undone after the transform (as k_x_wavepv does for its pair).
+    double ma = 0.0, mb = 0.0;
+#pragma unroll
+    for (int t = 0; t < P / 2; ++t) {
+      ma = fmax(ma, fmax(fabs(h1.a[t].x), fabs(h1.a[t].y)));
+      mb = fmax(mb, fmax(fabs(h1.b[t].x), fabs(h1.b[t].y)));
+    }
+    unsigned long long* mx = reinterpret_cast<unsigned long long*>(nq_smem + X::LDS_BYTES - 512) + 2 * c;
+    if (j == 0) {
+      mx[0] = 0ull;
+      mx[1] = 0ull;
+    }
+    wg_barrier();
+    atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
+    atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
+    wg_barrier();
+    ma = __longlong_as_double((long long)mx[0]);
+    mb = __longlong_as_double((long long)mx[1]);
+    int e = 0;
+    if (ma > 0.0 && mb > 0.0) e = ilogb(ma) - ilogb(mb);
+    e = e > 900 ? 900 : (e < -900 ? -900 : e);
+    const double sb = ldexp(1.0, e);
+    c_unscale = ldexp(1.0, -e);
+#pragma unroll
+    for (int t = 0; t < P / 2; ++t) h1.b[t] = cscale(h1.b[t], sb);
+    h1.bn = cscale(h1.bn, sb);
+    wg_barrier();
+  }
+  hs_pack<N, P, T, F, PAIRQ>(w, h1, j, c, lds, kk, false, false);
   NQ_PHASE_FENCE();
   F::template run<true>(w, j, c, lds, twr);
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     q[t] = w[t].x;
-    qpsi[t] = (MODE == MODE_COUPLED) ? w[t].x - w[t].y : w[t].x;
+    qpsi[t] = (MODE == MODE_COUPLED) ? w[t].x - w[t].y : (MODE == MODE_QGC ? w[t].y * c_unscale : w[t].x);   // QGC: c
   }
   // (u, v) = ifft of (-il psi, ik psi): Mu already holds T_y^-1[-il psi], Mp holds T_y^-1[psi]
   NQ_PHASE_FENCE();
   hs_pack<N, P, T, F, true>(w, h2, j, c, lds, kk, true, v_zero_nyq != 0);
   cd sp[P];          // spectral row of phi: kept for phix (Coupled)
-  if (MODE != MODE_QG) {
+  if (!ONLYQ) {
     const XRow rp = xrow(Mphi, row);
 #pragma unroll
     for (int t = 0; t < P; ++t) sp[t] = *rp.at(j + t * T);
@@ -393,8 +429,16 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   F::template run<false>(w, j, c, lds, twr);
   NQ_PHASE_FENCE();
   unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow(Muq, row), xrow(Mvq, row));
-  if (MODE == MODE_QG) {
-    if (more) hs_load<N, P, T, false>(h1, xrow(Mq, row_next), xrow(Mq, row_next), j);
+  if (ONLYQ) {
+    if (MODE == MODE_QGC) {          // ik F[u c] + il F[v c] needs F[u c], F[v c]  (ref QGModel.py:483-495)
+#pragma unroll
+      for (int t = 0; t < P; ++t) w[t] = cmake(u[t] * qpsi[t], v[t] * qpsi[t]);
+      NQ_PHASE_FENCE();
+      F::template run<false>(w, j, c, lds, twr);
+      NQ_PHASE_FENCE();
+      unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow(Mgx, row), xrow(Mgy, row));
+    }
+    if (more) hs_load<N, P, T, PAIRQ>(h1, xrow(Mq, row_next), xrow(PAIRQ ? Mqw : Mq, row_next), j);
     continue;
   }
   // phi tendency source in ONE array: W = cj (u phix + v phiy) + i cr phi q_psi  (cj = -1, cr = -1/2 in a step:
@@ -441,7 +485,7 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   F::template run<false>(acc, j, c, lds, twr);
   NQ_PHASE_FENCE();
   // first inputs of the next row block: requested before the stores so that they are not queued behind them
-  if (more) hs_load<N, P, T, MODE == MODE_COUPLED>(h1, xrow(Mq, row_next), xrow(MODE == MODE_COUPLED ? Mqw : Mq, row_next), j);
+  if (more) hs_load<N, P, T, PAIRQ>(h1, xrow(Mq, row_next), xrow(PAIRQ ? Mqw : Mq, row_next), j);
   {
     const XRow rp = xrow(Mw, row);
 #pragma unroll
@@ -833,7 +877,9 @@ k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict
            MArr Hqw, cd* __restrict__ qwh_out, cd* __restrict__ ph_out, YGeom g, double invM, double f,
            const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N,
            double* __restrict__ bud_part, const cd* __restrict__ q_bud, const cd* __restrict__ qh_minus,
-           const double* __restrict__ filt_m) {
+           const double* __restrict__ filt_m, const cd* __restrict__ c_hat) {
+  // MODE_QGC: c_hat (the passive scalar's spectrum) goes out through Hqw, and bud_part is [workgroup][6]: the three ep_psi
+  // sums, then sum w |c|^2 (without [0,0]), sum w wv2 |c|^2, sum w wv4 |c|^2 for ep_c (ref QGModel.py:595-598).
   // bud_part: [workgroup][3] Parseval sums for ep_psi (ref Kernel.py:635-640 / QGModel.py:588-593):
   //   sum w*wv4*Re(qb conj psi), sum w*wv2*Re(q conj psi), sum w*Re(qb conj psi); qb = q_bud (QGModel's
   //   stale q, QGModel.py:401) or q; w = 1 on the self-mirrored columns, 2 elsewhere.
@@ -848,7 +894,8 @@ k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict
   typename Y::F::Tw twr;
   Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
   double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
-  double s3[3] = {0.0, 0.0, 0.0};
+  double s3[3] = {0.0, 0.0, 0.0}, sc[3] = {0.0, 0.0, 0.0};
+  constexpr bool FOURTH = (MODE == MODE_COUPLED || MODE == MODE_QGC);
   cd a[P], b[P], u[P], q[P];
   if (MODE == MODE_COUPLED) {
 #pragma unroll
@@ -884,6 +931,16 @@ k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict
       psi = cmake(wv2i * (qw.x - qv.x), wv2i * (qw.y - qv.y));
     } else {
       psi = cmake(-wv2i * qv.x, -wv2i * qv.y);
+      if (MODE == MODE_QGC) {
+        qw = ok ? c_hat[idx] : cmake(0, 0);
+        if (bud_part && ok) {
+          const double wgt = (kg == 0 || kg == N / 2) ? 1.0 : 2.0;
+          const double m2 = wgt * (qw.x * qw.x + qw.y * qw.y);
+          sc[0] += (l == 0 && kg == 0) ? 0.0 : m2;
+          sc[1] += wv2 * m2;
+          sc[2] += wv2 * wv2 * m2;
+        }
+      }
     }
     if (ok && ph_out) {
       ph_out[idx] = psi;
@@ -924,7 +981,7 @@ k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict
   Y::F::template run<true>(u, j, c, lds, twr);
   Y::F::template run<true>(a, j, c, lds, twr);
   Y::F::template run<true>(q, j, c, lds, twr);
-  if (MODE == MODE_COUPLED) Y::F::template run<true>(b, j, c, lds, twr);
+  if (FOURTH) Y::F::template run<true>(b, j, c, lds, twr);
   if (ok) {
 #pragma unroll
     for (int t = 0; t < P; ++t) {
@@ -932,10 +989,12 @@ k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict
       Hu.ys[at] = u[t];
       Hp.ys[at] = a[t];
       Hq.ys[at] = q[t];
-      if (MODE == MODE_COUPLED) Hqw.ys[at] = b[t];
+      if (FOURTH) Hqw.ys[at] = b[t];
     }
   }
-  if (bud_part) block_sum_store<3>(s3, red, bud_part + 3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+  constexpr int NB = (MODE == MODE_QGC) ? 6 : 3;
+  if (bud_part) block_sum_store<3>(s3, red, bud_part + NB * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+  if (bud_part && MODE == MODE_QGC) block_sum_store<3>(sc, red, bud_part + NB * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 3);
 }
 
 }  // namespace nq

@@ -307,8 +307,8 @@ def test_exact_qh_option_tracks_the_nyquist_row_passenger(golden):
 def test_unsupported_options_fail_loudly():
     with pytest.raises(TypeError):
         models().QGModel.Model(nx=64, use_filter=False, dealias=True)     # the reference fails here too
-    with pytest.raises(NotImplementedError):
-        models().QGModel.Model(nx=64, passive_scalar=True)
+    with pytest.raises(RuntimeError):
+        models().QGModel.Model(nx=64).set_c(np.zeros((64, 64)))          # built without the passive scalar
     with pytest.raises(RuntimeError):
         models().CoupledModel.Model(nx=96)
     with pytest.raises(RuntimeError):
@@ -499,3 +499,26 @@ def test_ensemble_members_equal_individually_stepped_models():
         assert np.array_equal(m.phi, solo.phi) and np.array_equal(m.q, solo.q)
         assert np.allclose([m.Ke, m.Pw, m.Kw], [solo.Ke, solo.Pw, solo.Kw], rtol=1e-14)   # batched increments: last bit
     assert ens.member_steps() == 12
+
+
+@pytest.mark.parametrize("use_filter", [True, False])
+def test_qg_passive_scalar_against_the_reference(golden, use_filter):
+    """QGModel with passive_scalar=True through the reference itself (golden g10): q and c trajectories, Ke, cvar (the
+    device-side variance budget), and every diagnostics series with tdiags=1."""
+    g = golden("g10_qg_passive_64.npz")
+    key = "filter" if use_filter else "nofilter"
+    m = models().QGModel.Model(L=L, nx=64, tmax=19.5 * float(g["dt"]), dt=float(g["dt"]), twrite=10 ** 9,
+                               nu4=7.5e8 * 16, nu=5.0, mu=1e-8, use_filter=use_filter, U=-U0, tdiags=1, beta=2e-11,
+                               passive_scalar=True, nu4c=3e9, nuc=2.0, muc=1e-8)
+    m.set_q(g["q0"])
+    m.set_c(g["c0"])
+    m.run()
+    assert m.tc == 20
+    assert rel(m.q, g["q_" + key]) < 1e-11 and rel(m.qh, g["qh_" + key]) < 1e-11
+    assert rel(m.c, g["c_" + key]) < 1e-12 and rel(m.ch, g["ch_" + key]) < 1e-12
+    m._calc_derived_fields()
+    assert np.allclose([m.Ke, m.cvar, m.C2, m.gradC2], g["scalars_" + key], rtol=1e-10)
+    for name in m.diagnostics:
+        ref = g["diag_%s_%s" % (name, key)]
+        tol = 1e-7 if name == "Gamma_c" else 1e-8     # a nearly vanishing integral of rounding-sensitive terms
+        assert np.allclose(np.asarray(m.diagnostics[name]['value']), ref, rtol=tol, atol=1e-30), name

@@ -1003,6 +1003,8 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
     pp.model = NQ_MODEL_UNCOUPLED;
     pp.budgets = 0;
   }
+  if (pp.model == NQ_MODEL_QG && pp.passive_scalar != 0 && P != 1)
+    NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create_slab: QGModel's passive scalar is single-rank only");
   const nq_params* p = &pp;
   int S1, S2;
   if (!plan_for(p->nx, &S1, &S2)) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d unsupported (power of two in [64, 8192])", p->nx);

@@ -56,6 +56,8 @@ struct nq_ctx {
   // tables
   cd* tw = nullptr;
   int num_cu = 256;
+  cd *twx_half = nullptr;   // stage table of the N/2-point plan and the per-workgroup scratch rows of k_x_products_eo
+  cd *eo_scratch = nullptr;
   cd *twx = nullptr, *twx1 = nullptr;   // per-stage twiddle tables of the two row-kernel plans (WgFft::tw_off layout)
   double *kk = nullptr, *ll = nullptr, *filt_h = nullptr, *filt_f = nullptr;
   cd* contour = nullptr;
@@ -434,7 +436,7 @@ __global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums
 
 // ---------------------------------------------------------------------------------------------
 // size dispatch
-#define M_SMALL(M) M(64, 8, 8) M(128, 8, 16) M(256, 16, 16) M(512, 16, 32) M(1024, 32, 32) M(2048, 32, 64) M(8192, 64, 128)
+#define M_SMALL(M) M(64, 8, 8) M(128, 8, 16) M(256, 16, 16) M(512, 16, 32) M(1024, 32, 32) M(2048, 32, 64)
 #define NQ_FOR_SIZES(M) M(64, 8, 8) M(128, 8, 16) M(256, 16, 16) M(512, 16, 32) M(1024, 32, 32) M(2048, 32, 64) M(4096, 64, 64) M(8192, 64, 128)
 
 static bool plan_for(int N, int* S1, int* S2) {
@@ -618,6 +620,17 @@ static void launch_wavepv(nq_ctx* c) {
   ProfScope ps(c, PK_WAVEPV);
   switch (c->N) {
 #define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx1, c->kk); } break;
+    case 8192:
+      if (c->eo_scratch) {                            // even / odd samples as two 4096-point problems (no spills)
+        typedef XPlan<4096> X;
+        const int nb = c->Nloc, grid = nb < c->num_cu ? nb : c->num_cu;
+        const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd);
+        hipLaunchKernelGGL((k_x_wavepv_eo<8192>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx_half, c->tw, c->kk, nb, c->eo_scratch);
+      } else {
+        typedef XPlan1<8192> X;
+        hipLaunchKernelGGL((k_x_wavepv<8192>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx1, c->kk);
+      }
+      break;
     case 4096: {                                      // long rows: two transforms in flight, no spills
       typedef XPlan<4096> X;
       const size_t ldsb = X::LDS_BYTES + X::F::LDS_ELEMS * sizeof(cd);
@@ -631,6 +644,16 @@ static void launch_wavepv(nq_ctx* c) {
 template <int MODE>
 static void launch_products_m(nq_ctx* c, double cj, double cr, bool fresh_grad) {
   const int vz = c->kernel_family ? 1 : 0;
+  if (c->N == 8192 && MODE != MODE_QGC && c->eo_scratch) {
+    // rows too long for the register budget as one transform: even / odd samples as two 4096-point problems
+    typedef XPlan<4096> X;
+    const MArr& gx8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGx : c->mPhi;
+    const MArr& gy8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGy : c->mPhiy;
+    const int nb = c->Nloc, grid = nb < c->num_cu ? nb : c->num_cu;
+    const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd);
+    hipLaunchKernelGGL((k_x_products_eo<8192, MODE>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx8, gy8, c->mUq, c->mVq, c->mW, c->twx_half, c->tw, c->kk, vz, cj, cr, nb, c->eo_scratch);
+    return;
+  }
   const MArr& gx = (MODE == MODE_QGC) ? c->mUc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGx : c->mPhi);
   const MArr& gy = (MODE == MODE_QGC) ? c->mVc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGy : c->mPhiy);
   switch (c->N) {
@@ -1095,6 +1118,26 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
       ALLOC(c, dst, st.size() / 2 + 1);
       HIPCHK(c, hipMemcpyAsync(dst, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (N == 8192) {
+      // k_x_products_eo: stage table of the 4096-point plan (its own twiddles: exp(-2 pi i m / 4096) = twh[2m])
+      const int Mh = N / 2, PP = XPlan<8>::pts(Mh);
+      std::vector<double> st;
+      for (int sidx = 1; sidx < plan_stages(Mh, PP); ++sidx) {
+        const int R = plan_radix(Mh, PP, sidx), NS = plan_ns(Mh, PP, sidx);
+        for (int pw = 1; pw <= 8; pw *= (pw == 1 ? 4 : 2)) {
+          if ((pw == 4 && plan_tw_rows(Mh, PP, R) < 2) || (pw == 8 && plan_tw_rows(Mh, PP, R) < 3)) continue;
+          for (int jr = 0; jr < NS; ++jr) {
+            const long long m = ((long long)pw * jr * (Mh / (NS * R))) % Mh;
+            st.push_back(twh[2 * (2 * m)]);
+            st.push_back(twh[2 * (2 * m) + 1]);
+          }
+        }
+      }
+      ALLOC(c, c->twx_half, st.size() / 2 + 1);
+      HIPCHK(c, hipMemcpyAsync(c->twx_half, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      ALLOC(c, c->eo_scratch, (size_t)c->num_cu * 2 * Mh);
     }
     ALLOC(c, c->kk, (size_t)N);
     ALLOC(c, c->ll, (size_t)N);

@@ -499,6 +499,351 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   }   // row blocks
 }
 
+// ---- X2 for rows of 2M points that do not fit the register budget as one transform ------------------------
+// An 8192-point row with 8 points per thread needs 1024 threads, i.e. 128 VGPRs: k_x_products then spills 700 B per
+// lane.  But every physical-space operation of this kernel is pointwise, so the even and the odd samples of a row can
+// be processed as two independent problems of M = 4096 points with the 4096 plan (512 threads, 256 VGPRs):
+//     x[2m]   = ifft_M( X[k] + X[k+M] )[m],          x[2m+1] = ifft_M( (X[k] - X[k+M]) w^k )[m],   w = exp(2 pi i / 2M)
+//     Y[k]    = E[k] + conj(w^k) O[k],               Y[k+M]  = E[k] - conj(w^k) O[k],   E, O = fft_M(y_even), fft_M(y_odd)
+// The even pass parks its two output spectra (the packed (uq, vq) pair and W) in a per-workgroup scratch row in global
+// memory (L2-resident); the odd pass combines, splits the pair into its two half spectra and stores.  Inputs are read
+// once per pass (the second time from L2).  LDS: exchange area + stage twiddles of the M plan + the w^k table.
+template <int M, int P, int T, bool PAIR>
+__device__ __forceinline__ void eo_fold_pair(cd (&w)[P], const XRow& rowA, const XRow& rowB, int j, int par,
+                                             const cd* __restrict__ wtab, const double* __restrict__ kk, bool b_mul_ik,
+                                             bool b_zero_nyq, double b_scale) {
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int k = j + t * T, km = (k == 0) ? M : M - k;
+    cd a1 = *rowA.at(k), a2 = *rowA.at(km);
+    cd b1 = PAIR ? *rowB.at(k) : cmake(0, 0), b2 = PAIR ? *rowB.at(km) : cmake(0, 0);
+    if (PAIR && b_mul_ik) {
+      b1 = cscale(cmul_i(b1), kk[k]);
+      b2 = cscale(cmul_i(b2), kk[km]);
+    }
+    b1 = cscale(b1, b_scale);
+    b2 = cscale(b2, b_scale);
+    cd z1, z2;
+    if (k == 0) {                 // the two self-mirrored entries Z[0], Z[M]: imaginary parts of a, b dropped (hs_pack)
+      if (b_zero_nyq) b2.x = 0.0;
+      z1 = cmake(a1.x, b1.x);
+      z2 = cmake(a2.x, b2.x);
+    } else {
+      z1 = cmake(a1.x - b1.y, a1.y + b1.x);             // Z[k]   = a + i b
+      z2 = cmake(a2.x + b2.y, b2.x - a2.y);             // Z[k+M] = conj(a[M-k]) + i conj(b[M-k])
+    }
+    w[t] = (par == 0) ? cadd(z1, z2) : cmul(cmake(z1.x - z2.x, z1.y - z2.y), wtab[k]);
+  }
+}
+template <int M, int P, int T>
+__device__ __forceinline__ void eo_fold_full(cd (&w)[P], const XRow& row, int j, int par, const cd* __restrict__ wtab,
+                                             const double* __restrict__ kk, bool mul_ik) {
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int k = j + t * T;
+    cd x1 = *row.at(k), x2 = *row.at(k + M);
+    if (mul_ik) {
+      x1 = cscale(cmul_i(x1), kk[k]);
+      x2 = cscale(cmul_i(x2), kk[k + M]);
+    }
+    w[t] = (par == 0) ? cadd(x1, x2) : cmul(cmake(x1.x - x2.x, x1.y - x2.y), wtab[k]);
+  }
+}
+// the same in two steps, so that the loads can be issued a phase ahead (and one row serve two folds)
+template <int M, int P, int T>
+__device__ __forceinline__ void eo_load_full(cd (&x1)[P], cd (&x2)[P], const XRow& row, int j) {
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    x1[t] = *row.at(j + t * T);
+    x2[t] = *row.at(j + t * T + M);
+  }
+}
+template <int M, int P, int T>
+__device__ __forceinline__ void eo_fold_regs(cd (&w)[P], const cd (&x1)[P], const cd (&x2)[P], int j, int par,
+                                             const cd* __restrict__ wtab, const double* __restrict__ kk, bool mul_ik) {
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int k = j + t * T;
+    cd a = x1[t], b = x2[t];
+    if (mul_ik) {
+      a = cscale(cmul_i(a), kk[k]);
+      b = cscale(cmul_i(b), kk[k + M]);
+    }
+    w[t] = (par == 0) ? cadd(a, b) : cmul(cmake(a.x - b.x, a.y - b.y), wtab[k]);
+  }
+}
+// odd pass: r = O; scratch = E; writes the two half spectra of the packed pair
+template <int M, int P, int T, typename F>
+__device__ __forceinline__ void eo_unpack_pair_store(cd (&r)[P], int j, int c, cd* lds, const cd* __restrict__ escr,
+                                                     const cd* __restrict__ wtab, const XRow& rowA, const XRow& rowB,
+                                                     double scaleB = 1.0) {
+  wg_barrier();
+#pragma unroll
+  for (int t = 0; t < P; ++t) lds[F::lds_index(j + t * T, c)] = r[t];
+  wg_barrier();
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int k = j + t * T;
+    const cd e1 = escr[k], w1 = wtab[k];
+    const cd o1 = cmul(cmake(w1.x, -w1.y), r[t]);
+    const cd y = cadd(e1, o1);
+    cd ym;
+    if (k == 0) {
+      ym = y;                                                  // Y[2M] = Y[0]
+      const cd yM = cmake(e1.x - o1.x, e1.y - o1.y);           // Y[M] = E[0] - O[0], its own mirror
+      *rowA.at(M) = cmake(yM.x, 0.0);
+      *rowB.at(M) = cmake(scaleB * yM.y, 0.0);
+    } else {
+      const int km = M - k;
+      const cd e2 = escr[km], w2 = wtab[km];
+      const cd o2 = cmul(cmake(w2.x, -w2.y), lds[F::lds_index(km, c)]);
+      ym = cmake(e2.x - o2.x, e2.y - o2.y);                    // Y[2M - k] = E[M-k] - conj(w^(M-k)) O[M-k]
+    }
+    *rowA.at(k) = cmake(0.5 * (y.x + ym.x), 0.5 * (y.y - ym.y));
+    *rowB.at(k) = cmake(scaleB * 0.5 * (y.y + ym.y), scaleB * 0.5 * (ym.x - y.x));
+  }
+  wg_barrier();
+}
+
+template <int N2, int MODE>
+__global__ void __launch_bounds__(XPlan<N2 / 2>::THREADS, XPlan<N2 / 2>::MIN_WAVES)
+k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy, MArr Muq, MArr Mvq, MArr Mw,
+                const cd* __restrict__ tw, const cd* __restrict__ wglob, const double* __restrict__ kk, int v_zero_nyq,
+                double cj, double cr, int nblocks, cd* __restrict__ scratch) {
+  constexpr int M = N2 / 2;
+  typedef XPlan<M> X;
+  typedef typename X::F F;
+  constexpr int P = X::P, T = X::T;
+  static_assert(X::C == 1, "one row per workgroup");
+  const int j_tid = threadIdx.x;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd* twl = lds + F::LDS_ELEMS;
+  cd* wtab = twl + F::TW_LDS_ELEMS;                      // w^k = exp(+2 pi i k / N2), k < M
+  for (int i = threadIdx.x; i < F::TW_LDS_ELEMS; i += X::THREADS) twl[i] = tw[i];
+  for (int i = threadIdx.x; i < M; i += X::THREADS) {
+    const cd z = wglob[i];                               // global table holds exp(-2 pi i m / N2)
+    wtab[i] = cmake(z.x, -z.y);
+  }
+  typename F::TwLds twr;
+  twr.base = twl;
+  wg_barrier_all();
+  double* red = reinterpret_cast<double*>(wtab + M);
+  cd* escr_p = scratch + (size_t)blockIdx.x * 2 * M;     // E of the packed pair, then E of W
+  cd* escr_w = escr_p + M;
+  constexpr bool PAIRQ = (MODE == MODE_COUPLED || MODE == MODE_QGC);
+  constexpr bool ONLYQ = (MODE == MODE_QG || MODE == MODE_QGC);
+  for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+    int j = j_tid, c = 0;
+    asm volatile("" : "+v"(j), "+v"(c));
+    const size_t row = (size_t)rb;
+    double js[2] = {0.0, 0.0};
+#pragma unroll 1
+    for (int par_i = 0; par_i < 2; ++par_i) {
+      // the scratch row is written by this workgroup in the even pass and read back by it in the odd pass (and
+      // rewritten for the next row after that): order the two with a workgroup-scope fence and barrier
+      __threadfence_block();
+      __syncthreads();
+      int par = par_i;
+      asm volatile("" : "+s"(par), "+v"(j), "+v"(c));     // nothing of a pass may be hoisted or shared with the other
+      cd w[P];
+      double q[P], qpsi[P], u[P], v[P];
+      eo_fold_pair<M, P, T, PAIRQ>(w, xrow(Mq, row), xrow(PAIRQ ? Mqw : Mq, row), j, par, wtab, kk, false, false, 1.0);
+      NQ_PHASE_FENCE();
+      F::template run<true>(w, j, c, lds, twr);
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        q[t] = w[t].x;
+        qpsi[t] = (MODE == MODE_COUPLED) ? w[t].x - w[t].y : (MODE == MODE_QGC ? w[t].y : w[t].x);
+      }
+      NQ_PHASE_FENCE();
+      eo_fold_pair<M, P, T, true>(w, xrow(Mu, row), xrow(Mp, row), j, par, wtab, kk, true, v_zero_nyq != 0, 1.0);
+      NQ_PHASE_FENCE();
+      F::template run<true>(w, j, c, lds, twr);
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        u[t] = w[t].x;
+        v[t] = w[t].y;
+        w[t] = cmake(u[t] * q[t], v[t] * q[t]);
+      }
+      NQ_PHASE_FENCE();
+      F::template run<false>(w, j, c, lds, twr);
+      NQ_PHASE_FENCE();
+      if (par == 0) {
+#pragma unroll
+        for (int t = 0; t < P; ++t) escr_p[j + t * T] = w[t];
+      } else {
+        eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr_p, wtab, xrow(Muq, row), xrow(Mvq, row));
+      }
+      if (ONLYQ) {
+        if (MODE == MODE_QGC) {
+          NQ_PHASE_FENCE();
+          // second packed pair (u c, v c); the even pass parks it in the W slot of the scratch row
+#pragma unroll
+          for (int t = 0; t < P; ++t) w[t] = cmake(u[t] * qpsi[t], v[t] * qpsi[t]);
+          NQ_PHASE_FENCE();
+          F::template run<false>(w, j, c, lds, twr);
+          NQ_PHASE_FENCE();
+          if (par == 0) {
+#pragma unroll
+            for (int t = 0; t < P; ++t) escr_w[j + t * T] = w[t];
+          } else {
+            eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr_w, wtab, xrow(Mgx, row), xrow(Mgy, row));
+          }
+        }
+        continue;
+      }
+      if constexpr (!ONLYQ) {
+      // (requesting the full-width rows a phase ahead costs 64 VGPRs: the spills it causes eat the gain -- measured)
+      NQ_PHASE_FENCE();
+      eo_fold_full<M, P, T>(w, xrow(Mphi, row), j, par, wtab, kk, false);
+      NQ_PHASE_FENCE();
+      F::template run<true>(w, j, c, lds, twr);
+      cd acc[P];
+#pragma unroll
+      for (int t = 0; t < P; ++t) acc[t] = cmake(-cr * qpsi[t] * w[t].y, cr * qpsi[t] * w[t].x);
+      NQ_PHASE_FENCE();
+      eo_fold_full<M, P, T>(w, xrow(MODE == MODE_COUPLED ? Mphi : Mgx, row), j, par, wtab, kk, true);
+      NQ_PHASE_FENCE();
+      F::template run<true>(w, j, c, lds, twr);
+#pragma unroll
+      for (int t = 0; t < P; ++t) w[t] = cscale(w[t], u[t]);
+      cd pre[P];
+      NQ_PHASE_FENCE();
+      eo_fold_full<M, P, T>(pre, xrow(Mgy, row), j, par, wtab, kk, false);
+      NQ_PHASE_FENCE();
+      F::template run<true>(pre, j, c, lds, twr);
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        const cd J = cmake(w[t].x + pre[t].x * v[t], w[t].y + pre[t].y * v[t]);
+        js[0] += J.x;
+        js[1] += J.y;
+        acc[t] = cmake(acc[t].x + cj * J.x, acc[t].y + cj * J.y);
+      }
+      NQ_PHASE_FENCE();
+      F::template run<false>(acc, j, c, lds, twr);
+      NQ_PHASE_FENCE();
+      if (par == 0) {
+#pragma unroll
+        for (int t = 0; t < P; ++t) escr_w[j + t * T] = acc[t];
+      } else {
+        const XRow rp = xrow(Mw, row);
+#pragma unroll
+        for (int t = 0; t < P; ++t) {
+          const int k = j + t * T;
+          const cd e = escr_w[k], w1 = wtab[k];
+          const cd o = cmul(cmake(w1.x, -w1.y), acc[t]);
+          *rp.at(k) = cadd(e, o);
+          *rp.at(k + M) = cmake(e.x - o.x, e.y - o.y);
+        }
+      }
+      }   // !ONLYQ
+    }
+    if (!ONLYQ) {
+      NQ_PHASE_FENCE();
+      block_sum_store<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)rb * Muq.pitch + Muq.W));
+    }
+  }
+}
+
+// wave-PV sources for rows of 2M points, even / odd samples as two M-point problems (see k_x_products_eo)
+template <int N2>
+__global__ void __launch_bounds__(XPlan<N2 / 2>::THREADS, XPlan<N2 / 2>::MIN_WAVES)
+k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, const cd* __restrict__ wglob,
+              const double* __restrict__ kk, int nblocks, cd* __restrict__ scratch) {
+  constexpr int M = N2 / 2;
+  typedef XPlan<M> X;
+  typedef typename X::F F;
+  constexpr int P = X::P, T = X::T;
+  static_assert(X::C == 1, "one row per workgroup");
+  const int j_tid = threadIdx.x;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd* twl = lds + F::LDS_ELEMS;
+  cd* wtab = twl + F::TW_LDS_ELEMS;
+  for (int i = threadIdx.x; i < F::TW_LDS_ELEMS; i += X::THREADS) twl[i] = tw[i];
+  for (int i = threadIdx.x; i < M; i += X::THREADS) {
+    const cd z = wglob[i];
+    wtab[i] = cmake(z.x, -z.y);
+  }
+  typename F::TwLds twr;
+  twr.base = twl;
+  wg_barrier_all();
+  unsigned long long* mx = reinterpret_cast<unsigned long long*>(wtab + M);
+  cd* escr = scratch + (size_t)blockIdx.x * 2 * M;
+  // raw rows are requested one phase ahead: phi's row (it serves both phi and phix) before the forward transform and
+  // the stores of the previous pass, phiy's row before the first two inverse transforms
+  cd r1[P], r2[P];
+  eo_load_full<M, P, T>(r1, r2, xrow(Mphi, (size_t)blockIdx.x), j_tid);
+  for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+    int j = j_tid, c = 0;
+    const size_t row = (size_t)rb;
+    const bool more = rb + (int)gridDim.x < nblocks;
+    int e_scale = 0;                     // power-of-two rescale of the second field: chosen in the even pass, used in both
+#pragma unroll 1
+    for (int par_i = 0; par_i < 2; ++par_i) {
+      __threadfence_block();
+      __syncthreads();
+      int par = par_i;
+      asm volatile("" : "+s"(par), "+v"(j), "+v"(c));
+      cd w[P], gx[P];
+      double a[P];
+      eo_fold_regs<M, P, T>(w, r1, r2, j, par, wtab, kk, false);
+      eo_fold_regs<M, P, T>(gx, r1, r2, j, par, wtab, kk, true);
+      eo_load_full<M, P, T>(r1, r2, xrow(Mphiy, row), j);          // in flight during the next two transforms
+      NQ_PHASE_FENCE();
+      F::template run<true>(w, j, c, lds, twr);
+      double ma = 0.0, mb = 0.0;
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        a[t] = w[t].x * w[t].x + w[t].y * w[t].y;
+        ma = fmax(ma, a[t]);
+      }
+      NQ_PHASE_FENCE();
+      F::template run<true>(gx, j, c, lds, twr);
+      NQ_PHASE_FENCE();
+      eo_fold_regs<M, P, T>(w, r1, r2, j, par, wtab, kk, false);
+      // phi's row again: for the odd pass of this row, or for the next row of this workgroup
+      if (par == 0) eo_load_full<M, P, T>(r1, r2, xrow(Mphi, row), j);
+      else if (more) eo_load_full<M, P, T>(r1, r2, xrow(Mphi, row + gridDim.x), j);
+      NQ_PHASE_FENCE();
+      F::template run<true>(w, j, c, lds, twr);
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        const double b = -2.0 * (gx[t].x * w[t].y - gx[t].y * w[t].x);
+        mb = fmax(mb, fabs(b));
+        w[t] = cmake(a[t], b);
+      }
+      if (par == 0) {
+        if (j == 0) {
+          mx[0] = 0ull;
+          mx[1] = 0ull;
+        }
+        wg_barrier();
+        atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
+        atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
+        wg_barrier();
+        ma = __longlong_as_double((long long)mx[0]);
+        mb = __longlong_as_double((long long)mx[1]);
+        int e = 0;
+        if (ma > 0.0 && mb > 0.0) e = ilogb(ma) - ilogb(mb);
+        e_scale = e > 900 ? 900 : (e < -900 ? -900 : e);
+      }
+      const double sb = ldexp(1.0, e_scale);
+#pragma unroll
+      for (int t = 0; t < P; ++t) w[t].y *= sb;
+      NQ_PHASE_FENCE();
+      F::template run<false>(w, j, c, lds, twr);
+      NQ_PHASE_FENCE();
+      if (par == 0) {
+#pragma unroll
+        for (int t = 0; t < P; ++t) escr[j + t * T] = w[t];
+      } else {
+        // split into the two half spectra; the second carries the factor sb, undone here by scaling its rows
+        eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr, wtab, xrow(Ma, row), xrow(Mb, row), ldexp(1.0, -e_scale));
+      }
+    }
+  }
+}
+
 // ---- diagnostics tick: physical-space statistics (ref Kernel.py:613-623 conc, skew; :701 pi) ----------------
 // One row block: q, q_psi from the (q, qw) half-spectrum pair, phi from its mixed-space row; eight sums per
 // workgroup -> part[workgroup][8]:

@@ -32,6 +32,14 @@ TE = 1.0 / (U0 * K0)
 CANONICAL_B_PER_PT_STEP = {"coupled": 3136, "uncoupled": 2240, "qg": 848}
 X_PRODUCTS_B_PER_PT = {"coupled": 4 * 8 + 2 * 16 + 2 * 8 + 16, "uncoupled": 3 * 8 + 3 * 16 + 2 * 8 + 16,
                        "qg": 3 * 8 + 2 * 8}
+# algorithmic bytes per grid point and LAUNCH of the other fused kernels of the CoupledModel step:
+#  s_phi: tendency in 16, phi and phi_y out 32, ETDRK4 state + coefficient planes 80/80/112/128 in the four stages
+#         (mean 100), start-of-stage phih for the budget projections 12 (3 of 4 stages)
+#  x_wavepv: phi, phi_y rows in 32, two half-spectrum rows out 16;  s_q: 2 half rows in 16, state + coefficients 50;
+#  s_invert: 2 half rows in 16, q-hat 8, filter 4, four half rows out 32, psi-hat and qw-hat stored in the last stage 4
+KERNEL_B_PER_PT = {"coupled": {"x_products": 96.0, "s_phi": 160.0, "x_wavepv": 48.0, "s_q": 66.0, "s_invert": 64.0}}
+KERNEL_SYMBOL = {"x_products": "k_x_products", "s_phi": "k_s_phi", "x_wavepv": "k_x_wavepv", "s_q": "k_s_q",
+                 "s_invert": "k_s_invert", "y_A": "k_y_A"}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -82,7 +90,8 @@ class _SlabCtxView(object):
         self.r, self.L, self.h = rank, rank.L, rank.h
         self.budgets_enabled = rank.budgets
         self.KERNEL_CLASSES = _lib.Context.KERNEL_CLASSES
-        for name in ("sync", "timer_start", "timer_stop", "profile_enable", "profile_read", "device_bytes", "_chk"):
+        for name in ("sync", "timer_start", "timer_stop", "profile_enable", "profile_read", "profile_read_all",
+                     "device_bytes", "_chk"):
             setattr(self, name, getattr(_lib.Context, name).__get__(self))
 
 
@@ -256,7 +265,8 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    ctx.profile_enable(ctx.KERNEL_CLASSES["x_products"])
+    per_class = hasattr(ctx, "profile_read_all")
+    ctx.profile_enable(-2 if per_class else ctx.KERNEL_CLASSES["x_products"])      # HIP events around every launch
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
@@ -264,7 +274,12 @@ def main():
     dev_ms = ctx.timer_stop()
     barrier()
     wall = time.perf_counter() - t0
-    launches, kms = ctx.profile_read()
+    classes = None
+    if per_class:
+        classes = ctx.profile_read_all()
+        launches, kms = classes["x_products"]
+    else:
+        launches, kms = ctx.profile_read()
     ctx.profile_enable(-1)
     if sim is not None:
         # strong scaling: all ranks advance the SAME simulation; whole-job steps/s = steps / slowest rank
@@ -299,8 +314,17 @@ def main():
 
     if rank == 0:
         npts = float(args.nx) ** 2
+        # the roofline object describes the DOMINANT kernel of the timed region: the class with the largest total time
+        # among those whose algorithmic bytes are tabulated (the A sub-passes are separate launches of 0.1-0.2 ms each)
+        dom = "x_products"
+        table = KERNEL_B_PER_PT.get(args.model, {})
+        if classes:
+            cands = [k for k in classes if k in table and classes[k][0] > 0]
+            if cands:
+                dom = max(cands, key=lambda k: classes[k][1])
+                launches, kms = classes[dom]
         k_ms = kms / max(launches, 1)
-        k_bytes = X_PRODUCTS_B_PER_PT[args.model] * npts
+        k_bytes = (table[dom] if dom in table else X_PRODUCTS_B_PER_PT[args.model]) * npts
         if sim is not None:
             k_bytes /= world                       # each rank's launch covers nx/world rows
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
@@ -316,11 +340,13 @@ def main():
                        "parallelism": mode, "slab_fallback_reason": slab_error,
                        "device_ms_per_step_hip_events": dev_ms / args.steps,
                        "device_bytes": ctx.device_bytes(), **extra},
-            "roofline": {"bound": "hbm", "kernel": "k_x_products", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("k_x_products<%d, %d" % (args.nx, {"coupled": 0, "uncoupled": 1, "qg": 2}[args.model]))
-                         if (ctx.budgets_enabled and sim is None) else None,
+                         "traffic": measured_traffic(KERNEL_SYMBOL[dom] + "<") if (ctx.budgets_enabled and sim is None and args.nx == 4096) else None,
                          "launches": launches, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
+                         "per_kernel_ms_per_step": ({k: round(v[1] / args.steps, 4) for k, v in classes.items()} if classes else None),
+                         "per_kernel_frac_of_peak": ({k: round(table[k] * npts / (world if sim is not None else 1) / (classes[k][1] / classes[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                      for k in table if classes and classes[k][0] > 0} if classes else None),
                          "step_canonical_bytes": step_bytes,
                          "step_achieved_GBs": step_bytes / (wall / args.steps) / 1e9,
                          "step_frac_of_peak": step_bytes / (wall / args.steps) / 1e9 / (HBM_PEAK_GBS * (world if sim is not None else 1))},

@@ -178,8 +178,9 @@ int nq_timer_stop(nq_ctx* ctx, float* elapsed_ms);
 /* Per-kernel timing with HIP events on the context's stream.  While enabled, every launch of the
  * selected kernel class inside nq_step is bracketed by an event pair (cost ~2 us per launch).
  * class: 0 x_products, 1 x_wavepv, 2 s_q, 3 s_phi, 4 s_invert, 5 y_A (all A sub-passes)              */
-int nq_profile_enable(nq_ctx* ctx, int kernel_class);     /* -1 disables */
+int nq_profile_enable(nq_ctx* ctx, int kernel_class);     /* -1 disables, -2 brackets every class */
 int nq_profile_read(nq_ctx* ctx, int* launches, float* total_ms);   /* synchronises, then resets */
+int nq_profile_read_all(nq_ctx* ctx, int* launches6, float* total_ms6);   /* per class, after nq_profile_enable(-2) */
 /* bytes of device memory held by the context */
 long long nq_device_bytes(const nq_ctx* ctx);
 /* stream handle (hipStream_t) so that callers can order their own work */

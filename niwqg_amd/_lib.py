@@ -27,7 +27,7 @@ COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
            "nq_step", "nq_sync", "nq_get_field", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
            "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_get_coeff", "nq_diagnostics",
-           "nq_timer_start", "nq_timer_stop", "nq_profile_enable", "nq_profile_read", "nq_group_elems", "nq_create_slab",
+           "nq_timer_start", "nq_timer_stop", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
            "nq_reduce_buffer", "nq_device_bytes", "nq_stream"]
 
@@ -92,6 +92,7 @@ def lib():
     L.nq_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.nq_profile_enable.argtypes = [vp, ctypes.c_int]
     L.nq_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)]
+    L.nq_profile_read_all.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)]
     L.nq_group_elems.argtypes = [ctypes.POINTER(Params), ctypes.c_int, ctypes.c_int]
     L.nq_group_elems.restype = ctypes.c_longlong
     L.nq_create_slab.argtypes = [ctypes.POINTER(Params), dp, dp, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -277,6 +278,12 @@ class Context:
         n, ms = ctypes.c_int(), ctypes.c_float()
         self._chk(self.L.nq_profile_read(self.h, ctypes.byref(n), ctypes.byref(ms)), "nq_profile_read")
         return n.value, ms.value
+
+    def profile_read_all(self):
+        """{class name: (launches, total ms)} after profile_enable(-2)"""
+        n, ms = (ctypes.c_int * 6)(), (ctypes.c_float * 6)()
+        self._chk(self.L.nq_profile_read_all(self.h, n, ms), "nq_profile_read_all")
+        return {name: (n[k], ms[k]) for name, k in self.KERNEL_CLASSES.items()}
 
     def device_bytes(self):
         return int(self.L.nq_device_bytes(self.h))

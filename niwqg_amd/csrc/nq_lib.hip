@@ -98,6 +98,7 @@ struct nq_ctx {
   double* bsums = nullptr;                        // [4 stages][11] reduced sums of one step
   int prof_class = -1;
   std::vector<hipEvent_t> prof_ev;               // pairs
+  std::vector<int> prof_cls;                     // kernel class of each pair
   size_t prof_used = 0;
   bool have_q = false, have_phi = false;
   bool ybj = false;
@@ -451,7 +452,7 @@ enum { PK_PRODUCTS = 0, PK_WAVEPV = 1, PK_SQ = 2, PK_SPHI = 3, PK_INVERT = 4, PK
 struct ProfScope {
   nq_ctx* c;
   bool on;
-  ProfScope(nq_ctx* c_, int cls) : c(c_), on(c_->prof_class == cls) {
+  ProfScope(nq_ctx* c_, int cls) : c(c_), on(c_->prof_class == cls || c_->prof_class == -2) {   // -2: every class
     if (!on) return;
     if (c->prof_used + 2 > c->prof_ev.size()) {
       for (int i = 0; i < 2; ++i) {
@@ -460,6 +461,8 @@ struct ProfScope {
         c->prof_ev.push_back(e);
       }
     }
+    if (c->prof_cls.size() < c->prof_ev.size() / 2) c->prof_cls.resize(c->prof_ev.size() / 2);
+    c->prof_cls[c->prof_used / 2] = cls;
     (void)hipEventRecord(c->prof_ev[c->prof_used], c->stream);
   }
   ~ProfScope() {
@@ -1326,6 +1329,27 @@ int nq_profile_read(nq_ctx* c, int* launches, float* total_ms) {
   }
   *launches = (int)(c->prof_used / 2);
   *total_ms = tot;
+  c->prof_used = 0;
+  return 0;
+}
+
+int nq_profile_read_all(nq_ctx* c, int* launches6, float* total_ms6) {
+  if (!c || !launches6 || !total_ms6) return -1;
+  int rc = nq_sync(c);
+  if (rc) return rc;
+  for (int k = 0; k < 6; ++k) {
+    launches6[k] = 0;
+    total_ms6[k] = 0.f;
+  }
+  for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]));
+    const int k = c->prof_cls[i / 2];
+    if (k >= 0 && k < 6) {
+      launches6[k] += 1;
+      total_ms6[k] += ms;
+    }
+  }
   c->prof_used = 0;
   return 0;
 }

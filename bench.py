@@ -122,7 +122,7 @@ def build_slab(model, nx, grp, local_rank):
         phys.update(f=kw["f"], kappa2=kappa2, nuw=kw["nuw"], nu4w=kw["nu4w"], muw=kw["muw"])
     ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], grp.world, device=local_rank, only_rank=grp.rank,
                             budgets=True, **phys)
-    sim = slab.SlabSimulation(ranks, slab.TorchTransport(grp.dist))
+    sim = slab.SlabSimulation(ranks, slab.TorchTransport(grp.dist, stage_via_host=(getattr(grp, "backend", "") == "gloo")))
     if model == "qg" and nx == 2048:
         q = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx))
     else:
@@ -222,6 +222,7 @@ def main():
     import torch
     grp = Group(force=args.force_slab)   # nccl (= RCCL) when launched with WORLD_SIZE > 1
     rank, world, local_rank = grp.rank, grp.world, grp.local_rank
+    local_rank %= max(torch.cuda.device_count(), 1)      # gloo rehearsal: several ranks share the one GPU of the box
     torch.cuda.set_device(local_rank)
 
     if args.members > 0:

@@ -21,7 +21,9 @@ class Group(object):
             import torch
             import torch.distributed as dist
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # NIWQG_AMD_DIST_BACKEND=gloo: rehearse the multi-process path with several ranks on ONE GPU (RCCL
+                # refuses two ranks per device); the slab transport then stages its buffers through the host
+                backend = os.environ.get("NIWQG_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             kw = {}
             if backend == "nccl":
                 self.device = torch.device("cuda", self.local_rank)

@@ -190,3 +190,28 @@ def test_config4_8192_on_8_virtual_ranks_against_the_oracle():
     o0.set_q(q0)
     o0.set_phi(phi0)
     assert np.allclose(inc, [o.Ke - o0.Ke, o.Pw - o0.Pw, o.Kw - o0.Kw], rtol=1e-8, atol=1e-30)
+
+
+def test_bench_contract_with_two_ranks_rehearsed_over_gloo():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), with both
+    ranks on the one GPU of the test box and the collectives staged through gloo (NIWQG_AMD_DIST_BACKEND): the slab
+    set-up, the all-ranks agreement, barrier + max-over-ranks timing and the single JSON line of rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIWQG_AMD_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "256"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["slab_fallback_reason"] is None and "slab x2" in d["config"]["parallelism"]
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert "cpu_baseline" not in d                     # rank 0 at N = 1 only

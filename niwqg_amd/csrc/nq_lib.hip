@@ -101,6 +101,11 @@ struct nq_ctx {
   std::vector<int> prof_cls;                     // kernel class of each pair
   size_t prof_used = 0;
   bool have_q = false, have_phi = false;
+  // single-rank CoupledModel: the q update (memory-bound) runs on a second stream beside the wave-PV row kernel
+  // (transform-engine bound), which then leaves `overlap_cus` CUs free for it (0 = off)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int overlap_cus = 0;
   bool ybj = false;
   bool passive = false;  // QGModel with its passive scalar: state cq, spectrum emitted through the qw slots of G3 / G0
   EqState cq;
@@ -637,7 +642,9 @@ static void launch_wavepv(nq_ctx* c) {
     case 4096: {                                      // long rows: two transforms in flight, no spills
       typedef XPlan<4096> X;
       const size_t ldsb = X::LDS_BYTES + X::F::LDS_ELEMS * sizeof(cd);
-      const int nb = c->Nloc / X::C, grid = nb < c->num_cu ? nb : c->num_cu;      // one persistent workgroup per CU
+      int grid = c->num_cu - (c->stream2 ? c->overlap_cus : 0);                    // one persistent workgroup per CU
+      const int nb = c->Nloc / X::C;
+      if (grid > nb) grid = nb;
       hipLaunchKernelGGL((k_x_wavepv2<4096>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx, c->kk, nb);
     } break;
     M_SMALL(CASE_)
@@ -905,8 +912,39 @@ static void do_step_ybj(nq_ctx* c) {
   }
 }
 
+// CoupledModel, one rank: same kernels as do_step, but the q update waits until the wave-PV row kernel starts and
+// runs beside it on a second stream.  k_x_wavepv2 is bound by its row transforms and uses a persistent grid of
+// (CUs - overlap_cus) workgroups; the spectral q kernels need 34 KB of LDS, which only the CUs it left free can give.
+static void do_step_overlap(nq_ctx* c) {
+  hipStream_t main_stream = c->stream;
+  for (int s = 0; s < 4; ++s) {
+    phase_products(c, s);
+    int qslot = 0, wslot = 0;
+    launch_A_m(c, false, {&c->mW});
+    const int cur = c->w.cur;
+    const cd* y_start = (s == 0) ? c->w.y[cur] : (s == 1 ? c->w.y[(cur + 1) % 3] : c->w.y[(cur + 2) % 3]);
+    EtdArrays ew = etd_arrays(c->w, s, &wslot);
+    launch_sphi(c, ew, s, y_start);
+    launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
+    (void)hipEventRecord(c->ev_fork, main_stream);
+    c->stream = c->stream2;                                   // every launch helper uses c->stream
+    (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+    launch_A_m(c, false, {&c->mUq, &c->mVq});
+    EtdArrays eq = etd_arrays(c->q, s, &qslot);
+    launch_sq(c, eq, s);
+    (void)hipEventRecord(c->ev_join, c->stream2);
+    c->stream = main_stream;
+    phase_wavepv(c);
+    (void)hipStreamWaitEvent(main_stream, c->ev_join, 0);
+    phase_invert(c, s);
+  }
+  phase_budget_sums(c);
+  phase_budget_finish(c);
+}
+
 static void do_step(nq_ctx* c) {      // P == 1
   if (c->ybj) return do_step_ybj(c);
+  if (c->stream2 && c->p.model == NQ_MODEL_COUPLED && c->N == 4096 && !c->dual) return do_step_overlap(c);
   for (int s = 0; s < 4; ++s) {
     phase_products(c, s);
     phase_update(c, s);
@@ -1238,6 +1276,15 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
       c->mUc = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 2, true);
       c->mVc = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 3, true);
     }
+    if (P == 1 && p->model == NQ_MODEL_COUPLED && N == 4096) {
+      const char* e = getenv("NIWQG_AMD_OVERLAP_CUS");
+      c->overlap_cus = e ? atoi(e) : 0;
+      if (c->overlap_cus > 0 && c->overlap_cus < c->num_cu) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+      }
+    }
     c->mGx = c->mPhi;
     c->mGy = c->mPhiy;
     if (c->p.model == NQ_MODEL_UNCOUPLED) {        // frozen copy of the X side of G1 (quirk Q1)
@@ -1296,6 +1343,9 @@ int nq_destroy(nq_ctx* c) {
   for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->stream2) hipStreamDestroy(c->stream2);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
   delete c;
   return 0;

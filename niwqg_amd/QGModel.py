@@ -239,18 +239,25 @@ class Model(object):
     def _calc_ke_qg(self):
         return self._ctx.scalar(_lib.S_KE_QG)
 
+    # The purely spectral diagnostics come from the half-spectrum sums of ONE device pass (nq_diagnostics, entries
+    # [6..14], include/niwqg_amd.h): no plane is downloaded at a tick.
+    def _dsums(self):
+        if "_dsums" not in self._cache:
+            self._cache["_dsums"] = self._ctx.diagnostic_sums()
+        return self._cache["_dsums"]
+
     def _calc_ens(self):
-        return 0.5 * self.spec_var(self.qh)
+        """0.5 mean(q^2) (ref: niwqg/QGModel.py:657) by Parseval"""
+        return 0.5 * self._dsums()[6] / float(self.M) ** 2
 
     def _calc_ep_psi(self):
-        """ref: niwqg/QGModel.py:588-593"""
-        lap2psi = self.ifft(self.wv4 * self.ph)
-        lapq = self.ifft(-self.wv2 * self.qh)
-        return (self.nu4 * (self.q * lap2psi).mean() - self.nu * (self.p * lapq).mean()
-                + self.mu * (self.p * self.q).mean())
+        """ref: niwqg/QGModel.py:588-593 by Parseval"""
+        s = self._dsums()
+        return (self.nu4 * s[12] + self.nu * s[13] + self.mu * s[14]) / float(self.M) ** 2
 
     def _calc_chi_q(self):
-        return -self.nu4 * self.spec_var(self.wv2 * self.qh)
+        """ref: niwqg/QGModel.py:606-609"""
+        return -self.nu4 * self._dsums()[7] / float(self.M) ** 2
 
     def _calc_cfl(self):
         return self._ctx.scalar(_lib.S_CFL) * self.dt / self.dx      # max reduction on the device
@@ -277,7 +284,7 @@ class Model(object):
             ('time', 'Time', 'seconds', lambda s: s.t),
             ('ke_qg', 'Quasigeostrophic Kinetic Energy', r'm^2 s^{-2}', lambda s: s._calc_ke_qg()),
             ('Ke', 'Quasigeostrophic Kinetic Energy, from energy equation', r'm^2 s^{-2}', lambda s: s.Ke),
-            ('ens', 'Quasigeostrophic Potential Enstrophy', r's^{-2}', lambda s: 0.5 * (s.q ** 2).mean()),
+            ('ens', 'Quasigeostrophic Potential Enstrophy', r's^{-2}', lambda s: s._calc_ens()),
             ('ep_psi', 'The hyperviscous dissipation of QG kinetic energy', r'$m^2 s^{-3}$',
              lambda s: s._calc_ep_psi()),
             ('chi_q', 'The hyperviscous dissipation of QG kinetic energy', r'$s^{-3}$', lambda s: s._calc_chi_q()),

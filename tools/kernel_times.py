@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-m = bench.build_model("coupled", nx, 0)
+model = sys.argv[3] if len(sys.argv) > 3 else "coupled"
+m = bench.build_model(model, nx, 0)
 ctx = m._ctx
 ctx.step(3)
 ctx.sync()
@@ -20,6 +21,8 @@ for name, cls in sorted(ctx.KERNEL_CLASSES.items(), key=lambda kv: kv[1]):
 print("sum %.3f ms/step" % tot)
 import time
 ctx.sync()
+if model == "qg":
+    sys.exit(0)
 ctx.diagnostic_sums()
 t0 = time.perf_counter()
 for _ in range(5):

@@ -97,3 +97,37 @@ def test_coupled_steps_match_oracle(use_filter):
         assert rel(ctx.field(_lib.F_Q), orc.q) < 1e-12
         assert rel(ctx.field(_lib.F_PHI), orc.phi) < 1e-12
         assert rel(ctx.field(_lib.F_PHIH), orc.phih) < 1e-12
+
+
+def test_c_abi_fails_loudly_with_error_text():
+    """Every misuse returns a negative code and leaves a message in nq_last_error: nothing is silently ignored."""
+    import ctypes
+    from niwqg_amd import _lib
+    lib = _lib.lib()
+    kk = np.zeros(96)
+    p = _lib.Params(model=0, nx=96, budgets=1, dual_q=0, dt=1.0, U=0, f=1e-4, kappa2=1, nu=0, nu4=0, mu=0, nuw=0,
+                    nu4w=0, muw=0, beta=0, passive_scalar=0, nu4c=0, nuc=0, muc=0)
+    h = ctypes.c_void_p()
+    r = np.exp(2j * np.pi * (np.arange(1.0, 33.0) / 32.0)).view(np.float64)
+    rc = lib.nq_create(ctypes.byref(p), _lib._dptr(kk), _lib._dptr(kk), _lib._dptr(np.ones((96, 96))), _lib._dptr(r), 0,
+                     ctypes.byref(h))
+    assert rc < 0 and b"nx=96" in lib.nq_last_error(None)               # not a power of two
+    p.nx, p.model = 64, 7
+    rc = lib.nq_create(ctypes.byref(p), _lib._dptr(kk), _lib._dptr(kk), _lib._dptr(np.ones((64, 64))), _lib._dptr(r), 0,
+                     ctypes.byref(h))
+    assert rc < 0 and b"model" in lib.nq_last_error(None)
+    dk = 2 * np.pi / L
+    ll = dk * np.append(np.arange(0., 32), np.arange(-32., 0.))
+    ctx = _lib.Context(_lib.QG, 64, dk * np.arange(0., 33), ll, np.ones((64, 33)), 100.0, nu4=1e9)
+    with pytest.raises(RuntimeError, match="wave field"):
+        ctx.set_phi(np.zeros((64, 64), complex))                      # QGModel has no phi
+    with pytest.raises(RuntimeError, match="passive scalar"):
+        ctx.set_c(np.zeros((64, 64)))
+    with pytest.raises(RuntimeError):
+        ctx.field(99)
+    cw, _ = make_ctx("coupled", 64)
+    with pytest.raises(RuntimeError, match="set_phi"):
+        cw.diagnostic_sums()                                          # no phi yet
+    out = np.zeros(4)
+    assert lib.nq_phase(cw.h, 0, 9) < 0                                 # stage out of range
+    assert lib.nq_destroy(None) == 0

@@ -118,3 +118,22 @@ def test_float_clock_is_the_references():
         t += 0.1
         n += 1
     assert k.tc == n
+
+
+def test_enumerations_match_header(built):
+    """Field, scalar and model ids of the ctypes layer are the header's."""
+    header = open(os.path.join(ROOT, "include", "niwqg_amd.h")).read()
+    ids = {name: int(val) for name, val in re.findall(r"\b(NQ_[A-Z0-9_]+)\s*=\s*(\d+)", header)}
+    for py, c in (("F_Q", "NQ_F_Q"), ("F_QH", "NQ_F_QH"), ("F_P", "NQ_F_P"), ("F_PH", "NQ_F_PH"), ("F_PHI", "NQ_F_PHI"),
+                  ("F_PHIH", "NQ_F_PHIH"), ("F_U", "NQ_F_U"), ("F_V", "NQ_F_V"), ("F_QPSI", "NQ_F_QPSI"),
+                  ("F_QW", "NQ_F_QW"), ("F_QWH", "NQ_F_QWH"), ("F_PHIX", "NQ_F_PHIX"), ("F_PHIY", "NQ_F_PHIY"),
+                  ("F_QH_MINUS", "NQ_F_QH_MINUS"), ("F_C", "NQ_F_C"), ("F_CH", "NQ_F_CH"),
+                  ("F_QH_STAGE4", "NQ_F_QH_STAGE4"), ("S_KE", "NQ_S_KE"), ("S_PW", "NQ_S_PW"), ("S_KW", "NQ_S_KW"),
+                  ("S_KE_QG", "NQ_S_KE_QG"), ("S_KE_NIW", "NQ_S_KE_NIW"), ("S_PE_NIW", "NQ_S_PE_NIW"),
+                  ("S_CFL", "NQ_S_CFL"), ("COUPLED", "NQ_MODEL_COUPLED"), ("UNCOUPLED", "NQ_MODEL_UNCOUPLED"),
+                  ("QG", "NQ_MODEL_QG"), ("YBJ", "NQ_MODEL_YBJ")):
+        assert getattr(built, py) == ids[c], (py, c)
+    from niwqg_amd import slab
+    for i, name in enumerate(("PRODUCTS", "UPDATE", "WAVEPV", "INVERT", "EMIT_PHI", "INVERT_NOW", "BUDGET_SUMS",
+                              "BUDGET_FINISH")):
+        assert ids["NQ_PH_" + name] == i == getattr(slab, "PH_" + name)

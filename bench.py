@@ -206,8 +206,8 @@ def bench_ensemble(args, grp, rank, world, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)      # >= 100 timed, >= 20 warm-up steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--model", default="coupled", choices=["coupled", "uncoupled", "qg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -522,3 +522,24 @@ def test_qg_passive_scalar_against_the_reference(golden, use_filter):
         ref = g["diag_%s_%s" % (name, key)]
         tol = 1e-7 if name == "Gamma_c" else 1e-8     # a nearly vanishing integral of rounding-sensitive terms
         assert np.allclose(np.asarray(m.diagnostics[name]['value']), ref, rtol=tol, atol=1e-30), name
+
+
+def test_long_run_500_steps_stays_within_the_baseline_tolerance():
+    """BASELINE asks fp64 field RMS error < 1e-10 over 100 steps; five times that horizon at 128^2 with the wave packet
+    (filter on), against the oracle stepping beside it (the budget accumulators included)."""
+    nx = 128
+    kw = notebook_kwargs(nx, True)
+    o = O.NIWQGOracle("coupled", **kw)
+    m = models().CoupledModel.Model(**kw)
+    q0 = O.lamb_dipole(o.grid, U=U0, R=2 * np.pi / K0)
+    phi0 = 0.2 * O.wave_packet(o.grid, k=2 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2) + (1 + 1j) * U0
+    for x in (o, m):
+        x.set_q(q0)
+        x.set_phi(phi0)
+    for _ in range(500):
+        o._step_forward()
+    m.tmax = 499.5 * m.dt
+    m.run()
+    assert m.tc == 500
+    assert rel(m.q, o.q) < 1e-10 and rel(m.phi, o.phi) < 1e-10
+    assert np.allclose([m.Ke, m.Pw, m.Kw], [o.Ke, o.Pw, o.Kw], rtol=1e-9)

@@ -137,3 +137,30 @@ def test_enumerations_match_header(built):
     for i, name in enumerate(("PRODUCTS", "UPDATE", "WAVEPV", "INVERT", "EMIT_PHI", "INVERT_NOW", "BUDGET_SUMS",
                               "BUDGET_FINISH")):
         assert ids["NQ_PH_" + name] == i == getattr(slab, "PH_" + name)
+
+
+def test_exchange_group_sizes_without_a_gpu(built):
+    """nq_group_elems is pure host arithmetic: the four exchange groups of the slab decomposition carry 7 complex-plane
+    equivalents per stage for CoupledModel, fewer for the other models, and split evenly."""
+    import ctypes
+    L = built.lib()
+
+    def planes(model, nx, P, **kw):
+        p = built.Params(model=model, nx=nx, budgets=1, dual_q=0, dt=1.0, U=0, f=1e-4, kappa2=1, nu=0, nu4=0, mu=0, nuw=0,
+                         nu4w=0, muw=0, beta=0, passive_scalar=kw.get("passive", 0), nu4c=0, nuc=0, muc=0)
+        n = [L.nq_group_elems(ctypes.byref(p), P, g) for g in range(4)]
+        assert all(x >= 0 and x % P == 0 for x in n), n
+        return [x * P / float(nx) ** 2 for x in n]
+
+    for P in (1, 2, 4, 8):
+        g = planes(built.COUPLED, 4096, P)
+        assert abs(g[0] - 2) < 0.05 and abs(g[1] - 2) < 1e-12 and abs(g[2] - 1) < 0.05 and abs(g[3] - 2) < 0.07
+        assert 7.0 < sum(g) < 7.2                                   # half spectra carry N/2+1 columns plus padding
+    g = planes(built.UNCOUPLED, 1024, 2)
+    assert g[2] == 0 and abs(g[3] - 1.5) < 0.1                     # no wave-PV group, three half-spectrum arrays back
+    g = planes(built.QG, 2048, 4)
+    assert g[1] == 0 and g[2] == 0 and abs(g[0] - 1) < 0.05        # uq, vq only
+    assert planes(built.QG, 2048, 1, passive=1)[0] > 1.9           # + uc, vc
+    p = built.Params(model=0, nx=4096, budgets=1, dual_q=0, dt=1.0, U=0, f=1e-4, kappa2=1, nu=0, nu4=0, mu=0, nuw=0, nu4w=0,
+                     muw=0, beta=0, passive_scalar=0, nu4c=0, nuc=0, muc=0)
+    assert L.nq_group_elems(ctypes.byref(p), 3, 0) < 0             # 4096 rows do not split over 3 ranks

@@ -1,17 +1,30 @@
 #!/usr/bin/env python
 """Benchmark of the ETDRK4 hot path on MI355X (contract: task statement, section 4).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one full ETDRK4 time step (4 stages, 36 fused 2-D transforms + budgets) of
-CoupledModel 4096^2 fp64 (BASELINE.json configs[2]: LambDipole q, uniform phi, filter on), with the
-state resident in HBM.  Prints ONE JSON line.  `roofline` is for the dominant kernel (k_x_products),
-timed live with HIP events on the context's stream; `cpu_baseline` times the numpy oracle in its
-reference-faithful mode (104 c2c transforms per step, 1 thread) on a bounded sample.
+One "step" = one full ETDRK4 time step (4 stages; 32 fused 2-D transforms + in-step budgets) of CoupledModel 4096^2
+fp64 (BASELINE.json configs[2]: LambDipole q, uniform phi, filter on), state resident in HBM.  Prints ONE JSON line.
+
+* `value` = K steps / wall time of the region bracketed by barrier + synchronize on both sides (max over ranks).
+  The K steps are issued as 5 blocks with a HIP event between blocks (no synchronisation inside the region):
+  `blocks_ms_per_step` / `median_block_steps_per_s` are SURVEY 8d's "median of 5".
+* `roofline` describes the DOMINANT kernel class of the timed region (largest total time among ALL six classes, every
+  launch bracketed by HIP events on the context's stream): achieved = algorithmic bytes per launch / average launch
+  duration.  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC summary, used only if that summary was
+  taken from the very sources that are running (sha256 of niwqg_amd/csrc + include/ stamped into it), else null.
+* `cpu_baseline` times the numpy oracle in its reference-faithful mode (104 c2c numpy.fft transforms per step, one thread)
+  at 2048^2 -- measured, >= 2 steps -- and scales by N^2 log2 N to the workload's grid (4.4x; `--cpu-baseline-nx 4096`
+  measures at the full size, about 6 minutes; the result of that run is kept in profiles/).
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts N ranks itself (torch.distributed.run, child
+process, before any GPU call); with WORLD_SIZE set it must equal --gpus.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,35 +39,64 @@ K0 = 10 * (2 * np.pi / L)
 U0 = 0.1
 TE = 1.0 / (U0 * K0)
 
-# algorithmic bytes per grid point ("bytes"): SURVEY 8(d) canonical figure per step, and the
-# bytes one k_x_products launch must move (4 half-spectrum + 2 full inputs, 2 half + 1 full outputs: the two phi
-# tendency sources of the canonical count leave the kernel as ONE array)
-CANONICAL_B_PER_PT_STEP = {"coupled": 3136, "uncoupled": 2240, "qg": 848}
-X_PRODUCTS_B_PER_PT = {"coupled": 4 * 8 + 2 * 16 + 2 * 8 + 16, "uncoupled": 3 * 8 + 3 * 16 + 2 * 8 + 16,
-                       "qg": 3 * 8 + 2 * 8}
-# algorithmic bytes per grid point and LAUNCH of the other fused kernels of the CoupledModel step:
-#  s_phi: tendency in 16, phi and phi_y out 32, ETDRK4 state + coefficient planes 80/80/112/128 in the four stages
-#         (mean 100), start-of-stage phih for the budget projections 12 (3 of 4 stages)
-#  x_wavepv: phi, phi_y rows in 32, two half-spectrum rows out 16;  s_q: 2 half rows in 16, state + coefficients 50;
-#  s_invert: 2 half rows in 16, q-hat 8, filter 4, four half rows out 32, psi-hat and qw-hat stored in the last stage 4
-KERNEL_B_PER_PT = {"coupled": {"x_products": 96.0, "s_phi": 160.0, "x_wavepv": 48.0, "s_q": 66.0, "s_invert": 64.0}}
+# canonical algorithmic bytes per grid point and STEP (2 passes x (read + write) per required transform,
+# 64 B/pt complex, 32 B/pt real, + ETDRK4 state/coefficient streaming)
+# (YBJModel is not in the survey's table: same convention, complex x3 inverse (phi, phix, phiy) + x2 forward per stage =
+# 320 -> 1280, + the phi equation's 416 of ETDRK4 streaming)
+CANONICAL_B_PER_PT_STEP = {"coupled": 3136, "uncoupled": 2240, "qg": 848, "ybj": 1696}
+# Algorithmic bytes per grid point and LAUNCH of the six kernel classes as this design runs them.
+#  x_products: 4 half-spectrum + 2 full rows in, 2 half + 1 full out (the phi tendency leaves as ONE array)
+#  y_A       : in-place radix-S2 sub-pass, 32 B/pt per complex-plane equivalent (16 read + 16 written); per stage
+#              W (1) + uq,vq (2 half = 1) + phi,phiy (2) + a,b (1) + u,psi,q,qw (4 half = 2) = 7 planes in 5 launches
+#  s_phi     : tendency in 16, phi and phi_y out 32, ETDRK4 state + coefficient planes 80/80/112/128 in the four stages
+#              (mean 100), start-of-stage phih for the budget projections 12 (3 of 4 stages)
+#  x_wavepv  : phi, phi_y rows in 32, two half-spectrum rows out 16;  s_q: 2 half rows in 16, state + coefficients 50
+#  s_invert  : 2 half rows in 16, q-hat 8, filter 4, four half rows out 32, psi-hat and qw-hat stored in the last stage 4
+KERNEL_B_PER_PT = {
+    "coupled": {"x_products": 96.0, "s_phi": 160.0, "x_wavepv": 48.0, "s_q": 66.0, "s_invert": 64.0, "y_A": 7 * 32.0 / 5},
+    "uncoupled": {"x_products": 3 * 8 + 3 * 16 + 2 * 8 + 16, "s_phi": 160.0, "s_q": 66.0, "s_invert": 44.0,
+                  "y_A": (1 + 1 + 2 + 1.5) * 32.0 / 4},
+    "qg": {"x_products": 3 * 8 + 2 * 8, "s_q": 66.0, "s_invert": 44.0, "y_A": (1 + 1.5) * 32.0 / 2},
+    "ybj": {"x_products": 3 * 8 + 3 * 16 + 2 * 8 + 16, "s_phi": 148.0, "y_A": (1 + 2) * 32.0 / 2},
+}
 KERNEL_SYMBOL = {"x_products": "k_x_products", "s_phi": "k_s_phi", "x_wavepv": "k_x_wavepv", "s_q": "k_s_q",
                  "s_invert": "k_s_invert", "y_A": "k_y_A"}
 HBM_PEAK_GBS = 8000.0
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")
 
 
-def measured_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/r01_pmc_summary.json: FETCH_SIZE/WRITE_SIZE in separate passes, FETCH doubled as the gfx950
-    note in MI355X_MICROARCH.md prescribes; same workload, same command).  None if the file is absent."""
+def source_hash():
+    """sha256 over the device sources and the C header: ties a PMC summary to the build it was measured on."""
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "include", "niwqg_amd.h")]
+    d = os.path.join(ROOT, "niwqg_amd", "csrc")
+    files += sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".hpp", ".h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def measured_traffic(symbol):
+    """(bytes per launch of `symbol`, total bytes per step, note) from profiles/pmc_summary.json (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; written by
+    tools/pmc_summary.py), or (None, None, why) when the file is absent or was taken from other sources."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        for name, v in d["kernels"].items():
-            if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
-                return v["hbm_bytes_per_launch"]
+        d = json.load(open(PMC_SUMMARY))
     except Exception:
-        pass
-    return None
+        return None, None, "no profiles/pmc_summary.json"
+    if d.get("source_sha256") != source_hash():
+        return None, None, "profiles/pmc_summary.json was measured on other sources (hash mismatch)"
+    per, step = None, d.get("step_hbm_bytes")
+    tot, n = 0.0, 0
+    for name, v in d.get("kernels", {}).items():
+        if name.startswith(symbol + "<") and "hbm_bytes_per_launch" in v:
+            w = v.get("launches_sampled", 1)
+            tot += v["hbm_bytes_per_launch"] * w
+            n += w
+    if n:
+        per = tot / n
+    return per, step, "committed profile of these sources: " + d.get("note", "")[:120]
 
 
 def c3_kwargs(nx, model):
@@ -67,18 +109,25 @@ def c3_kwargs(nx, model):
     return kw
 
 
-def build_model(model, nx, device):
-    import niwqg_amd
+def initial_fields(model, nx, grid):
     from niwqg_amd import InitialConditions as ic
-    mod = {"coupled": niwqg_amd.CoupledModel, "uncoupled": niwqg_amd.UnCoupledModel, "qg": niwqg_amd.QGModel}[model]
-    m = mod.Model(device=device, **c3_kwargs(nx, model))
-    if model == "qg" and nx == 2048:
+    if model == "qg" and nx == 2048:                    # BASELINE config 2
         q = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx))
     else:
-        q = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+        q = ic.LambDipole(grid, U=U0, R=2 * np.pi / K0)
+    phi = None if model == "qg" else (np.ones((nx, nx)) + 1j) * (2 * U0) / np.sqrt(2)
+    return q, phi
+
+
+def build_model(model, nx, device, kind=None):
+    import niwqg_amd
+    mod = {"coupled": niwqg_amd.CoupledModel, "uncoupled": niwqg_amd.UnCoupledModel, "qg": niwqg_amd.QGModel,
+           "ybj": niwqg_amd.YBJModel}[kind or model]
+    m = mod.Model(device=device, **c3_kwargs(nx, model))
+    q, phi = initial_fields(model, nx, m)
     m.set_q(q)
-    if model != "qg":
-        m.set_phi((np.ones((nx, nx)) + 1j) * (2 * U0) / np.sqrt(2))
+    if phi is not None:
+        m.set_phi(phi)
     return m
 
 
@@ -91,23 +140,15 @@ class _SlabCtxView(object):
         self.budgets_enabled = rank.budgets
         self.KERNEL_CLASSES = _lib.Context.KERNEL_CLASSES
         for name in ("sync", "timer_start", "timer_stop", "profile_enable", "profile_read", "profile_read_all",
-                     "device_bytes", "_chk"):
+                     "device_bytes", "event_record", "event_elapsed", "_chk"):
             setattr(self, name, getattr(_lib.Context, name).__get__(self))
 
 
 def build_slab(model, nx, grp, local_rank):
-    """One slab-decomposed simulation over all ranks of `grp` (niwqg_amd.slab); every rank prepares the same
-    initial condition on the host and uploads its own column slab of the spectra."""
-    import niwqg_amd
-    from niwqg_amd import _lib, slab, InitialConditions as ic
+    """One slab-decomposed simulation over all ranks of `grp` (niwqg_amd.slab).  Two stages so that the ranks can agree
+    that every one of them got its memory BEFORE the first collective: allocate() then initialise()."""
+    from niwqg_amd import _lib, slab
     kw = c3_kwargs(nx, model)
-
-    class G(object):          # the grid attributes InitialConditions.LambDipole reads
-        pass
-    g = G()
-    g.nx = nx
-    cell = (np.arange(nx) + 0.5) / nx * L
-    g.x, g.y = np.meshgrid(cell, cell)
     dk = 2 * np.pi / L
     ll = dk * np.append(np.arange(0., nx / 2), np.arange(-nx / 2, 0.))
     kk = ll.copy() if model != "qg" else dk * np.arange(0., nx // 2 + 1)
@@ -120,55 +161,93 @@ def build_slab(model, nx, grp, local_rank):
     if model != "qg":
         kappa2 = (kw["m"] * kw["f"] / kw["N"]) ** 2
         phys.update(f=kw["f"], kappa2=kappa2, nuw=kw["nuw"], nu4w=kw["nu4w"], muw=kw["muw"])
-    ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], grp.world, device=local_rank, only_rank=grp.rank,
-                            budgets=True, **phys)
-    sim = slab.SlabSimulation(ranks, slab.TorchTransport(grp.dist, stage_via_host=(getattr(grp, "backend", "") == "gloo")))
-    if model == "qg" and nx == 2048:
-        q = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx))
-    else:
-        q = ic.LambDipole(g, U=U0, R=2 * np.pi / K0)
-    sim.set_q_spectrum(np.fft.rfft2(q))
-    if model != "qg":
-        sim.set_phi_spectrum(np.fft.fft2((np.ones((nx, nx)) + 1j) * (2 * U0) / np.sqrt(2)))
-    sim.sync()
-    return sim, _SlabCtxView(ranks[0])
+
+    def allocate():
+        ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], grp.world, device=local_rank, only_rank=grp.rank,
+                                budgets=True, **phys)
+        tr = slab.TorchTransport(grp.dist, stage_via_host=(getattr(grp, "backend", "") == "gloo"))
+        return slab.SlabSimulation(ranks, tr)
+
+    def initialise(sim):
+        class G(object):          # the grid attributes InitialConditions.LambDipole reads
+            pass
+        g = G()
+        g.nx = nx
+        cell = (np.arange(nx) + 0.5) / nx * L
+        g.x, g.y = np.meshgrid(cell, cell)
+        q, phi = initial_fields(model, nx, g)
+        sim.set_q(q)
+        if phi is not None:
+            sim.set_phi(phi)
+        sim.sync()
+        return _SlabCtxView(sim.ranks[0])
+
+    return allocate, initialise
 
 
-def cpu_baseline(model, nx_target, budget_s=20.0):
-    """Reference-faithful numpy oracle (oracle/niwqg_oracle.py), one thread, on a bounded sample:
-    the same model at a grid that finishes in ~20 s; steps/s is scaled to nx_target with N^2 log2 N."""
-    try:
-        import threadpoolctl
-        limiter = threadpoolctl.threadpool_limits(1)
-    except Exception:
-        limiter = None
+def _oracle_for(model, nx, table_workers):
     from oracle import niwqg_oracle as O
-    nx = 512 if model != "qg" else 1024
     kw = c3_kwargs(nx, model)
     kw.pop("twrite"), kw.pop("tdiags")
     if model == "qg":
-        m = O.QGOracle(twrite=10 ** 9, tdiags=10 ** 9, **kw)
+        m = O.QGOracle(twrite=10 ** 9, tdiags=10 ** 9, coeff_chunk=8, table_workers=table_workers, **kw)
     else:
-        m = O.NIWQGOracle(model, twrite=10 ** 9, tdiags=10 ** 9, coeff_chunk=16, **kw)
-    m.set_q(O.lamb_dipole(m.grid, U=U0, R=2 * np.pi / K0))
+        m = O.NIWQGOracle(model, twrite=10 ** 9, tdiags=10 ** 9, coeff_chunk=8, table_workers=table_workers, **kw)
+    if model == "qg" and nx == 2048:
+        m.set_q(1e-5 * np.random.default_rng(0).standard_normal((nx, nx)))
+    else:
+        m.set_q(O.lamb_dipole(m.grid, U=U0, R=2 * np.pi / K0))
     if model != "qg":
         m.set_phi((np.ones((nx, nx)) + 1j) * (2 * U0) / np.sqrt(2))
-    m._step_forward()                      # includes the one-off tc==0 diagnostics tick
+    return m
+
+
+def _time_oracle(m, budget_s, min_steps, max_steps=200):
+    m._step_forward()                      # untimed: includes the one-off tc == 0 diagnostics tick
+    f0 = sum(m.fft_calls)
     t0, n = time.perf_counter(), 0
     while True:
         m._step_forward()
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 200:
+        if (el > budget_s and n >= min_steps) or n >= max_steps:
             break
+    return n, el, (sum(m.fft_calls) - f0) // n
+
+
+def cpu_baseline(model, nx_target, nx_sample=None, budget_s=20.0):
+    """Reference-faithful numpy oracle (oracle/niwqg_oracle.py: numpy.fft, the reference's 104/72/33 transforms per
+    step, ONE thread for the timed steps) MEASURED at nx_sample (default 2048, or the target when smaller), >= 2 steps,
+    and scaled to nx_target by N^2 log2 N.  The untimed constructor uses a thread pool for the coefficient tables.
+    A short 512^2 run is kept as a cross-check of that scaling law (`fit_check`)."""
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(1)
+    except Exception:
+        pass
+    cores = os.cpu_count() or 1
+    tw = max(1, min(16, cores - 1))
+    nx = nx_sample or min(nx_target, 2048)
+
+    def cost(n):
+        return n ** 2 * np.log2(n)
+
+    m = _oracle_for(model, nx, tw)
+    n, el, nfft = _time_oracle(m, budget_s, 2)
+    del m
     sps = n / el
-    scale = (nx_target ** 2 * np.log2(nx_target)) / (nx ** 2 * np.log2(nx))
-    if limiter is not None:
-        limiter.unregister() if hasattr(limiter, "unregister") else None
-    return {"value": sps / scale, "unit": "steps/s", "cores": 1, "kind": "port",
-            "sample": "%s oracle (numpy.fft, %d transforms/step) %d^2: %d steps in %.1f s = %.3f steps/s; "
-                      "scaled by N^2 log2 N to %d^2" % (model, sum(m.fft_calls) // (n + 1), nx, n, el, sps, nx_target),
-            "measured_steps_per_s_at_sample": sps, "sample_nx": nx, "host_cores_available": os.cpu_count()}
+    out = {"value": sps * cost(nx) / cost(nx_target), "unit": "steps/s", "cores": 1, "kind": "port",
+           "sample": "%s oracle (numpy.fft, %d transforms/step, 1 thread) MEASURED at %d^2: %d steps in %.1f s = %.4f steps/s%s"
+                     % (model, nfft, nx, n, el, sps,
+                        "" if nx == nx_target else "; scaled by N^2 log2 N (x%.2f) to %d^2" % (cost(nx_target) / cost(nx), nx_target)),
+           "measured_steps_per_s_at_sample": sps, "sample_nx": nx, "sample_steps": n, "host_cores_available": cores}
+    if nx > 512:
+        m = _oracle_for(model, 512, tw)
+        n5, el5, _ = _time_oracle(m, 4.0, 2)
+        s5 = n5 / el5
+        out["fit_check"] = {"nx": 512, "measured_steps_per_s": s5, "predicted_at_sample_nx": s5 * cost(512) / cost(nx),
+                            "measured_over_predicted_at_sample_nx": sps / (s5 * cost(512) / cost(nx))}
+    return out
 
 
 def bench_ensemble(args, grp, rank, world, local_rank):
@@ -203,20 +282,40 @@ def bench_ensemble(args, grp, rank, world, local_rank):
     grp.close()
 
 
+def relaunch_as_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD job (this process has not touched the
+    GPU yet and never will) and pass rank 0's JSON line through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)      # SURVEY 8d: >= 100 timed, >= 20 warm-up steps
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nx", type=int, default=4096)
-    ap.add_argument("--model", default="coupled", choices=["coupled", "uncoupled", "qg"])
+    ap.add_argument("--model", default="coupled", choices=["coupled", "uncoupled", "qg", "ybj"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-nx", type=int, default=0, help="grid of the MEASURED CPU sample (default: min(nx, 2048))")
     ap.add_argument("--force-slab", action="store_true", help="use the slab path (and its collectives) even with one rank")
     ap.add_argument("--members", type=int, default=0, help="BASELINE config 5 instead of the headline: this many "
                     "independent UnCoupledModel 1024^2 members PER GPU (8 in the config), no collective")
     ap.add_argument("--replicas", action="store_true", help="with --gpus N > 1: N independent replicas instead of one "
                                                             "slab-decomposed simulation")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(relaunch_as_ranks(args.gpus))
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s: launch with torch.distributed.run --nproc-per-node %d, or "
+                 "run `python bench.py --gpus %d` without a launcher" % (args.gpus, env_world, args.gpus, args.gpus))
 
     from niwqg_amd.distributed import Group, aggregate_throughput
     import torch
@@ -228,26 +327,31 @@ def main():
     if args.members > 0:
         return bench_ensemble(args, grp, rank, world, local_rank)
 
+    phys_model = "uncoupled" if args.model == "ybj" else args.model       # YBJ: the UnCoupled workload, phi-only stepping
     mode = "single GPU"
-    slab_error = None
     sim = None
     if (world > 1 or (args.force_slab and grp.dist is not None)) and not args.replicas:
-        # ONE simulation, slab-decomposed over the ranks: 4 all_to_all_single per stage over RCCL
+        if args.model == "ybj":
+            sys.exit("bench.py: YBJModel is single-rank only")
+        # ONE simulation, slab-decomposed over the ranks.  Allocation is the only step allowed to fail
+        # softly: the ranks agree on it BEFORE the first collective; from then on any error is fatal (a rank that
+        # dropped out of a collective sequence cannot be recovered from inside the job).
+        allocate, initialise = build_slab(args.model, args.nx, grp, local_rank)
+        err = None
         try:
-            sim, ctx = build_slab(args.model, args.nx, grp, local_rank)
-            sim.step(1)                             # exercises every collective once
-            sim.sync()
-            mode = "slab x%d, one all_to_all per transition (16 per step)" % world
-        except Exception as e:                      # never lose the whole scaling run to a transport problem
-            slab_error = "%s: %s" % (type(e).__name__, e)
-            sim = None
+            sim = allocate()
+        except (RuntimeError, MemoryError) as e:
+            err = "%s: %s" % (type(e).__name__, e)
         ok = grp.sum([1.0 if sim is not None else 0.0])[0]
-        if ok < world:                              # all ranks take the same path
-            if slab_error is None:
-                slab_error = "another rank failed to set up the slab path"
-            sim = None
+        if ok < world:
+            sys.stderr.write("bench.py rank %d: slab allocation failed on %d of %d ranks (%s)\n"
+                             % (rank, world - int(ok), world, err or "this rank was fine"))
+            grp.close()
+            sys.exit(3)
+        ctx = initialise(sim)
+        mode = "slab x%d: %s" % (world, sim.describe())
     if sim is None:
-        m = build_model(args.model, args.nx, local_rank)
+        m = build_model(phys_model, args.nx, local_rank, kind=args.model)
         ctx = m._ctx
         if world > 1:
             mode = "replicas x%d (one full problem per GPU)" % world
@@ -266,21 +370,22 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    per_class = hasattr(ctx, "profile_read_all")
-    ctx.profile_enable(-2 if per_class else ctx.KERNEL_CLASSES["x_products"])      # HIP events around every launch
+    NBLK = 5 if args.steps >= 5 else 1
+    blocks = [args.steps // NBLK + (1 if i < args.steps % NBLK else 0) for i in range(NBLK)]
+    ctx.profile_enable(-2)                                  # HIP events around every launch of the six kernel classes
+    if sim is not None:
+        sim.reset_counters()
     barrier()
     t0 = time.perf_counter()
-    ctx.timer_start()
-    advance(args.steps)
-    dev_ms = ctx.timer_stop()
+    ctx.event_record(0)
+    for i, nb in enumerate(blocks):
+        advance(nb)
+        ctx.event_record(i + 1)
     barrier()
     wall = time.perf_counter() - t0
-    classes = None
-    if per_class:
-        classes = ctx.profile_read_all()
-        launches, kms = classes["x_products"]
-    else:
-        launches, kms = ctx.profile_read()
+    block_ms = [ctx.event_elapsed(i, i + 1) / nb for i, nb in enumerate(blocks)]
+    dev_ms = ctx.event_elapsed(0, NBLK)
+    classes = ctx.profile_read_all()
     ctx.profile_enable(-1)
     if sim is not None:
         # strong scaling: all ranks advance the SAME simulation; whole-job steps/s = steps / slowest rank
@@ -291,69 +396,70 @@ def main():
 
     extra = {}
     if sim is not None:
-        # volume this rank hands to the all-to-alls per step (off-rank part), for the xGMI arithmetic in DESIGN.md 9
-        per_stage = sum(t.numel() * 16 for t in sim.ranks[0].gx if t is not None)
-        extra["exchange_GB_sent_per_rank_per_step"] = 4 * per_stage * (world - 1) / max(world, 1) / 1e9
+        extra.update(sim.counters(args.steps))
         if world > 1:
             # the other way to use N GPUs (config 5 style): N independent simulations, no collective.  Timed AFTER
             # and OUTSIDE the K-step region above; reported as context only, never as `value`.
-            try:
-                sim.sync()
-                m2 = build_model(args.model, args.nx, local_rank)
-                m2._ctx.step(2)
-                m2._ctx.sync()
-                grp.barrier()
-                t1 = time.perf_counter()
-                m2._ctx.step(args.steps)
-                m2._ctx.sync()
-                grp.barrier()
-                extra["replicas_aggregate_steps_per_s"] = aggregate_throughput(grp, args.steps, time.perf_counter() - t1)[0]
-                del m2
-            except Exception as e:
-                extra["replicas_aggregate_steps_per_s"] = None
-                extra["replicas_error"] = "%s: %s" % (type(e).__name__, e)
+            sim.sync()
+            m2 = build_model(args.model, args.nx, local_rank)
+            m2._ctx.step(2)
+            m2._ctx.sync()
+            grp.barrier()
+            t1 = time.perf_counter()
+            m2._ctx.step(args.steps)
+            m2._ctx.sync()
+            grp.barrier()
+            extra["replicas_aggregate_steps_per_s"] = aggregate_throughput(grp, args.steps, time.perf_counter() - t1)[0]
+            del m2
 
     if rank == 0:
         npts = float(args.nx) ** 2
-        # the roofline object describes the DOMINANT kernel of the timed region: the class with the largest total time
-        # among those whose algorithmic bytes are tabulated (the A sub-passes are separate launches of 0.1-0.2 ms each)
-        dom = "x_products"
-        table = KERNEL_B_PER_PT.get(args.model, {})
-        if classes:
-            cands = [k for k in classes if k in table and classes[k][0] > 0]
-            if cands:
-                dom = max(cands, key=lambda k: classes[k][1])
-                launches, kms = classes[dom]
-        k_ms = kms / max(launches, 1)
-        k_bytes = (table[dom] if dom in table else X_PRODUCTS_B_PER_PT[args.model]) * npts
-        if sim is not None:
-            k_bytes /= world                       # each rank's launch covers nx/world rows
+        share = world if sim is not None else 1            # a slab rank's launch covers 1/world of the grid
+        table = KERNEL_B_PER_PT[args.model]
+        cands = [k for k in classes if k in table and classes[k][0] > 0]
+        dom = max(cands, key=lambda k: classes[k][1])
+        launches, kms = classes[dom]
+        k_ms = kms / launches
+        k_bytes = table[dom] * npts / share
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
         step_bytes = CANONICAL_B_PER_PT_STEP[args.model] * npts
+        design_bytes = sum(table[k] * npts / share * classes[k][0] for k in cands) / args.steps * share
+        traffic, pmc_step, pmc_note = (None, None, "PMC summary is for the default workload only")
+        if sim is None and args.nx == 4096 and args.model == "coupled" and ctx.budgets_enabled:
+            traffic, pmc_step, pmc_note = measured_traffic(KERNEL_SYMBOL[dom])
+        real_bytes = pmc_step if pmc_step else design_bytes
+        s_per_step = wall / args.steps
+        peak = HBM_PEAK_GBS * share
         out = {
             "metric": "time-steps/sec, %sModel %d^2 fp64 (achieved HBM GB/s in roofline)" % (
-                {"coupled": "Coupled", "uncoupled": "UnCoupled", "qg": "QG"}[args.model], args.nx),
+                {"coupled": "Coupled", "uncoupled": "UnCoupled", "qg": "QG", "ybj": "YBJ"}[args.model], args.nx),
             "value": sps, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
+            "ms_per_step": 1e3 * s_per_step, "higher_is_better": True,
             "scaling": "strong" if sim is not None else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%sModel LambDipole %d^2 fp64, ETDRK4, filter on, budgets %s"
-                                   % (args.model, args.nx, "on" if ctx.budgets_enabled else "off"),
-                       "parallelism": mode, "slab_fallback_reason": slab_error,
+            "config": {"workload": "%sModel %s %d^2 fp64, ETDRK4, filter on, budgets %s"
+                                   % (args.model, "random-q" if (args.model == "qg" and args.nx == 2048) else "LambDipole",
+                                      args.nx, "on" if ctx.budgets_enabled else "off"),
+                       "parallelism": mode,
                        "device_ms_per_step_hip_events": dev_ms / args.steps,
+                       "blocks_ms_per_step": [round(b, 5) for b in block_ms],
+                       "median_block_steps_per_s": 1e3 / float(np.median(block_ms)),
                        "device_bytes": ctx.device_bytes(), **extra},
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(KERNEL_SYMBOL[dom] + "<") if (ctx.budgets_enabled and sim is None and args.nx == 4096) else None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_note,
                          "launches": launches, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
-                         "per_kernel_ms_per_step": ({k: round(v[1] / args.steps, 4) for k, v in classes.items()} if classes else None),
-                         "per_kernel_frac_of_peak": ({k: round(table[k] * npts / (world if sim is not None else 1) / (classes[k][1] / classes[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                                      for k in table if classes and classes[k][0] > 0} if classes else None),
+                         "per_kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in classes.items()},
+                         "per_kernel_frac_of_peak": {k: round(table[k] * npts / share / (classes[k][1] / classes[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                     for k in cands},
                          "step_canonical_bytes": step_bytes,
-                         "step_achieved_GBs": step_bytes / (wall / args.steps) / 1e9,
-                         "step_frac_of_peak": step_bytes / (wall / args.steps) / 1e9 / (HBM_PEAK_GBS * (world if sim is not None else 1))},
+                         "step_achieved_GBs": step_bytes / s_per_step / 1e9,
+                         "step_frac_of_peak": step_bytes / s_per_step / 1e9 / peak,
+                         "step_real_bytes": real_bytes,
+                         "step_real_source": "rocprofv3 PMC (profiles/pmc_summary.json)" if pmc_step else "design table x launches",
+                         "step_real_GBs": real_bytes / s_per_step / 1e9,
+                         "step_real_frac": real_bytes / s_per_step / 1e9 / peak},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model, args.nx)
+            out["cpu_baseline"] = cpu_baseline(phys_model, args.nx, nx_sample=args.cpu_baseline_nx or None)
         print(json.dumps(out))
     grp.close()
 

@@ -25,21 +25,25 @@ typedef struct nq_ctx nq_ctx;
 enum { NQ_MODEL_COUPLED = 0, NQ_MODEL_UNCOUPLED = 1, NQ_MODEL_QG = 2,
        NQ_MODEL_YBJ = 3 /* niwqg/YBJModel.py: steady psi, nq_step advances phi only (YBJModel.py:52-87); single rank */ };
 
-/* field ids for nq_get_field */
+/* field ids for nq_get_field.  Exact host shapes (C-contiguous; "cplx" = interleaved re,im doubles); nq_field_doubles()
+ * returns the number of doubles written.  Spectra of REAL fields (qh, ph, qwh, ch) always come as the HALF spectrum
+ * (ny, nx/2+1), k = 0..nx/2, for every model: the reference's Kernel-family (ny,nx) arrays follow from
+ * X(l,k) = conj X(-l,-k) for k > nx/2 (niwqg_amd/Kernel.py: hermitian_full; with dual_q the k < 0 side of qh is
+ * NQ_F_QH_MINUS instead).  phih is a genuine full plane. */
 enum {
-  NQ_F_Q = 0,      /* real (ny,nx)       q      = Re ifft(qh)                 Kernel.py:97/CoupledModel.py:97 */
-  NQ_F_QH = 1,     /* cplx spectral      qh     (full plane; (ny,nx/2+1) for QG)                                */
-  NQ_F_P = 2,      /* real               p      streamfunction                CoupledModel.py:93               */
-  NQ_F_PH = 3,     /* cplx spectral      ph                                                                     */
-  NQ_F_PHI = 4,    /* cplx (ny,nx)       phi                                  Kernel.py:337                    */
-  NQ_F_PHIH = 5,   /* cplx spectral      phih                                                                   */
-  NQ_F_U = 6,      /* real               u = Re ifft(-il ph)                  Kernel.py:481                    */
-  NQ_F_V = 7,      /* real               v = Re ifft( ik ph)                                                    */
-  NQ_F_QPSI = 8,   /* real               q_psi                                CoupledModel.py:145-152          */
-  NQ_F_QW = 9,     /* real               qw                                                                     */
-  NQ_F_QWH = 10,   /* cplx spectral      qwh                                  CoupledModel.py:86-88            */
-  NQ_F_PHIX = 11,  /* cplx               phix (as last refreshed: quirk Q1)   Kernel.py:610                    */
-  NQ_F_PHIY = 12,  /* cplx               phiy                                                                   */
+  NQ_F_Q = 0,      /* real (ny,nx)        q      = Re ifft(qh)                 Kernel.py:97/CoupledModel.py:97 */
+  NQ_F_QH = 1,     /* cplx (ny,nx/2+1)    qh                                                                    */
+  NQ_F_P = 2,      /* real (ny,nx)        p      streamfunction                CoupledModel.py:93               */
+  NQ_F_PH = 3,     /* cplx (ny,nx/2+1)    ph                                                                    */
+  NQ_F_PHI = 4,    /* cplx (ny,nx)        phi                                  Kernel.py:337                    */
+  NQ_F_PHIH = 5,   /* cplx (ny,nx)        phih                                                                  */
+  NQ_F_U = 6,      /* real (ny,nx)        u = Re ifft(-il ph)                  Kernel.py:481                    */
+  NQ_F_V = 7,      /* real (ny,nx)        v = Re ifft( ik ph)                                                   */
+  NQ_F_QPSI = 8,   /* real (ny,nx)        q_psi = q - qw (q without waves)     CoupledModel.py:145-152          */
+  NQ_F_QW = 9,     /* real (ny,nx)        qw                                   (coupled model only)             */
+  NQ_F_QWH = 10,   /* cplx (ny,nx/2+1)    qwh                                  CoupledModel.py:86-88            */
+  NQ_F_PHIX = 11,  /* cplx (ny,nx)        phix (as last refreshed: quirk Q1)   Kernel.py:610                    */
+  NQ_F_PHIY = 12,  /* cplx (ny,nx)        phiy                                                                  */
   NQ_F_QH_MINUS = 13,/* cplx half spectrum conj(qh(-l,-k)), k = 0..nx/2 (dual_q contexts only)                  */
   NQ_F_C = 14,       /* real (ny,nx)       c      passive scalar of QGModel     QGModel.py:403-404               */
   NQ_F_CH = 15,      /* cplx (ny,nx/2+1)   ch                                                                     */
@@ -107,6 +111,8 @@ int nq_sync(nq_ctx* ctx);
 
 /* copy a field to the host in the reference's layout (blocking) */
 int nq_get_field(nq_ctx* ctx, int field_id, double* host_out);
+/* number of doubles nq_get_field(field_id) writes for this context (-1: unknown id or NULL ctx) */
+long long nq_field_doubles(const nq_ctx* ctx, int field_id);
 int nq_get_scalar(nq_ctx* ctx, int scalar_id, double* out);
 
 /* the FFT seam, Kernel.fft / Kernel.ifft (Kernel.py:562-566): complex (ny,nx) -> complex (ny,nx);
@@ -116,11 +122,25 @@ int nq_ifft2(nq_ctx* ctx, const double* in_cplx, double* out_cplx);
 int nq_rfft2(nq_ctx* ctx, const double* in_real, double* out_cplx);
 int nq_irfft2(nq_ctx* ctx, const double* in_cplx, double* out_real);
 
-/* Kernel.jacobian_psi_q (Kernel.py:471-486), jacobian_psi_phi (:457-469),
- * CoupledModel.jacobian_phic_phi (CoupledModel.py:59-73): full-plane complex result on the host.     */
+/* The three Jacobians, evaluated on the current device state, in the reference's own array layouts and with its
+ * [0,0] conventions (assembled on the device; nothing left for the caller to multiply or expand):
+ *   nq_jacobian_psi_q    Kernel.jacobian_psi_q (Kernel.py:471-486): ik*fft(u q) + il*fft(v q), [0,0] = 0
+ *                          -> cplx (ny, nx)       = 2*ny*nx doubles          (Kernel family)
+ *                        QGModel.jacobian_psi_q (QGModel.py:469-481): same, [0,0] kept
+ *                          -> cplx (ny, nx/2+1)   = 2*ny*(nx/2+1) doubles    (NQ_MODEL_QG)
+ *   nq_jacobian_psi_phi  Kernel.jacobian_psi_phi (Kernel.py:457-469): fft(u phix + v phiy), [0,0] = 0 (kept by a
+ *                        NQ_MODEL_YBJ context, YBJModel.py:123-133)         -> cplx (ny, nx) = 2*ny*nx doubles
+ *   nq_jacobian_phic_phi CoupledModel.jacobian_phic_phi (CoupledModel.py:59-73), [0,0] = 0; refreshes phix, phiy
+ *                                                                           -> cplx (ny, nx) = 2*ny*nx doubles
+ * nq_products_uq_vq has no reference counterpart: the two transforms fft(u q), fft(v q) themselves on k = 0..nx/2,
+ *                        cplx (2, ny, nx/2+1) = 4*ny*(nx/2+1) doubles (tests; callers with their own flux forms). */
 int nq_jacobian_psi_q(nq_ctx* ctx, double* out_cplx);
 int nq_jacobian_psi_phi(nq_ctx* ctx, double* out_cplx);
 int nq_jacobian_phic_phi(nq_ctx* ctx, double* out_cplx);
+int nq_products_uq_vq(nq_ctx* ctx, double* out_cplx2);
+/* fft(phi * q_psi), cplx (ny, nx) = 2*ny*nx doubles: the refraction source of Kernel.py:332 (before its -0.5j factor;
+ * mean not removed), formed by the row kernel exactly as inside a step */
+int nq_refraction(nq_ctx* ctx, double* out_cplx);
 
 /* Diagnostics tick on the device: the raw sums from which every scalar of increment_diagnostics (Diagnostics.py:41-58;
  * the 21 kernel lambdas Kernel.py:718-868 and the 3 class lambdas CoupledModel.py:115-136) follows without any plane
@@ -147,7 +167,8 @@ int nq_get_coeff(nq_ctx* ctx, int eq, int which, double* out_cplx);
  * (spectral kernels).  Arrays that cross together form an exchange group g = 0..3; each group has an x-side
  * and a y-side buffer of nq_group_elems() complex128 elements, both cut into nranks equal blocks, so that ONE
  * all_to_all_single(recv = other side, send = this side) moves the group.  The caller owns the collectives
- * (torch.distributed / RCCL); the library only runs the phases in between, on the stream it was given.
+ * (torch.distributed / RCCL); the library only runs the phases in between, on the stream it was given (stream ==
+ * NULL: a private stream the library creates -- then the caller must order its collectives against nq_stream()).
  *   buffers[2g], buffers[2g+1] : x-side and y-side device buffers of group g (may be NULL for empty groups)
  *   buffers[8]                 : 64 doubles for the per-step budget sums (summed over ranks by the caller)  */
 long long nq_group_elems(const nq_params* p, int nranks, int group);
@@ -175,6 +196,10 @@ int nq_reduce_buffer(nq_ctx* ctx, int which, void** device_ptr, int* count);
 /* timing of the hot loop with HIP events on the context's stream */
 int nq_timer_start(nq_ctx* ctx);
 int nq_timer_stop(nq_ctx* ctx, float* elapsed_ms);
+/* 16 event slots on the context's stream: record marks between asynchronous nq_step calls, read the time between
+ * two marks afterwards (blocks until slot_b has passed) */
+int nq_event_record(nq_ctx* ctx, int slot);
+int nq_event_elapsed(nq_ctx* ctx, int slot_a, int slot_b, float* elapsed_ms);
 /* Per-kernel timing with HIP events on the context's stream.  While enabled, every launch of the
  * selected kernel class inside nq_step is bracketed by an event pair (cost ~2 us per launch).
  * class: 0 x_products, 1 x_wavepv, 2 s_q, 3 s_phi, 4 s_invert, 5 y_A (all A sub-passes)              */

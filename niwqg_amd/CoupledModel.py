@@ -21,9 +21,9 @@ class Model(Kernel.Kernel):
     def jacobian_phic_phi(self):
         """F[Re i(phix* phiy - phiy* phix)], [0,0] = 0; refreshes phix, phiy from the current phih.
         ref: niwqg/CoupledModel.py:59-73"""
-        jach = hermitian_full(self._ctx.wave_jacobian())
-        jach[0, 0] = 0
-        return jach
+        self._cache.pop("phix", None)
+        self._cache.pop("phiy", None)
+        return self._ctx.jacobian_phic_phi()
 
     def _calc_ke_qg_decomp(self):
         """ref: niwqg/CoupledModel.py:99-113 from the half-spectrum sums of the device tick (Parseval)"""

@@ -228,16 +228,11 @@ class Kernel(object):
 
     def jacobian_psi_q(self):
         """ik F[u q] + il F[v q], [0,0] = 0.  ref: niwqg/Kernel.py:471-486"""
-        f1, f2 = self._ctx.products_uq_vq()
-        jach = self.ik * hermitian_full(f1) + self.il * hermitian_full(f2)
-        jach[0, 0] = 0
-        return jach
+        return self._ctx.jacobian_psi_q()
 
     def jacobian_psi_phi(self):
         """F[u phix + v phiy], [0,0] = 0.  ref: niwqg/Kernel.py:457-469"""
-        jach = self._ctx.advection_phi()
-        jach[0, 0] = 0
-        return jach
+        return self._ctx.jacobian_psi_phi()
 
     def spec_var(self, ph):
         """ref: niwqg/Kernel.py:654-658"""

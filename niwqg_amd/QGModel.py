@@ -163,8 +163,7 @@ class Model(object):
 
     def jacobian_psi_q(self):
         """ik F[u q] + il F[v q] on the half spectrum, [0,0] NOT zeroed.  ref: niwqg/QGModel.py:469-481"""
-        f1, f2 = self._ctx.products_uq_vq()
-        return self.ik * f1 + self.il * f2
+        return self._ctx.jacobian_psi_q()
 
     def spec_var(self, ph):
         """ref: niwqg/QGModel.py:611-619"""

@@ -23,7 +23,7 @@ class Model(Kernel.Kernel):
 
     def jacobian_psi_phi(self):
         """F[u phix + v phiy] with [0,0] left alone (ref: niwqg/YBJModel.py:123-133)"""
-        return self._ctx.advection_phi()
+        return self._ctx.jacobian_psi_phi()
 
     def _calc_grad_phi(self):
         """ref: niwqg/YBJModel.py:135-139"""

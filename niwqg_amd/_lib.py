@@ -26,8 +26,8 @@ COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
 
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
            "nq_step", "nq_sync", "nq_get_field", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
-           "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_get_coeff", "nq_diagnostics",
-           "nq_timer_start", "nq_timer_stop", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
+           "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_diagnostics",
+           "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
            "nq_reduce_buffer", "nq_device_bytes", "nq_stream"]
 
@@ -81,15 +81,19 @@ def lib():
     for name in ("nq_destroy", "nq_invert", "nq_refresh_grad_phi", "nq_sync", "nq_timer_start"):
         getattr(L, name).argtypes = [vp]
     for name in ("nq_set_q", "nq_set_c", "nq_set_phi", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi",
-                 "nq_diagnostics"):
+                 "nq_products_uq_vq", "nq_refraction", "nq_diagnostics"):
         getattr(L, name).argtypes = [vp, dp]
     for name in ("nq_fft2", "nq_ifft2", "nq_rfft2", "nq_irfft2"):
         getattr(L, name).argtypes = [vp, dp, dp]
     L.nq_step.argtypes = [vp, ctypes.c_int]
     L.nq_get_field.argtypes = [vp, ctypes.c_int, dp]
+    L.nq_field_doubles.argtypes = [vp, ctypes.c_int]
+    L.nq_field_doubles.restype = ctypes.c_longlong
     L.nq_get_scalar.argtypes = [vp, ctypes.c_int, dp]
     L.nq_get_coeff.argtypes = [vp, ctypes.c_int, ctypes.c_int, dp]
     L.nq_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.nq_event_record.argtypes = [vp, ctypes.c_int]
+    L.nq_event_elapsed.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     L.nq_profile_enable.argtypes = [vp, ctypes.c_int]
     L.nq_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)]
     L.nq_profile_read_all.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)]
@@ -196,12 +200,16 @@ class Context:
 
     def field(self, fid):
         n, h = self.nx, self.nx // 2 + 1
+        nd = self.L.nq_field_doubles(self.h, fid)           # the library states the size; shapes as in the header
+        if nd < 0:
+            raise RuntimeError("nq_get_field: unknown field id %d" % fid)
         if fid in self._REAL:
             out = np.empty((n, n), np.float64)
         elif fid in self._HALF:
             out = np.empty((n, h), np.complex128)
         else:
             out = np.empty((n, n), np.complex128)
+        assert out.view(np.float64).size == nd, fid
         self._chk(self.L.nq_get_field(self.h, fid, _dptr(out.view(np.float64))), "nq_get_field(%d)" % fid)
         return out
 
@@ -243,20 +251,33 @@ class Context:
     def irfft2(self, a):
         return self._xf(self.L.nq_irfft2, a, np.complex128, (self.nx, self.nx), np.float64)
 
-    # --- Jacobian pieces (device transforms; the model classes assemble the reference's arrays)
+    # --- Jacobians in the reference's layouts (assembled on the device)
+    def jacobian_psi_q(self):
+        """Kernel family: (ny, nx) with [0,0] = 0 (Kernel.py:471-486); QGModel: (ny, nx/2+1) (QGModel.py:469-481)"""
+        out = np.empty((self.nx, self.nx if self.model != QG else self.nx // 2 + 1), np.complex128)
+        self._chk(self.L.nq_jacobian_psi_q(self.h, _dptr(out.view(np.float64))), "nq_jacobian_psi_q")
+        return out
+
     def products_uq_vq(self):
+        """fft(u q), fft(v q) on k = 0..nx/2"""
         n, h = self.nx, self.nx // 2 + 1
         out = np.empty((2, n, h), np.complex128)
-        self._chk(self.L.nq_jacobian_psi_q(self.h, _dptr(out.view(np.float64))), "nq_jacobian_psi_q")
+        self._chk(self.L.nq_products_uq_vq(self.h, _dptr(out.view(np.float64))), "nq_products_uq_vq")
         return out[0], out[1]
 
-    def advection_phi(self):
+    def jacobian_psi_phi(self):
         out = np.empty((self.nx, self.nx), np.complex128)
         self._chk(self.L.nq_jacobian_psi_phi(self.h, _dptr(out.view(np.float64))), "nq_jacobian_psi_phi")
         return out
 
-    def wave_jacobian(self):
-        out = np.empty((self.nx, self.nx // 2 + 1), np.complex128)
+    def refraction(self):
+        """fft(phi * q_psi) from the row kernel (Kernel.py:332 without the -0.5j)"""
+        out = np.empty((self.nx, self.nx), np.complex128)
+        self._chk(self.L.nq_refraction(self.h, _dptr(out.view(np.float64))), "nq_refraction")
+        return out
+
+    def jacobian_phic_phi(self):
+        out = np.empty((self.nx, self.nx), np.complex128)
         self._chk(self.L.nq_jacobian_phic_phi(self.h, _dptr(out.view(np.float64))), "nq_jacobian_phic_phi")
         return out
 
@@ -267,6 +288,14 @@ class Context:
     def timer_stop(self):
         ms = ctypes.c_float()
         self._chk(self.L.nq_timer_stop(self.h, ctypes.byref(ms)), "nq_timer_stop")
+        return ms.value
+
+    def event_record(self, slot):
+        self._chk(self.L.nq_event_record(self.h, int(slot)), "nq_event_record")
+
+    def event_elapsed(self, a, b):
+        ms = ctypes.c_float()
+        self._chk(self.L.nq_event_elapsed(self.h, int(a), int(b), ctypes.byref(ms)), "nq_event_elapsed")
         return ms.value
 
     KERNEL_CLASSES = {"x_products": 0, "x_wavepv": 1, "s_q": 2, "s_phi": 3, "s_invert": 4, "y_A": 5}

@@ -29,8 +29,11 @@ static thread_local std::string g_last_error;
     if (e_ != hipSuccess) NQ_FAIL(ctx, -5, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-#define NQ_SINGLE_RANK(c, what) \
-  if ((c)->P != 1) NQ_FAIL(c, -4, what ": not available on a slab context (nranks > 1)")
+#define NQ_SINGLE_RANK(c, what)                                                              \
+  do {                                                                                       \
+    if (!(c)) NQ_FAIL((nq_ctx*)nullptr, -1, what ": null context");                          \
+    if ((c)->P != 1) NQ_FAIL(c, -4, what ": not available on a slab context (nranks > 1)");  \
+  } while (0)
 
 // ---------------------------------------------------------------------------------------------
 struct EqState {           // ETDRK4 state of one equation
@@ -50,6 +53,7 @@ struct nq_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t marks[16] = {};               // nq_event_record / nq_event_elapsed
   std::string err;
   long long bytes = 0;
   std::vector<void*> allocs;
@@ -224,6 +228,46 @@ __global__ void k_avg_interior(const cd* __restrict__ a, const cd* __restrict__ 
     v = cmake(0.5 * (v.x + w.x), 0.5 * (v.y + w.y));
   }
   out[idx] = v;
+}
+
+// a *= -i, contiguous array
+__global__ void k_mul_minus_i(cd* __restrict__ a, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) a[i] = cmul_mi(a[i]);
+}
+
+// out = a - b on a half-spectrum plane (q_psi = q - qw, ref CoupledModel.py:145-152)
+__global__ void k_sub_half(const cd* __restrict__ a, const cd* __restrict__ b, cd* __restrict__ out, int width, int pitch) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+  if (k >= width) return;
+  const size_t idx = (size_t)l * pitch + k;
+  out[idx] = csub(a[idx], b[idx]);
+}
+
+// Half spectra of REAL fields -> the reference's array layouts.  a(l,k) = f(l,k) for k <= N/2 and conj f(-l,-k) beyond
+// (what numpy.fft.fft2 of the real field holds there); out has `wout` columns (N: Kernel family, N/2+1: QGModel).
+//   mode 0: out = a1                               (ref CoupledModel.py:71: fft of a real field)
+//   mode 1: out = i kk[k] a1 + i ll[l] a2          (ref Kernel.py:484 / QGModel.py:481: ik*fft(u q) + il*fft(v q))
+__global__ void k_expand_half(const cd* __restrict__ f1, const cd* __restrict__ f2, cd* __restrict__ out, int N,
+                              int pitch_h, int wout, int mode, const double* __restrict__ kk,
+                              const double* __restrict__ ll) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+  if (k >= wout) return;
+  cd a, b = cmake(0, 0);
+  if (k <= N / 2) {
+    const size_t at = (size_t)l * pitch_h + k;
+    a = f1[at];
+    if (mode == 1) b = f2[at];
+  } else {
+    const size_t at = (size_t)((N - l) % N) * pitch_h + (N - k);
+    a = cconj(f1[at]);
+    if (mode == 1) b = cconj(f2[at]);
+  }
+  if (mode == 1) {
+    const double kx = kk[k], ly = ll[l];
+    a = cmake(-(kx * a.y + ly * b.y), kx * a.x + ly * b.x);
+  }
+  out[(size_t)l * wout + k] = a;
 }
 
 // reductions: sum over a real/complex plane of a pointwise expression; result in out[0..] via atomics
@@ -1341,6 +1385,8 @@ int nq_destroy(nq_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   for (void* p : c->allocs) hipFree(p);
   for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
+  for (hipEvent_t e : c->marks)
+    if (e) hipEventDestroy(e);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->stream2) hipStreamDestroy(c->stream2);
@@ -1417,6 +1463,23 @@ int nq_timer_stop(nq_ctx* c, float* ms) {
   return 0;
 }
 
+int nq_event_record(nq_ctx* c, int slot) {
+  if (!c) return -1;
+  if (slot < 0 || slot >= 16) NQ_FAIL(c, -1, "nq_event_record: slot %d (0..15)", slot);
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->marks[slot]) HIPCHK(c, hipEventCreate(&c->marks[slot]));
+  HIPCHK(c, hipEventRecord(c->marks[slot], c->stream));
+  return 0;
+}
+int nq_event_elapsed(nq_ctx* c, int slot_a, int slot_b, float* ms) {
+  if (!c || !ms) return -1;
+  if (slot_a < 0 || slot_a >= 16 || slot_b < 0 || slot_b >= 16 || !c->marks[slot_a] || !c->marks[slot_b])
+    NQ_FAIL(c, -1, "nq_event_elapsed: slots %d, %d not recorded", slot_a, slot_b);
+  HIPCHK(c, hipEventSynchronize(c->marks[slot_b]));
+  HIPCHK(c, hipEventElapsedTime(ms, c->marks[slot_a], c->marks[slot_b]));
+  return 0;
+}
+
 int nq_set_q(nq_ctx* c, const double* q_host) {
   if (!c || !q_host) return -1;
   NQ_SINGLE_RANK(c, "nq_set_q");
@@ -1469,6 +1532,7 @@ int nq_invert(nq_ctx* c) {
 
 int nq_refresh_grad_phi(nq_ctx* c) {
   if (!c) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
   if (c->p.model == NQ_MODEL_UNCOUPLED) {
     // freeze the X side of group 1 (phi, phiy rows as the row kernels see them)
     HIPCHK(c, hipMemcpyAsync(c->Gs, c->G[1].bx, sizeof(cd) * c->G[1].elems, hipMemcpyDeviceToDevice, c->stream));
@@ -1591,6 +1655,7 @@ int nq_reduce_buffer(nq_ctx* c, int which, void** ptr, int* count) {
 int nq_fft2(nq_ctx* c, const double* in, double* out) {
   if (!c || !in || !out) return -1;
   NQ_SINGLE_RANK(c, "nq_fft2");
+  HIPCHK(c, hipSetDevice(c->device));
   const size_t full = (size_t)c->N * c->N;
   HIPCHK(c, hipMemcpyAsync(c->scr_f0, in, sizeof(cd) * full, hipMemcpyHostToDevice, c->stream));
   fwd2d_full(c, c->scr_f0, c->scr_f0, c->scr_f1);
@@ -1600,6 +1665,7 @@ int nq_fft2(nq_ctx* c, const double* in, double* out) {
 int nq_ifft2(nq_ctx* c, const double* in, double* out) {
   if (!c || !in || !out) return -1;
   NQ_SINGLE_RANK(c, "nq_ifft2");
+  HIPCHK(c, hipSetDevice(c->device));
   const size_t full = (size_t)c->N * c->N;
   HIPCHK(c, hipMemcpyAsync(c->scr_f0, in, sizeof(cd) * full, hipMemcpyHostToDevice, c->stream));
   inv2d_full(c, c->scr_f0, c->scr_f0, c->scr_f1);
@@ -1609,6 +1675,7 @@ int nq_ifft2(nq_ctx* c, const double* in, double* out) {
 int nq_rfft2(nq_ctx* c, const double* in, double* out) {
   if (!c || !in || !out) return -1;
   NQ_SINGLE_RANK(c, "nq_rfft2");
+  HIPCHK(c, hipSetDevice(c->device));
   const int N = c->N;
   HIPCHK(c, hipMemcpyAsync(c->scr_r, in, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
   fwd2d_half(c, c->scr_r, c->scr_h1, c->scr_h0);
@@ -1618,6 +1685,7 @@ int nq_rfft2(nq_ctx* c, const double* in, double* out) {
 int nq_irfft2(nq_ctx* c, const double* in, double* out) {
   if (!c || !in || !out) return -1;
   NQ_SINGLE_RANK(c, "nq_irfft2");
+  HIPCHK(c, hipSetDevice(c->device));
   const int N = c->N;
   HIPCHK(c, hipMemcpy2DAsync(c->scr_h1, sizeof(cd) * c->Ph, in, sizeof(cd) * c->Wh, sizeof(cd) * c->Wh, N, hipMemcpyHostToDevice, c->stream));
   inv2d_half(c, c->scr_h1, c->scr_r, c->scr_h0);
@@ -1671,6 +1739,18 @@ int nq_get_field(nq_ctx* c, int id, double* host) {
         return get_real_from_half(c, c->scr_f1, 0, host);
       }
       return get_real_from_half(c, qh, 0, host);
+    case NQ_F_QPSI: {
+      const cd* src = qh;
+      if (c->dual) {
+        hipLaunchKernelGGL(k_avg_interior, dim3((c->Wh + 63) / 64, c->N), dim3(64), 0, c->stream, qh, (const cd*)c->q2.y[c->q2.cur], c->scr_f1, c->Wh, c->Ph, c->N);
+        src = c->scr_f1;
+      }
+      if (c->p.model == NQ_MODEL_COUPLED && !c->ybj) {
+        hipLaunchKernelGGL(k_sub_half, dim3((c->Wh + 63) / 64, c->N), dim3(64), 0, c->stream, src, (const cd*)c->qwh, c->scr_f1, c->Wh, c->Ph);
+        src = c->scr_f1;
+      }
+      return get_real_from_half(c, src, 0, host);
+    }
     case NQ_F_P: return get_real_from_half(c, c->ph, 0, host);
     case NQ_F_U: return get_real_from_half(c, c->ph, 1, host);
     case NQ_F_V: {
@@ -1783,51 +1863,68 @@ int nq_get_coeff(nq_ctx* c, int eq, int which, double* out) {
   const int width = half ? c->Wh : N, pitch = half ? c->Ph : N;
   const size_t cnt = (size_t)N * pitch;
   cd* tmp[6];
-  for (int i = 0; i < 6; ++i) {
-    void* p = nullptr;
-    HIPCHK(c, hipMalloc(&p, cnt * sizeof(cd)));
-    tmp[i] = reinterpret_cast<cd*>(p);
-  }
+  void* blockp = nullptr;                               // one allocation: nothing to leak when it fails
+  HIPCHK(c, hipMalloc(&blockp, 6 * cnt * sizeof(cd)));
+  for (int i = 0; i < 6; ++i) tmp[i] = reinterpret_cast<cd*>(blockp) + (size_t)i * cnt;
   const int e = half ? (c->kernel_family ? 0 : 2) : 1;
   hipLaunchKernelGGL(k_etdrk4_coeffs, dim3((width + 63) / 64, N), dim3(64), 0, c->stream, e, N, width, pitch, 0, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5]);
   hipError_t er = hipMemcpy2DAsync(out, sizeof(cd) * width, tmp[which], sizeof(cd) * pitch, sizeof(cd) * width, N, hipMemcpyDeviceToHost, c->stream);
   int rc = nq_sync(c);
-  for (int i = 0; i < 6; ++i) hipFree(tmp[i]);
+  (void)hipFree(blockp);
   if (er != hipSuccess) NQ_FAIL(c, -5, "nq_get_coeff: copy failed");
   return rc;
 }
 
-// Jacobians for the public API: the device produces the transforms, the Python mirror assembles the
-// reference's full-plane arrays (multiplying by ik/il and expanding Hermitian halves).
-int nq_jacobian_psi_q(nq_ctx* c, double* out_cplx) {
-  // out: 2 half-spectrum planes (ny, nx/2+1): F[u q] then F[v q]
-  NQ_SINGLE_RANK(c, "nq_jacobian_psi_q");
-  if (!c || !out_cplx) return -1;
-  HIPCHK(c, hipSetDevice(c->device));
+// ---- the three Jacobians of the public API, in the reference's own array layouts ------------------------------
+// F[u q], F[v q] of the current state as two half-spectrum planes in scr_h0, scr_h1
+static void products_to_scratch(nq_ctx* c) {
   launch_products(c);
   launch_A_m(c, false, {&c->mUq, &c->mVq});
   launch_B_p(c, false, c->mUq.ys, c->mUq.pitch, c->scr_h0, c->Ph, c->Wh, 1.0);
   launch_B_p(c, false, c->mVq.ys, c->mVq.pitch, c->scr_h1, c->Ph, c->Wh, 1.0);
+}
+// Kernel.jacobian_psi_q (ref Kernel.py:471-486): ik*fft(u q) + il*fft(v q) as the full (ny, nx) plane, [0,0] = 0;
+// QGModel.jacobian_psi_q (ref QGModel.py:469-481): the same on (ny, nx/2+1), [0,0] kept.
+int nq_jacobian_psi_q(nq_ctx* c, double* out_cplx) {
+  NQ_SINGLE_RANK(c, "nq_jacobian_psi_q");
+  if (!out_cplx) NQ_FAIL(c, -1, "nq_jacobian_psi_q: null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  products_to_scratch(c);
+  const int N = c->N, wout = c->kernel_family ? N : c->WhG;
+  hipLaunchKernelGGL(k_expand_half, dim3((wout + 63) / 64, N), dim3(64), 0, c->stream, (const cd*)c->scr_h0, (const cd*)c->scr_h1, c->scr_f0, N, c->Ph, wout, 1, c->kk, c->ll);
+  if (c->kernel_family) HIPCHK(c, hipMemsetAsync(c->scr_f0, 0, sizeof(cd), c->stream));
+  HIPCHK(c, hipMemcpyAsync(out_cplx, c->scr_f0, sizeof(cd) * (size_t)N * wout, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+// the two transforms themselves, (2, ny, nx/2+1): fft(u q) then fft(v q) restricted to k = 0..nx/2 (no reference
+// counterpart: exported for tests and for callers that assemble their own flux forms)
+int nq_products_uq_vq(nq_ctx* c, double* out_cplx) {
+  NQ_SINGLE_RANK(c, "nq_products_uq_vq");
+  if (!out_cplx) NQ_FAIL(c, -1, "nq_products_uq_vq: null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  products_to_scratch(c);
   int rc = get_half_spec(c, c->scr_h0, out_cplx);
   if (rc) return rc;
   return get_half_spec(c, c->scr_h1, out_cplx + 2 * (size_t)c->N * c->Wh);
 }
+// Kernel.jacobian_psi_phi (ref Kernel.py:457-469): fft(u phix + v phiy), (ny, nx), [0,0] = 0.  YBJModel's own version
+// (ref YBJModel.py:123-133) keeps [0,0], and so does a YBJ context.
 int nq_jacobian_psi_phi(nq_ctx* c, double* out_cplx) {
-  // out: full plane F[u phix + v phiy] (the caller zeroes [0,0])
   NQ_SINGLE_RANK(c, "nq_jacobian_psi_phi");
-  if (!c || !out_cplx) return -1;
+  if (!out_cplx) NQ_FAIL(c, -1, "nq_jacobian_psi_phi: null output");
   if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
   HIPCHK(c, hipSetDevice(c->device));
   launch_products(c, 1.0, 0.0);                       // the Jacobian part alone
   launch_A_m(c, false, {&c->mW});
   launch_B_p(c, false, c->mW.ys, c->mW.pitch, c->scr_f0, c->N, c->N, 1.0);
+  if (!c->ybj) HIPCHK(c, hipMemsetAsync(c->scr_f0, 0, sizeof(cd), c->stream));
   HIPCHK(c, hipMemcpyAsync(out_cplx, c->scr_f0, sizeof(cd) * (size_t)c->N * c->N, hipMemcpyDeviceToHost, c->stream));
   return nq_sync(c);
 }
 // ---- diagnostics tick on the device (ref Diagnostics.py:41-58, Kernel.py:613-706, :718-868, CoupledModel.py:99-136) --
 int nq_diagnostics(nq_ctx* c, double* out) {
   NQ_SINGLE_RANK(c, "nq_diagnostics");
-  if (!c || !out) return -1;
+  if (!out) NQ_FAIL(c, -1, "nq_diagnostics: null output");
   HIPCHK(c, hipSetDevice(c->device));
   const int N = c->N, NB = 1024;
   const double M = (double)N * N;
@@ -1887,16 +1984,48 @@ int nq_diagnostics(nq_ctx* c, double* out) {
   return nq_sync(c);
 }
 
-int nq_jacobian_phic_phi(nq_ctx* c, double* out_cplx) {
-  // out: half-spectrum plane F[Re i(phix* phiy - phiy* phix)]
-  NQ_SINGLE_RANK(c, "nq_jacobian_phic_phi");
-  if (!c || !out_cplx) return -1;
-  if (c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "jacobian_phic_phi exists only in the coupled model");
+// fft(phi * q_psi), (ny, nx): the refraction source of ref Kernel.py:332, :350, :367, :385 before its -0.5j factor,
+// formed by the row kernel exactly as inside a step (mean NOT removed)
+int nq_refraction(nq_ctx* c, double* out_cplx) {
+  NQ_SINGLE_RANK(c, "nq_refraction");
+  if (!out_cplx) NQ_FAIL(c, -1, "nq_refraction: null output");
+  if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
   HIPCHK(c, hipSetDevice(c->device));
+  const size_t full = (size_t)c->N * c->N;
+  launch_products(c, 0.0, 1.0);                       // W = i phi q_psi
+  launch_A_m(c, false, {&c->mW});
+  launch_B_p(c, false, c->mW.ys, c->mW.pitch, c->scr_f0, c->N, c->N, 1.0);
+  hipLaunchKernelGGL(k_mul_minus_i, dim3((unsigned)((full + 255) / 256)), dim3(256), 0, c->stream, c->scr_f0, full);
+  HIPCHK(c, hipMemcpyAsync(out_cplx, c->scr_f0, sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+
+// CoupledModel.jacobian_phic_phi (ref CoupledModel.py:59-73): fft(Re i(phix* phiy - phiy* phix)), (ny, nx), [0,0] = 0
+int nq_jacobian_phic_phi(nq_ctx* c, double* out_cplx) {
+  NQ_SINGLE_RANK(c, "nq_jacobian_phic_phi");
+  if (!out_cplx) NQ_FAIL(c, -1, "nq_jacobian_phic_phi: null output");
+  if (c->p.model != NQ_MODEL_COUPLED || c->ybj) NQ_FAIL(c, -4, "jacobian_phic_phi exists only in the coupled model");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = c->N;
   launch_wavepv(c);
   launch_A_m(c, false, {&c->mB});
   launch_B_p(c, false, c->mB.ys, c->mB.pitch, c->scr_h0, c->Ph, c->Wh, 1.0);
-  return get_half_spec(c, c->scr_h0, out_cplx);
+  hipLaunchKernelGGL(k_expand_half, dim3((N + 63) / 64, N), dim3(64), 0, c->stream, (const cd*)c->scr_h0, (const cd*)nullptr, c->scr_f0, N, c->Ph, N, 0, c->kk, c->ll);
+  HIPCHK(c, hipMemsetAsync(c->scr_f0, 0, sizeof(cd), c->stream));
+  HIPCHK(c, hipMemcpyAsync(out_cplx, c->scr_f0, sizeof(cd) * (size_t)N * N, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+
+// number of DOUBLES nq_get_field(field_id) writes for this context (-1: unknown id)
+long long nq_field_doubles(const nq_ctx* c, int id) {
+  if (!c) return -1;
+  const long long n = c->N, h = c->N / 2 + 1;
+  switch (id) {
+    case NQ_F_Q: case NQ_F_P: case NQ_F_U: case NQ_F_V: case NQ_F_QPSI: case NQ_F_QW: case NQ_F_C: return n * n;
+    case NQ_F_QH: case NQ_F_PH: case NQ_F_QWH: case NQ_F_QH_MINUS: case NQ_F_CH: case NQ_F_QH_STAGE4: return 2 * n * h;
+    case NQ_F_PHI: case NQ_F_PHIH: case NQ_F_PHIX: case NQ_F_PHIY: return 2 * n * n;
+    default: return -1;
+  }
 }
 
 }  // extern "C"

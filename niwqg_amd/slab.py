@@ -210,6 +210,25 @@ class SlabSimulation(object):
         for r in self.ranks:
             r.refresh_grad_phi()
 
+    def set_q(self, q):
+        """physical q (ny, nx) on the host (every rank holds the same array)"""
+        self.set_q_spectrum(np.fft.rfft2(q))
+
+    def set_phi(self, phi):
+        self.set_phi_spectrum(np.fft.fft2(phi))
+
+    def describe(self):
+        return "one all_to_all_single per transition (16 per Coupled step), phases dispatched from Python"
+
+    def reset_counters(self):
+        pass
+
+    def counters(self, nsteps):
+        """volume this rank hands to the all-to-alls per step (off-rank part), for the xGMI arithmetic in DESIGN.md 9"""
+        P = self.ranks[0].nranks
+        per_stage = sum(t.numel() * 16 for t in self.ranks[0].gx if t is not None)
+        return {"exchange_GB_sent_per_rank_per_step": 4 * per_stage * (P - 1) / max(P, 1) / 1e9}
+
     # --- time stepping --------------------------------------------------------------------------------------
     def step(self, nsteps=1):
         tr, ranks = self.tr, self.ranks

@@ -13,6 +13,12 @@ Rules (see the task statement, section 3):
     the build container by ``tests/golden/make_golden.py``, which imports the
     real reference) -- ``tests/test_oracle_golden.py`` is that check.
 
+``workers`` (default 1 = the reference's arithmetic and cost exactly: numpy.fft, one thread) lets the parity tests at
+2048^2 and above finish in minutes: the coefficient tables are then built chunk-by-chunk on a thread pool (same
+arithmetic per element) and the FFT seam goes through ``scipy.fft`` with that many workers, which moves q and phi by
+~3e-16 relative ("noise floor").  ``table_workers`` threads only the (one-off) coefficient tables.  The CPU baseline of bench.py times
+steps with workers=1 (numpy.fft, one thread) and uses table_workers only to shorten the untimed constructor.
+
 It deliberately keeps the reference's transform count (104 / 72 / 33 full 2-D
 transforms per step for Coupled / UnCoupled / QG) so that it can stand in for the
 reference's CPU cost; ``fft_calls`` counts them.
@@ -89,7 +95,7 @@ def spectral_filter(g: SpectralGrid, use_filter: bool, dealias: bool) -> np.ndar
 _CONTOUR_M = 32
 
 
-def etdrk4_tables(c: np.ndarray, dt: float, rows_per_chunk: int = 64) -> dict:
+def etdrk4_tables(c: np.ndarray, dt: float, rows_per_chunk: int = 64, workers: int = 1) -> dict:
     """ETDRK4 (Cox-Matthews / Kassam-Trefethen) coefficient planes for exponent ``c``.
 
     ref: niwqg/Kernel.py:419-433 (and :443-454, QGModel.py:429-443).  The reference
@@ -100,7 +106,7 @@ def etdrk4_tables(c: np.ndarray, dt: float, rows_per_chunk: int = 64) -> dict:
     ch = c * dt
     r = np.exp(2j * np.pi * (np.arange(1.0, _CONTOUR_M + 1) / _CONTOUR_M))
     out = {k: np.empty_like(ch) for k in ("Q", "f0", "fab", "fc")}
-    for r0 in range(0, ch.shape[0], rows_per_chunk):
+    def chunk(r0):
         sl = slice(r0, r0 + rows_per_chunk)
         LR = ch[sl, :, None] + r[None, None, :]
         LR2 = LR * LR
@@ -110,6 +116,15 @@ def etdrk4_tables(c: np.ndarray, dt: float, rows_per_chunk: int = 64) -> dict:
         out["f0"][sl] = dt * ((-4.0 - LR + eLR * (4.0 - 3.0 * LR + LR2)) / LR3).mean(axis=-1)
         out["fab"][sl] = dt * ((2.0 + LR + eLR * (-2.0 + LR)) / LR3).mean(axis=-1)
         out["fc"][sl] = dt * ((-4.0 - 3.0 * LR - LR2 + eLR * (4.0 - LR)) / LR3).mean(axis=-1)
+
+    starts = range(0, ch.shape[0], rows_per_chunk)
+    if workers > 1:                 # numpy ufuncs release the GIL: row chunks in parallel, same arithmetic per element
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(chunk, starts))
+    else:
+        for r0 in starts:
+            chunk(r0)
     out["E"] = np.exp(ch)
     out["Eh"] = np.exp(ch / 2.0)
     return out
@@ -152,9 +167,11 @@ class NIWQGOracle:
     def __init__(self, kind="coupled", nx=128, ny=None, L=5e5, dt=10000.0, twrite=1000.0,
                  tmax=250000.0, use_filter=True, cflmax=0.8, U=0.0, f=1e-4, N=0.01,
                  m=0.025, g=9.81, nu4=0, nu4w=0, nu=20, nuw=50.0, mu=0, muw=0,
-                 dealias=False, tdiags=10, coeff_chunk=64):
+                 dealias=False, tdiags=10, coeff_chunk=64, workers=1, table_workers=None):
         assert kind in ("coupled", "uncoupled", "ybj")
         self.kind = kind
+        self.workers = int(workers)
+        table_workers = self.workers if table_workers is None else int(table_workers)
         # ref: niwqg/Kernel.py:100-137 (parameter bookkeeping; ny ignored)
         self.nx = self.ny = nx
         self.L = self.W = L
@@ -190,8 +207,8 @@ class NIWQGOracle:
         cq += -nu4 * self.wv4 - nu * self.wv2 - mu
         cw = np.zeros(shp, complex) - 1j * self.k * U
         cw += -nu4w * self.wv4 - 0.5j * f * (self.wv2 / self.kappa2) - nuw * self.wv2 - muw
-        self.coef_q = etdrk4_tables(cq, dt, coeff_chunk)
-        self.coef_w = etdrk4_tables(cw, dt, coeff_chunk)
+        self.coef_q = etdrk4_tables(cq, dt, coeff_chunk, table_workers)
+        self.coef_w = etdrk4_tables(cw, dt, coeff_chunk, table_workers)
 
         self.t = 0          # ref: niwqg/Kernel.py:219-225
         self.tc = 0
@@ -201,10 +218,16 @@ class NIWQGOracle:
     # ---- FFT seam (ref: niwqg/Kernel.py:553-566) --------------------------
     def fft(self, a):
         self.fft_calls[0] += 1
+        if self.workers > 1:
+            import scipy.fft
+            return scipy.fft.fft2(a, workers=self.workers)
         return np.fft.fft2(a)
 
     def ifft(self, a):
         self.fft_calls[1] += 1
+        if self.workers > 1:
+            import scipy.fft
+            return scipy.fft.ifft2(a, workers=self.workers)
         return np.fft.ifft2(a)
 
     # ---- model closures ----------------------------------------------------
@@ -325,7 +348,7 @@ class NIWQGOracle:
         self._calc_rel_vorticity()
         J = self.u * self.phix + self.v * self.phiy
         self.fft_calls[1] += 1
-        self.lapphi = np.fft.ifft2(-self.wv2 * self.phih)
+        self.lapphi = np.fft.ifft2(-self.wv2 * self.phih) if self.workers <= 1 else self.ifft(-self.wv2 * self.phih)
         lap2phi = self.ifft(self.wv4 * self.phih)
         diss = -self.nu4w * lap2phi + self.nuw * self.lapphi - self.muw * self.phi
         J_diss = -(diss * np.conj(J)).imag
@@ -508,7 +531,10 @@ class QGOracle:
 
     def __init__(self, nx=128, ny=None, L=5e5, dt=10000.0, twrite=1000, tmax=250000.0,
                  use_filter=True, U=0.0, nu4=5e9, nu=0, mu=0, beta=0, dealias=False,
-                 tdiags=10, coeff_chunk=64, passive_scalar=False, nu4c=5e9, nuc=0, muc=0):
+                 tdiags=10, coeff_chunk=64, passive_scalar=False, nu4c=5e9, nuc=0, muc=0, workers=1,
+                 table_workers=None):
+        self.workers = int(workers)
+        table_workers = self.workers if table_workers is None else int(table_workers)
         self.nx = self.ny = nx
         self.L = self.W = L
         self.dt, self.twrite, self.tmax, self.tdiags = dt, twrite, tmax, tdiags
@@ -527,12 +553,12 @@ class QGOracle:
         c = np.zeros(self.qh.shape, complex)
         c += -nu4 * self.wv4 - nu * self.wv2 - mu - 1j * self.k * U
         c += beta * self.ik * self.wv2i
-        self.coef_q = etdrk4_tables(c, dt, coeff_chunk)
+        self.coef_q = etdrk4_tables(c, dt, coeff_chunk, table_workers)
         self.passive_scalar, self.nu4c, self.nuc, self.muc = passive_scalar, nu4c, nuc, muc
         if passive_scalar:          # ref: niwqg/QGModel.py:446-466 (no mean-flow or beta term in this operator)
             cc = np.zeros(self.qh.shape, complex)
             cc += -nu4c * self.wv4 - nuc * self.wv2 - muc
-            self.coef_c = etdrk4_tables(cc, dt, coeff_chunk)
+            self.coef_c = etdrk4_tables(cc, dt, coeff_chunk, table_workers)
         self.C2, self.gradC2, self.cvar, self.Gamma_c = 0.0, 0.0, 0.0, 0.0
         self.t = 0
         self.tc = 0
@@ -542,10 +568,16 @@ class QGOracle:
 
     def fft(self, a):               # ref: niwqg/QGModel.py:551
         self.fft_calls[0] += 1
+        if self.workers > 1:
+            import scipy.fft
+            return scipy.fft.rfft2(a, workers=self.workers)
         return np.fft.rfft2(a)
 
     def ifft(self, a):              # ref: niwqg/QGModel.py:552
         self.fft_calls[1] += 1
+        if self.workers > 1:
+            import scipy.fft
+            return scipy.fft.irfft2(a, workers=self.workers)
         return np.fft.irfft2(a)
 
     def spec_var(self, ah):         # ref: niwqg/QGModel.py:611-619

@@ -1,0 +1,215 @@
+"""Parity AT SIZE: the BASELINE configurations on their own workloads, and states that fill the whole spectrum.
+
+The small-grid tests pin the algorithm; these pin the size-dependent machinery -- the per-size row plans (2048: 256
+threads x 8 points, 4096: persistent 512 x 8 with two transforms in flight, 8192: even/odd split), high-index twiddles,
+the filter band, the Nyquist row/column rules -- against the CPU oracle (oracle/niwqg_oracle.py, pinned to the reference
+by tests/test_oracle_golden.py) on white-noise states, where every mode of the grid is populated.
+
+The oracle runs with ``workers=NW`` here (thread pool for its coefficient tables, scipy.fft for its FFT seam: 3e-16
+away from the numpy.fft path) so that one step at 4096^2 costs a few minutes instead of half an hour;
+tests/test_oracle_golden.py::test_oracle_workers_option_is_arithmetic_neutral pins that option on the CPU.
+
+Tolerances: relative L2; BASELINE bar 1e-10 over 100 steps.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import niwqg_oracle as O
+from test_oracle_golden import notebook_kwargs, rel, L, K0, U0
+
+pytestmark = pytest.mark.gpu
+
+NW = max(1, min(16, (os.cpu_count() or 2) - 1))
+
+
+def steps(m, n):
+    while m.tc < n:
+        m._step_forward()
+
+
+def rel_no_passenger(qh, ref):
+    n = ref.shape[0]
+    a, b = qh.copy(), ref.copy()
+    for x in (a, b):
+        x[n // 2, 1:n // 2] = 0
+        x[n // 2, n // 2 + 1:] = 0
+    return rel(a, b)
+
+
+# ---- BASELINE config 2: QGModel 2048^2, random q ---------------------------------------------------------------------
+def test_config2_qgmodel_2048_random_q_against_the_oracle():
+    """ref: niwqg/QGModel.py:328-407 on BASELINE.json configs[1] exactly as bench.py --model qg --nx 2048 builds it."""
+    import niwqg_amd
+    import bench
+    nx = 2048
+    kw = bench.c3_kwargs(nx, "qg")
+    q0 = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx))
+    m = niwqg_amd.QGModel.Model(**kw)
+    o = O.QGOracle(coeff_chunk=8, workers=NW, **kw)
+    for x in (m, o):
+        x.set_q(q0)
+    for _ in range(2):
+        o._step_forward()
+    steps(m, 2)
+    eq, eh, ep = rel(m.q, o.q), rel(m.qh, o.qh), rel(m.ph, o.ph)
+    print("QG 2048^2 randn, 2 steps: rel q %.2e qh %.2e ph %.2e; Ke %.6e vs %.6e" % (eq, eh, ep, m.Ke, o.Ke))
+    assert eq < 1e-11 and eh < 1e-11 and ep < 1e-11
+    assert abs(m.Ke - o.Ke) < 1e-10 * abs(o.Ke)
+    assert abs(m._calc_ke_qg() - o._calc_ke_qg()) < 1e-11 * o._calc_ke_qg()
+    # the spectrum really is full: the last retained column / the Nyquist row carry energy before the filter acts
+    h0 = np.abs(np.fft.rfft2(q0))
+    assert h0[nx // 2, 5] > 0 and h0[7, nx // 2] > 0
+
+
+# ---- BASELINE config 5: UnCoupledModel 1024^2 ensemble members --------------------------------------------------------
+@pytest.mark.parametrize("member,tdiags", [(0, 1), (0, 10 ** 9), (7, 1), (7, 10 ** 9)])
+def test_config5_uncoupled_1024_member_against_the_oracle(member, tdiags):
+    """ref: niwqg/UnCoupledModel.py:54-64 with quirk Q1 (stale phix, phiy: the trajectory depends on tdiags) at the size and
+    on the initial condition of BASELINE.json configs[4] (niwqg_amd.ensemble.config5_member)."""
+    from niwqg_amd import ensemble, InitialConditions as ic
+    nx = 1024
+    m = ensemble.config5_member(member, nx=nx, tdiags=tdiags)
+    kw = dict(L=m.L, nx=nx, tmax=1e30, dt=m.dt, m=m.m, N=m.N, f=m.f, twrite=10 ** 9, tdiags=tdiags, nu4=m.nu4, nu4w=m.nu4w,
+              nu=m.nu, nuw=m.nuw, mu=m.mu, muw=m.muw, use_filter=True, U=m.U)
+    o = O.NIWQGOracle("uncoupled", coeff_chunk=8, workers=NW, **kw)
+    o.set_q(1e-5 * np.random.default_rng(member).standard_normal((nx, nx)))
+    o.set_phi(0.1 * O.wave_packet(o.grid, k=3 * K0, l=0, R=L / 6, x0=L / 2, y0=L / 2))
+    for _ in range(2):
+        o._step_forward()
+    steps(m, 2)
+    eq, ep, eh = rel(m.q, o.q), rel(m.phi, o.phi), rel(m.phih, o.phih)
+    print("UnCoupled 1024^2 member %d tdiags=%g, 2 steps: rel q %.2e phi %.2e phih %.2e" % (member, tdiags, eq, ep, eh))
+    assert eq < 1e-11 and ep < 1e-11 and eh < 1e-11
+    assert rel(m.phix, o.phix) < 1e-11 and rel(m.phiy, o.phiy) < 1e-11      # stale or fresh, as the reference leaves them
+    assert np.allclose([m.Ke, m.Pw, m.Kw], [o.Ke, o.Pw, o.Kw], rtol=1e-8)
+
+
+def test_config5_q1_is_visible_at_size():
+    """tdiags=1 and tdiags=inf must DIFFER (quirk Q1 acts at 1024^2 as it does in golden g4 at 64^2)."""
+    from niwqg_amd import ensemble
+    a = ensemble.config5_member(3, nx=1024, tdiags=1)
+    b = ensemble.config5_member(3, nx=1024, tdiags=10 ** 9)
+    steps(a, 3)
+    steps(b, 3)
+    assert rel(a.phi, b.phi) > 1e-6
+
+
+# ---- rough fields at size: CoupledModel, every dissipation parameter non-zero ----------------------------------------
+def rough_kwargs(nx):
+    kw = notebook_kwargs(nx, True)
+    kw.update(nu4w=kw["nu4"] * 0.1, mu=1e-8, muw=2e-8)
+    return kw
+
+
+@pytest.mark.parametrize("nx", [2048, 4096])
+def test_rough_field_coupled_step_against_the_oracle(nx):
+    """One full ETDRK4 step (ref: niwqg/Kernel.py:307-397, CoupledModel.py:59-97) of white-noise q and phi: the filter
+    band, the Nyquist lines and every high-index twiddle of the size's own kernels are exercised and compared."""
+    import niwqg_amd
+    kw = rough_kwargs(nx)
+    rng = np.random.default_rng(11)
+    q0 = 1e-5 * rng.standard_normal((nx, nx))
+    phi0 = 0.05 * (rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx)))
+    m = niwqg_amd.CoupledModel.Model(**kw)
+    m.set_q(q0)
+    m.set_phi(phi0)
+    steps(m, 1)
+    got = dict(q=m.q, phi=m.phi, phih=m.phih, qh=m.qh, ph=m.ph, b=[m.Ke, m.Pw, m.Kw])
+    del m                                            # free the device before the oracle's host arrays grow
+    o = O.NIWQGOracle("coupled", coeff_chunk=4, workers=NW, **kw)
+    o.set_q(q0)
+    o.set_phi(phi0)
+    o._step_forward()
+    errs = {k: rel(got[k], getattr(o, k)) for k in ("q", "phi", "phih", "ph")}
+    errs["qh"] = rel_no_passenger(got["qh"], o.qh)
+    print("Coupled %d^2 rough field, 1 step:" % nx, {k: "%.2e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < 1e-11, (k, v)
+    assert np.allclose(got["b"], [o.Ke, o.Pw, o.Kw], rtol=1e-8)
+    # what was compared is rough: the filter-band modes are populated in the oracle's result
+    k65 = int(0.65 * nx / 2) + 3
+    assert np.abs(o.phih[k65, k65]) > 0 and np.abs(o.qh[k65, 3]) > 0
+
+
+# ---- 8192^2: the seam and the even/odd row kernels on a full spectrum --------------------------------------------------
+def test_fft_seam_8192_against_numpy():
+    """nq_fft2 / nq_ifft2 (ref: niwqg/Kernel.py:562-566) of a random 8192^2 plane against scipy/numpy pocketfft."""
+    import scipy.fft
+    import niwqg_amd
+    nx = 8192
+    m = niwqg_amd.CoupledModel.Model(**notebook_kwargs(nx, True))
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx))
+    fa = m.fft(a)
+    ref = scipy.fft.fft2(a, workers=NW)
+    e = rel(fa, ref)
+    print("8192^2 nq_fft2 vs pocketfft: %.2e" % e)
+    assert e < 2e-15
+    del ref
+    e = rel(m.ifft(fa), a)
+    assert e < 2e-15
+
+
+def test_row_kernels_8192_on_a_full_spectrum_against_numpy():
+    """k_x_products_eo / k_x_wavepv_eo (the 8192-point rows as two 4096-point problems) on white-noise q and phi, through the
+    C-ABI Jacobian exports, against the reference's formulas evaluated with pocketfft on the host:
+    jacobian_psi_q (ref Kernel.py:471-486), jacobian_psi_phi (:457-469), refraction (:332), jacobian_phic_phi and the
+    wave-PV inversion (CoupledModel.py:59-97)."""
+    import scipy.fft
+    import niwqg_amd
+    nx = 8192
+    kw = rough_kwargs(nx)
+    m = niwqg_amd.CoupledModel.Model(**kw)
+    rng = np.random.default_rng(21)
+    q0 = 1e-5 * rng.standard_normal((nx, nx))
+    phi0 = 0.05 * (rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx)))
+    m.set_phi(phi0)            # phi first: the inversion of set_q then contains the wave part (quirk Q2)
+    m.set_q(q0)
+
+    def F(a):
+        return scipy.fft.fft2(a, workers=NW)
+
+    def Fi(a):
+        return scipy.fft.ifft2(a, workers=NW)
+
+    kk = m.kk
+    ik, il = 1j * kk[None, :], 1j * m.ll[:, None]
+    wv2 = kk[None, :] ** 2 + m.ll[:, None] ** 2
+    wv2i = np.zeros_like(wv2)
+    wv2i[wv2 != 0] = 1.0 / wv2[wv2 != 0]
+    phih = F(phi0)
+    phix, phiy = Fi(ik * phih), Fi(il * phih)
+    jw = F((1j * (np.conj(phix) * phiy - np.conj(phiy) * phix)).real)
+    jw[0, 0] = 0
+    e = rel(m.jacobian_phic_phi(), jw)
+    print("8192^2 jacobian_phic_phi %.2e" % e)
+    assert e < 1e-12
+    qwh = 0.5 * (0.5 * (-wv2 * F(np.abs(phi0) ** 2)) + jw) / m.f * m.filtr
+    del jw
+    qh = F(q0)
+    pw = Fi(wv2i * qwh).real
+    pv = Fi(-(wv2i * qh)).real
+    ph = F(pv + pw)
+    del pw, pv
+    assert rel(m.ph, ph) < 1e-12
+    u, v = Fi(-il * ph).real, Fi(ik * ph).real
+    del ph
+    q = Fi(qh).real
+    jq = ik * F(u * q) + il * F(v * q)
+    jq[0, 0] = 0
+    e = rel(m.jacobian_psi_q(), jq)
+    print("8192^2 jacobian_psi_q %.2e" % e)
+    assert e < 1e-12
+    del jq
+    jp = F(u * phix + v * phiy)
+    jp[0, 0] = 0
+    e = rel(m.jacobian_psi_phi(), jp)
+    print("8192^2 jacobian_psi_phi %.2e" % e)
+    assert e < 1e-12
+    del jp, u, v, phix, phiy
+    q_psi = q - Fi(qwh).real
+    e = rel(m._ctx.refraction(), F(phi0 * q_psi))
+    print("8192^2 refraction %.2e" % e)
+    assert e < 1e-12

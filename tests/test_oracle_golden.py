@@ -233,3 +233,29 @@ def test_qg_passive_scalar_oracle_matches_reference(golden):
         assert np.allclose([o.Ke, o.cvar, o.C2, o.gradC2], g["scalars_" + key], rtol=1e-11)
         for name in o.diagnostics:
             assert np.allclose(o.diag(name), g["diag_%s_%s" % (name, key)], rtol=1e-9, atol=1e-30), name
+
+
+def test_oracle_workers_option_is_arithmetic_neutral():
+    """``workers > 1`` (threaded coefficient tables, scipy.fft seam) is only there to make the at-size GPU parity tests
+    affordable: the tables must be bit-identical and the trajectory within the FFT-backend noise floor."""
+    kw = notebook_kwargs(128, True)
+    kw.update(nu4w=1e9, mu=1e-8, muw=2e-8)
+    a = O.NIWQGOracle("coupled", coeff_chunk=8, **kw)
+    b = O.NIWQGOracle("coupled", coeff_chunk=8, workers=4, **kw)
+    for nm in ("E", "Eh", "Q", "f0", "fab", "fc"):
+        assert np.array_equal(a.coef_q[nm], b.coef_q[nm]) and np.array_equal(a.coef_w[nm], b.coef_w[nm])
+    rng = np.random.default_rng(2)
+    q0 = 1e-5 * rng.standard_normal((128, 128))
+    phi0 = 0.05 * (rng.standard_normal((128, 128)) + 1j * rng.standard_normal((128, 128)))
+    for o in (a, b):
+        o.set_q(q0)
+        o.set_phi(phi0)
+        steps(o, 5)
+    assert rel(b.q, a.q) < 1e-13 and rel(b.phi, a.phi) < 1e-13
+    assert np.allclose([b.Ke, b.Pw, b.Kw], [a.Ke, a.Pw, a.Kw], rtol=1e-11)
+    qa = O.QGOracle(L=L, nx=128, dt=a.dt, nu4=5e11, U=-U0, tdiags=10 ** 9, twrite=10 ** 9, tmax=1e30)
+    qb = O.QGOracle(L=L, nx=128, dt=a.dt, nu4=5e11, U=-U0, tdiags=10 ** 9, twrite=10 ** 9, tmax=1e30, workers=4)
+    for o in (qa, qb):
+        o.set_q(q0)
+        steps(o, 5)
+    assert rel(qb.q, qa.q) < 1e-13

@@ -451,4 +451,5 @@ struct WgFft {
   }
 };
 
+
 }  // namespace nq

@@ -668,19 +668,19 @@ static YGeom geom_full(const nq_ctx* c) {
 }
 
 // fused-stage launches ----------------------------------------------------------------------------
-static void launch_wavepv(nq_ctx* c) {
-  ProfScope ps(c, PK_WAVEPV);
+template <bool SLAB>
+static void launch_wavepv_t(nq_ctx* c) {
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx1, c->kk); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n, SLAB>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx1, c->kk); } break;
     case 8192:
       if (c->eo_scratch) {                            // even / odd samples as two 4096-point problems (no spills)
         typedef XPlan<4096> X;
         const int nb = c->Nloc, grid = nb < c->num_cu ? nb : c->num_cu;
         const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd);
-        hipLaunchKernelGGL((k_x_wavepv_eo<8192>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx_half, c->tw, c->kk, nb, c->eo_scratch);
+        hipLaunchKernelGGL((k_x_wavepv_eo<8192, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx_half, c->tw, c->kk, nb, c->eo_scratch);
       } else {
         typedef XPlan1<8192> X;
-        hipLaunchKernelGGL((k_x_wavepv<8192>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx1, c->kk);
+        hipLaunchKernelGGL((k_x_wavepv<8192, SLAB>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx1, c->kk);
       }
       break;
     case 4096: {                                      // long rows: two transforms in flight, no spills
@@ -689,14 +689,20 @@ static void launch_wavepv(nq_ctx* c) {
       int grid = c->num_cu - (c->stream2 ? c->overlap_cus : 0);                    // one persistent workgroup per CU
       const int nb = c->Nloc / X::C;
       if (grid > nb) grid = nb;
-      hipLaunchKernelGGL((k_x_wavepv2<4096>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx, c->kk, nb);
+      hipLaunchKernelGGL((k_x_wavepv2<4096, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx, c->kk, nb);
     } break;
     M_SMALL(CASE_)
 #undef CASE_
   }
 }
-template <int MODE>
-static void launch_products_m(nq_ctx* c, double cj, double cr, bool fresh_grad) {
+// one rank: the row kernels address their rows without the block arithmetic of the slab layout (XRowT<false>)
+static void launch_wavepv(nq_ctx* c) {
+  ProfScope ps(c, PK_WAVEPV);
+  if (c->P > 1) launch_wavepv_t<true>(c);
+  else launch_wavepv_t<false>(c);
+}
+template <int MODE, bool SLAB>
+static void launch_products_t(nq_ctx* c, double cj, double cr, bool fresh_grad) {
   const int vz = c->kernel_family ? 1 : 0;
   if (c->N == 8192 && MODE != MODE_QGC && c->eo_scratch) {
     // rows too long for the register budget as one transform: even / odd samples as two 4096-point problems
@@ -705,7 +711,7 @@ static void launch_products_m(nq_ctx* c, double cj, double cr, bool fresh_grad) 
     const MArr& gy8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGy : c->mPhiy;
     const int nb = c->Nloc, grid = nb < c->num_cu ? nb : c->num_cu;
     const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd);
-    hipLaunchKernelGGL((k_x_products_eo<8192, MODE>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx8, gy8, c->mUq, c->mVq, c->mW, c->twx_half, c->tw, c->kk, vz, cj, cr, nb, c->eo_scratch);
+    hipLaunchKernelGGL((k_x_products_eo<8192, MODE, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx8, gy8, c->mUq, c->mVq, c->mW, c->twx_half, c->tw, c->kk, vz, cj, cr, nb, c->eo_scratch);
     return;
   }
   const MArr& gx = (MODE == MODE_QGC) ? c->mUc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGx : c->mPhi);
@@ -714,10 +720,15 @@ static void launch_products_m(nq_ctx* c, double cj, double cr, bool fresh_grad) 
 #define CASE_(n, a, b) case n: { typedef XPlan<n> X; const int nb = c->Nloc / X::C; \
     /* one workgroup fits per CU (LDS) and does not spill: persistent; 8192-point rows spill and do better with dynamic dispatch */ \
     const int grid = (X::LDS_BYTES > 80 * 1024 && X::THREADS <= 512 && nb > c->num_cu) ? c->num_cu : nb; \
-    hipLaunchKernelGGL((k_x_products<n, MODE>), dim3(grid), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mW, c->twx, c->kk, vz, cj, cr, nb); } break;
+    hipLaunchKernelGGL((k_x_products<n, MODE, SLAB>), dim3(grid), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mW, c->twx, c->kk, vz, cj, cr, nb); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
+}
+template <int MODE>
+static void launch_products_m(nq_ctx* c, double cj, double cr, bool fresh_grad) {
+  if (c->P > 1) launch_products_t<MODE, true>(c, cj, cr, fresh_grad);
+  else launch_products_t<MODE, false>(c, cj, cr, fresh_grad);
 }
 // Mw <- cj * (u phix + v phiy) + i cr * phi q_psi; a step uses the phi tendency itself: cj = -1, cr = -1/2
 // fresh_grad (UnCoupled layouts only): phix, phiy from the rows of Mphi, Mphiy instead of the frozen copy
@@ -1017,7 +1028,7 @@ static void launch_project(nq_ctx* c, double* part) {
 template <int MODE>
 static void launch_xdiag_m(nq_ctx* c, double qbar, double abar, double* part) {
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_diag<n, MODE>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mQ, c->mQw, c->mPhi, c->twx, c->kk, qbar, abar, part); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_diag<n, MODE, false>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mQ, c->mQw, c->mPhi, c->twx, c->kk, qbar, abar, part); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }

@@ -39,23 +39,31 @@ struct MArr {
   unsigned magic;    // else kx / W = (kx * magic) >> 24, magic = ceil(2^24 / W); exact for kx < 8192, W < 2048
   long long blk;     // X-side block stride = local rows * pitch
 };
-struct XRow {        // one local row of an MArr on the X side
+// One local row of an MArr on the X side.  SLAB = false (one rank: a single block) makes at() a plain `p + kx`: the
+// block arithmetic costs eight integer instructions per access, three of them quarter-rate 32-bit multiplies, and the
+// row kernels make ~90 accesses per row -- a quarter of their VALU time (profiles/r02 notes in DESIGN.md section 4).
+template <bool SLAB>
+struct XRowT {
   cd* p;
   int W, shift;
   unsigned magic;
   long long blk;
   __device__ __forceinline__ cd* at(int kx) const {
+    if constexpr (!SLAB) return p + kx;
     const int b = shift >= 0 ? (kx >> shift) : (int)(((unsigned)kx * magic) >> 24);
     return p + (long long)b * blk + (kx - b * W);
   }
 };
-__device__ __forceinline__ XRow xrow(const MArr& a, size_t row) {
-  XRow r;
+template <bool SLAB>
+__device__ __forceinline__ XRowT<SLAB> xrow(const MArr& a, size_t row) {
+  XRowT<SLAB> r;
   r.p = a.xs + row * (size_t)a.pitch;
-  r.W = a.W;
-  r.shift = a.shift;
-  r.magic = a.magic;
-  r.blk = a.blk;
+  if constexpr (SLAB) {
+    r.W = a.W;
+    r.shift = a.shift;
+    r.magic = a.magic;
+    r.blk = a.blk;
+  }
   return r;
 }
 // Column-slab geometry of the spectral (Y-side) kernels.
@@ -82,8 +90,8 @@ struct YGeom {
 template <int P> struct HsRegs {
   cd a[P / 2], b[P / 2], an, bn;      // elements m = j + t*T (t < P/2) and, for thread j = 0, m = N/2
 };
-template <int N, int P, int T, bool PAIR>
-__device__ __forceinline__ void hs_load(HsRegs<P>& r, const XRow& rowA, const XRow& rowB, int j) {
+template <int N, int P, int T, bool PAIR, typename Row>
+__device__ __forceinline__ void hs_load(HsRegs<P>& r, const Row& rowA, const Row& rowB, int j) {
 #pragma unroll
   for (int t = 0; t < P / 2; ++t) {
     r.a[t] = *rowA.at(j + t * T);
@@ -133,9 +141,9 @@ __device__ __forceinline__ void hs_pack(cd (&w)[P], const HsRegs<P>& r, int j, i
 
 // After a forward row FFT of z = a + i*b (a, b real), split into the two half spectra and store
 // kx = 0..N/2.  Needs the mirrored element Z[N-kx], fetched through LDS.
-template <int N, int P, int T, typename F>
-__device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* lds, const XRow& rowA,
-                                                  const XRow& rowB, double scaleB = 1.0) {
+template <int N, int P, int T, typename F, typename Row>
+__device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* lds, const Row& rowA,
+                                                  const Row& rowB, double scaleB = 1.0) {
   wg_barrier();
 #pragma unroll
   for (int t = 0; t < P; ++t) lds[F::lds_index(j + t * T, c)] = r[t];
@@ -156,14 +164,14 @@ __device__ __forceinline__ void unpack_pair_store(cd (&r)[P], int j, int c, cd* 
 
 // ---- X1: wave potential-vorticity sources (CoupledModel._invert, ref CoupledModel.py:59-88) ------
 // The spectral row of phi is fetched once and kept (sp) for the second transform (phix = ifft(ik phi)).
-template <int N>
+template <int N, bool SLAB>
 __global__ void __launch_bounds__(XPlan1<N>::THREADS, XPlan1<N>::MIN_WAVES)
 k_x_wavepv(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, const double* __restrict__ kk) {
   typedef XPlan1<N> X;
   constexpr int P = X::P, T = X::T;
   const int j = threadIdx.x % T, c = threadIdx.x / T;
   const size_t row = (size_t)blockIdx.x * X::C + c;
-  const XRow rphi = xrow(Mphi, row), rphiy = xrow(Mphiy, row);
+  const XRowT<SLAB> rphi = xrow<SLAB>(Mphi, row), rphiy = xrow<SLAB>(Mphiy, row);
   cd* lds = reinterpret_cast<cd*>(nq_smem);
   // stage twiddles: table in LDS behind the exchange area (`tw` = host-built stage table here)
   cd* twl = lds + XPlan1<N>::F::LDS_ELEMS;
@@ -227,14 +235,14 @@ k_x_wavepv(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, c
   NQ_PHASE_FENCE();
   X::F::template run<false>(w, j, c, lds, twr);
   NQ_PHASE_FENCE();
-  unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, xrow(Ma, row), xrow(Mb, row), isb);
+  unpack_pair_store<N, P, T, typename X::F>(w, j, c, lds, xrow<SLAB>(Ma, row), xrow<SLAB>(Mb, row), isb);
 }
 
 // Variant for long rows: 8 points per thread, ONE workgroup per CU, the two transforms that share an input (phi and
 // phix = ifft(ik phi)) in flight together (WgFft::run2: the LDS stores of one drain under the butterflies of the
 // other), phiy prefetched under them.  No spills (k_x_wavepv at 16 points per thread spills 32 VGPRs at 4096:
 // +0.33 GB of scratch traffic per launch, profiles/r01_pmc_summary.json).
-template <int N>
+template <int N, bool SLAB>
 __global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
 k_x_wavepv2(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, const double* __restrict__ kk,
             int nblocks) {
@@ -253,7 +261,7 @@ k_x_wavepv2(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, 
   // forward transform of this one, so its latency hides behind that transform and the stores
   cd nxt[P];
   {
-    const XRow r0 = xrow(Mphi, (size_t)blockIdx.x * X::C + c_tid);
+    const XRowT<SLAB> r0 = xrow<SLAB>(Mphi, (size_t)blockIdx.x * X::C + c_tid);
 #pragma unroll
     for (int t = 0; t < P; ++t) nxt[t] = *r0.at(j_tid + t * T);
   }
@@ -264,7 +272,7 @@ k_x_wavepv2(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, 
     asm volatile("" : "+v"(j), "+v"(c));
     const size_t row = (size_t)rb * X::C + c;
     const bool more = rb + (int)gridDim.x < nblocks;
-    const XRow rphiy = xrow(Mphiy, row);
+    const XRowT<SLAB> rphiy = xrow<SLAB>(Mphiy, row);
     cd w[P], gx[P], py[P];
     double a[P];
 #pragma unroll
@@ -292,7 +300,7 @@ k_x_wavepv2(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, 
       w[t] = cmake(a[t], b);
     }
     if (more) {
-      const XRow rn = xrow(Mphi, row + (size_t)gridDim.x * X::C);
+      const XRowT<SLAB> rn = xrow<SLAB>(Mphi, row + (size_t)gridDim.x * X::C);
 #pragma unroll
       for (int t = 0; t < P; ++t) nxt[t] = *rn.at(j + t * T);
     }
@@ -316,7 +324,7 @@ k_x_wavepv2(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, 
     NQ_PHASE_FENCE();
     F::template run<false>(w, j, c, lds, twr);
     NQ_PHASE_FENCE();
-    unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow(Ma, row), xrow(Mb, row), isb);
+    unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow<SLAB>(Ma, row), xrow<SLAB>(Mb, row), isb);
   }
 }
 
@@ -327,7 +335,7 @@ k_x_wavepv2(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, 
 // MODE_QG: only Muq, Mvq.  MODE_QGC: the passive scalar c arrives paired with q (Mqw slot) and the products u c, v c leave
 // through Mgx, Mgy (= the Muc, Mvc half-spectrum arrays).  MODE_UNCOUPLED: q_psi = q, phix/phiy from the (possibly stale) Mgx/Mgy.
 // Register plan: q, q_psi, u, v are reals (32 VGPRs each); complex working sets are 64.
-template <int N, int MODE>
+template <int N, int MODE, bool SLAB>
 __global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
 k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy, MArr Muq, MArr Mvq, MArr Mw,
              const cd* __restrict__ tw, const double* __restrict__ kk, int v_zero_nyq, double cj, double cr,
@@ -353,7 +361,7 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   HsRegs<P> h1;
   {
     const size_t row0 = (size_t)blockIdx.x * X::C + c_tid;
-    hs_load<N, P, T, PAIRQ>(h1, xrow(Mq, row0), xrow(PAIRQ ? Mqw : Mq, row0), j_tid);
+    hs_load<N, P, T, PAIRQ>(h1, xrow<SLAB>(Mq, row0), xrow<SLAB>(PAIRQ ? Mqw : Mq, row0), j_tid);
   }
   for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
   // per-iteration copies the compiler cannot see through: otherwise every LDS / row address of the transforms is
@@ -366,7 +374,7 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   cd w[P];
   double q[P], qpsi[P], u[P], v[P];
   HsRegs<P> h2;
-  hs_load<N, P, T, true>(h2, xrow(Mu, row), xrow(Mp, row), j);
+  hs_load<N, P, T, true>(h2, xrow<SLAB>(Mu, row), xrow<SLAB>(Mp, row), j);
   NQ_PHASE_FENCE();
   double c_unscale = 1.0;
   if constexpr (MODE == MODE_QGC) {
@@ -413,7 +421,7 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   hs_pack<N, P, T, F, true>(w, h2, j, c, lds, kk, true, v_zero_nyq != 0);
   cd sp[P];          // spectral row of phi: kept for phix (Coupled)
   if (!ONLYQ) {
-    const XRow rp = xrow(Mphi, row);
+    const XRowT<SLAB> rp = xrow<SLAB>(Mphi, row);
 #pragma unroll
     for (int t = 0; t < P; ++t) sp[t] = *rp.at(j + t * T);
   }
@@ -428,7 +436,7 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   NQ_PHASE_FENCE();
   F::template run<false>(w, j, c, lds, twr);
   NQ_PHASE_FENCE();
-  unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow(Muq, row), xrow(Mvq, row));
+  unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow<SLAB>(Muq, row), xrow<SLAB>(Mvq, row));
   if (ONLYQ) {
     if (MODE == MODE_QGC) {          // ik F[u c] + il F[v c] needs F[u c], F[v c]  (ref QGModel.py:483-495)
 #pragma unroll
@@ -436,9 +444,9 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
       NQ_PHASE_FENCE();
       F::template run<false>(w, j, c, lds, twr);
       NQ_PHASE_FENCE();
-      unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow(Mgx, row), xrow(Mgy, row));
+      unpack_pair_store<N, P, T, F>(w, j, c, lds, xrow<SLAB>(Mgx, row), xrow<SLAB>(Mgy, row));
     }
-    if (more) hs_load<N, P, T, PAIRQ>(h1, xrow(Mq, row_next), xrow(PAIRQ ? Mqw : Mq, row_next), j);
+    if (more) hs_load<N, P, T, PAIRQ>(h1, xrow<SLAB>(Mq, row_next), xrow<SLAB>(PAIRQ ? Mqw : Mq, row_next), j);
     continue;
   }
   // phi tendency source in ONE array: W = cj (u phix + v phiy) + i cr phi q_psi  (cj = -1, cr = -1/2 in a step:
@@ -446,7 +454,7 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   // the row sums of the Jacobian part travel in a padding column of Muq and are added back in k_s_phi)
   cd pre[P];         // prefetch buffer: Mgy, in flight during the next two transforms
   {
-    const XRow rgy = xrow(Mgy, row);
+    const XRowT<SLAB> rgy = xrow<SLAB>(Mgy, row);
 #pragma unroll
     for (int t = 0; t < P; ++t) {
       w[t] = sp[t];
@@ -459,7 +467,7 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
 #pragma unroll
   for (int t = 0; t < P; ++t) acc[t] = cmake(-cr * qpsi[t] * w[t].y, cr * qpsi[t] * w[t].x);   // i cr phi q_psi
   {
-    const XRow rgx = xrow(Mgx, row);
+    const XRowT<SLAB> rgx = xrow<SLAB>(Mgx, row);
 #pragma unroll
     for (int t = 0; t < P; ++t) {
       const int kx = j + t * T;
@@ -485,9 +493,9 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   F::template run<false>(acc, j, c, lds, twr);
   NQ_PHASE_FENCE();
   // first inputs of the next row block: requested before the stores so that they are not queued behind them
-  if (more) hs_load<N, P, T, PAIRQ>(h1, xrow(Mq, row_next), xrow(PAIRQ ? Mqw : Mq, row_next), j);
+  if (more) hs_load<N, P, T, PAIRQ>(h1, xrow<SLAB>(Mq, row_next), xrow<SLAB>(PAIRQ ? Mqw : Mq, row_next), j);
   {
-    const XRow rp = xrow(Mw, row);
+    const XRowT<SLAB> rp = xrow<SLAB>(Mw, row);
 #pragma unroll
     for (int t = 0; t < P; ++t) *rp.at(j + t * T) = acc[t];
   }
@@ -508,8 +516,8 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
 // The even pass parks its two output spectra (the packed (uq, vq) pair and W) in a per-workgroup scratch row in global
 // memory (L2-resident); the odd pass combines, splits the pair into its two half spectra and stores.  Inputs are read
 // once per pass (the second time from L2).  LDS: exchange area + stage twiddles of the M plan + the w^k table.
-template <int M, int P, int T, bool PAIR>
-__device__ __forceinline__ void eo_fold_pair(cd (&w)[P], const XRow& rowA, const XRow& rowB, int j, int par,
+template <int M, int P, int T, bool PAIR, typename Row>
+__device__ __forceinline__ void eo_fold_pair(cd (&w)[P], const Row& rowA, const Row& rowB, int j, int par,
                                              const cd* __restrict__ wtab, const double* __restrict__ kk, bool b_mul_ik,
                                              bool b_zero_nyq, double b_scale) {
 #pragma unroll
@@ -535,8 +543,8 @@ __device__ __forceinline__ void eo_fold_pair(cd (&w)[P], const XRow& rowA, const
     w[t] = (par == 0) ? cadd(z1, z2) : cmul(cmake(z1.x - z2.x, z1.y - z2.y), wtab[k]);
   }
 }
-template <int M, int P, int T>
-__device__ __forceinline__ void eo_fold_full(cd (&w)[P], const XRow& row, int j, int par, const cd* __restrict__ wtab,
+template <int M, int P, int T, typename Row>
+__device__ __forceinline__ void eo_fold_full(cd (&w)[P], const Row& row, int j, int par, const cd* __restrict__ wtab,
                                              const double* __restrict__ kk, bool mul_ik) {
 #pragma unroll
   for (int t = 0; t < P; ++t) {
@@ -550,8 +558,8 @@ __device__ __forceinline__ void eo_fold_full(cd (&w)[P], const XRow& row, int j,
   }
 }
 // the same in two steps, so that the loads can be issued a phase ahead (and one row serve two folds)
-template <int M, int P, int T>
-__device__ __forceinline__ void eo_load_full(cd (&x1)[P], cd (&x2)[P], const XRow& row, int j) {
+template <int M, int P, int T, typename Row>
+__device__ __forceinline__ void eo_load_full(cd (&x1)[P], cd (&x2)[P], const Row& row, int j) {
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     x1[t] = *row.at(j + t * T);
@@ -573,9 +581,9 @@ __device__ __forceinline__ void eo_fold_regs(cd (&w)[P], const cd (&x1)[P], cons
   }
 }
 // odd pass: r = O; scratch = E; writes the two half spectra of the packed pair
-template <int M, int P, int T, typename F>
+template <int M, int P, int T, typename F, typename Row>
 __device__ __forceinline__ void eo_unpack_pair_store(cd (&r)[P], int j, int c, cd* lds, const cd* __restrict__ escr,
-                                                     const cd* __restrict__ wtab, const XRow& rowA, const XRow& rowB,
+                                                     const cd* __restrict__ wtab, const Row& rowA, const Row& rowB,
                                                      double scaleB = 1.0) {
   wg_barrier();
 #pragma unroll
@@ -605,7 +613,7 @@ __device__ __forceinline__ void eo_unpack_pair_store(cd (&r)[P], int j, int c, c
   wg_barrier();
 }
 
-template <int N2, int MODE>
+template <int N2, int MODE, bool SLAB>
 __global__ void __launch_bounds__(XPlan<N2 / 2>::THREADS, XPlan<N2 / 2>::MIN_WAVES)
 k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy, MArr Muq, MArr Mvq, MArr Mw,
                 const cd* __restrict__ tw, const cd* __restrict__ wglob, const double* __restrict__ kk, int v_zero_nyq,
@@ -647,7 +655,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       asm volatile("" : "+s"(par), "+v"(j), "+v"(c));     // nothing of a pass may be hoisted or shared with the other
       cd w[P];
       double q[P], qpsi[P], u[P], v[P];
-      eo_fold_pair<M, P, T, PAIRQ>(w, xrow(Mq, row), xrow(PAIRQ ? Mqw : Mq, row), j, par, wtab, kk, false, false, 1.0);
+      eo_fold_pair<M, P, T, PAIRQ>(w, xrow<SLAB>(Mq, row), xrow<SLAB>(PAIRQ ? Mqw : Mq, row), j, par, wtab, kk, false, false, 1.0);
       NQ_PHASE_FENCE();
       F::template run<true>(w, j, c, lds, twr);
 #pragma unroll
@@ -656,7 +664,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
         qpsi[t] = (MODE == MODE_COUPLED) ? w[t].x - w[t].y : (MODE == MODE_QGC ? w[t].y : w[t].x);
       }
       NQ_PHASE_FENCE();
-      eo_fold_pair<M, P, T, true>(w, xrow(Mu, row), xrow(Mp, row), j, par, wtab, kk, true, v_zero_nyq != 0, 1.0);
+      eo_fold_pair<M, P, T, true>(w, xrow<SLAB>(Mu, row), xrow<SLAB>(Mp, row), j, par, wtab, kk, true, v_zero_nyq != 0, 1.0);
       NQ_PHASE_FENCE();
       F::template run<true>(w, j, c, lds, twr);
 #pragma unroll
@@ -672,7 +680,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
 #pragma unroll
         for (int t = 0; t < P; ++t) escr_p[j + t * T] = w[t];
       } else {
-        eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr_p, wtab, xrow(Muq, row), xrow(Mvq, row));
+        eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr_p, wtab, xrow<SLAB>(Muq, row), xrow<SLAB>(Mvq, row));
       }
       if (ONLYQ) {
         if (MODE == MODE_QGC) {
@@ -687,7 +695,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
 #pragma unroll
             for (int t = 0; t < P; ++t) escr_w[j + t * T] = w[t];
           } else {
-            eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr_w, wtab, xrow(Mgx, row), xrow(Mgy, row));
+            eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr_w, wtab, xrow<SLAB>(Mgx, row), xrow<SLAB>(Mgy, row));
           }
         }
         continue;
@@ -695,21 +703,21 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       if constexpr (!ONLYQ) {
       // (requesting the full-width rows a phase ahead costs 64 VGPRs: the spills it causes eat the gain -- measured)
       NQ_PHASE_FENCE();
-      eo_fold_full<M, P, T>(w, xrow(Mphi, row), j, par, wtab, kk, false);
+      eo_fold_full<M, P, T>(w, xrow<SLAB>(Mphi, row), j, par, wtab, kk, false);
       NQ_PHASE_FENCE();
       F::template run<true>(w, j, c, lds, twr);
       cd acc[P];
 #pragma unroll
       for (int t = 0; t < P; ++t) acc[t] = cmake(-cr * qpsi[t] * w[t].y, cr * qpsi[t] * w[t].x);
       NQ_PHASE_FENCE();
-      eo_fold_full<M, P, T>(w, xrow(MODE == MODE_COUPLED ? Mphi : Mgx, row), j, par, wtab, kk, true);
+      eo_fold_full<M, P, T>(w, xrow<SLAB>(MODE == MODE_COUPLED ? Mphi : Mgx, row), j, par, wtab, kk, true);
       NQ_PHASE_FENCE();
       F::template run<true>(w, j, c, lds, twr);
 #pragma unroll
       for (int t = 0; t < P; ++t) w[t] = cscale(w[t], u[t]);
       cd pre[P];
       NQ_PHASE_FENCE();
-      eo_fold_full<M, P, T>(pre, xrow(Mgy, row), j, par, wtab, kk, false);
+      eo_fold_full<M, P, T>(pre, xrow<SLAB>(Mgy, row), j, par, wtab, kk, false);
       NQ_PHASE_FENCE();
       F::template run<true>(pre, j, c, lds, twr);
 #pragma unroll
@@ -726,7 +734,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
 #pragma unroll
         for (int t = 0; t < P; ++t) escr_w[j + t * T] = acc[t];
       } else {
-        const XRow rp = xrow(Mw, row);
+        const XRowT<SLAB> rp = xrow<SLAB>(Mw, row);
 #pragma unroll
         for (int t = 0; t < P; ++t) {
           const int k = j + t * T;
@@ -746,7 +754,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
 }
 
 // wave-PV sources for rows of 2M points, even / odd samples as two M-point problems (see k_x_products_eo)
-template <int N2>
+template <int N2, bool SLAB>
 __global__ void __launch_bounds__(XPlan<N2 / 2>::THREADS, XPlan<N2 / 2>::MIN_WAVES)
 k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, const cd* __restrict__ wglob,
               const double* __restrict__ kk, int nblocks, cd* __restrict__ scratch) {
@@ -772,7 +780,7 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
   // raw rows are requested one phase ahead: phi's row (it serves both phi and phix) before the forward transform and
   // the stores of the previous pass, phiy's row before the first two inverse transforms
   cd r1[P], r2[P];
-  eo_load_full<M, P, T>(r1, r2, xrow(Mphi, (size_t)blockIdx.x), j_tid);
+  eo_load_full<M, P, T>(r1, r2, xrow<SLAB>(Mphi, (size_t)blockIdx.x), j_tid);
   for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
     int j = j_tid, c = 0;
     const size_t row = (size_t)rb;
@@ -788,7 +796,7 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
       double a[P];
       eo_fold_regs<M, P, T>(w, r1, r2, j, par, wtab, kk, false);
       eo_fold_regs<M, P, T>(gx, r1, r2, j, par, wtab, kk, true);
-      eo_load_full<M, P, T>(r1, r2, xrow(Mphiy, row), j);          // in flight during the next two transforms
+      eo_load_full<M, P, T>(r1, r2, xrow<SLAB>(Mphiy, row), j);          // in flight during the next two transforms
       NQ_PHASE_FENCE();
       F::template run<true>(w, j, c, lds, twr);
       double ma = 0.0, mb = 0.0;
@@ -802,8 +810,8 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
       NQ_PHASE_FENCE();
       eo_fold_regs<M, P, T>(w, r1, r2, j, par, wtab, kk, false);
       // phi's row again: for the odd pass of this row, or for the next row of this workgroup
-      if (par == 0) eo_load_full<M, P, T>(r1, r2, xrow(Mphi, row), j);
-      else if (more) eo_load_full<M, P, T>(r1, r2, xrow(Mphi, row + gridDim.x), j);
+      if (par == 0) eo_load_full<M, P, T>(r1, r2, xrow<SLAB>(Mphi, row), j);
+      else if (more) eo_load_full<M, P, T>(r1, r2, xrow<SLAB>(Mphi, row + gridDim.x), j);
       NQ_PHASE_FENCE();
       F::template run<true>(w, j, c, lds, twr);
 #pragma unroll
@@ -838,7 +846,7 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
         for (int t = 0; t < P; ++t) escr[j + t * T] = w[t];
       } else {
         // split into the two half spectra; the second carries the factor sb, undone here by scaling its rows
-        eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr, wtab, xrow(Ma, row), xrow(Mb, row), ldexp(1.0, -e_scale));
+        eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr, wtab, xrow<SLAB>(Ma, row), xrow<SLAB>(Mb, row), ldexp(1.0, -e_scale));
       }
     }
   }
@@ -850,7 +858,7 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
 //   sum q^2, sum q_psi^2, sum q_psi^3, sum (q_psi - qbar)^2, sum ups^2, sum ups q_psi, sum q_psi Re phi, sum q_psi Im phi
 // with ups = |phi|^2 - abar (abar = mean |phi|^2 and qbar = mean q_psi come from the spectral sums: centring BEFORE
 // squaring, as the reference does, keeps std(ups) meaningful for nearly uniform waves).
-template <int N, int MODE>
+template <int N, int MODE, bool SLAB>
 __global__ void __launch_bounds__(XPlan<N>::THREADS, XPlan<N>::MIN_WAVES)
 k_x_diag(MArr Mq, MArr Mqw, MArr Mphi, const cd* __restrict__ tw, const double* __restrict__ kk, double qbar,
          double abar, double* __restrict__ part) {
@@ -868,7 +876,7 @@ k_x_diag(MArr Mq, MArr Mqw, MArr Mphi, const cd* __restrict__ tw, const double* 
   double* red = reinterpret_cast<double*>(nq_smem + X::LDS_BYTES - 512);
   cd w[P];
   HsRegs<P> h1;
-  hs_load<N, P, T, MODE == MODE_COUPLED>(h1, xrow(Mq, row), xrow(MODE == MODE_COUPLED ? Mqw : Mq, row), j);
+  hs_load<N, P, T, MODE == MODE_COUPLED>(h1, xrow<SLAB>(Mq, row), xrow<SLAB>(MODE == MODE_COUPLED ? Mqw : Mq, row), j);
   NQ_PHASE_FENCE();
   hs_pack<N, P, T, F, MODE == MODE_COUPLED>(w, h1, j, c, lds, kk, false, false);
   NQ_PHASE_FENCE();
@@ -886,7 +894,7 @@ k_x_diag(MArr Mq, MArr Mqw, MArr Mphi, const cd* __restrict__ tw, const double* 
     s1[3] += qc * qc;
   }
   {
-    const XRow rp = xrow(Mphi, row);
+    const XRowT<SLAB> rp = xrow<SLAB>(Mphi, row);
 #pragma unroll
     for (int t = 0; t < P; ++t) w[t] = *rp.at(j + t * T);
   }

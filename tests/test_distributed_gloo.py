@@ -27,11 +27,13 @@ WORKER = textwrap.dedent("""
 
 
 def test_two_rank_gloo_plumbing(tmp_path):
+    from conftest import free_port
+    port = free_port()
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert '"ok": true' in out.stdout
@@ -89,10 +91,12 @@ SLAB_WORKER = textwrap.dedent("""
 def test_torch_transport_equals_virtual_transport(tmp_path):
     """The real transport (all_to_all_single / all_reduce) and the single-process stand-in used by the GPU
     tests move the same blocks: 2 gloo ranks on CPU tensors."""
+    from conftest import free_port
+    port = free_port()
     script = tmp_path / "slab_worker.py"
     script.write_text(SLAB_WORKER)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29519", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "slab transports agree" in out.stdout

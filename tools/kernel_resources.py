@@ -18,7 +18,7 @@ for b in blocks:
         m = re.search(key + r": (\d+)", b)
         return int(m.group(1)) if m else -1
 
-    dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+    dem = subprocess.run(["c++filt", name.split()[0]], capture_output=True, text=True).stdout.strip()
     dem = re.sub(r"\(.*", "", dem).replace("void nq::", "")
     if pat and not re.search(pat, dem):
         continue

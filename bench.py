@@ -119,6 +119,24 @@ def initial_fields(model, nx, grid):
     return q, phi
 
 
+def lamb_dipole_rows(xs, ys, nx, U=U0, R=2 * np.pi / K0):
+    """rows `ys` of InitialConditions.LambDipole (ref: niwqg/InitialConditions.py:77-114; same arithmetic per point) without
+    ever forming the full plane: what a slab rank needs of the initial condition"""
+    from scipy import special
+    x, y = np.meshgrid(xs, ys)
+    x0, y0 = xs[nx // 2], xs[nx // 2]
+    r = np.sqrt((x - x0) ** 2 + (y - y0) ** 2)
+    s = np.zeros_like(r)
+    away = r != 0.
+    s[away] = (y[away] - y0) / r[away]
+    lam = 3.8317 / R
+    C = -(2. * U * lam) / special.j0(lam * R)
+    q = np.zeros_like(r)
+    inside = r <= R
+    q[inside] = C * special.j1(lam * r[inside]) * s[inside]
+    return q
+
+
 def build_model(model, nx, device, kind=None):
     import niwqg_amd
     mod = {"coupled": niwqg_amd.CoupledModel, "uncoupled": niwqg_amd.UnCoupledModel, "qg": niwqg_amd.QGModel,
@@ -144,7 +162,7 @@ class _SlabCtxView(object):
             setattr(self, name, getattr(_lib.Context, name).__get__(self))
 
 
-def build_slab(model, nx, grp, local_rank):
+def build_slab(model, nx, grp, local_rank, nchunks=2):
     """One slab-decomposed simulation over all ranks of `grp` (niwqg_amd.slab).  Two stages so that the ranks can agree
     that every one of them got its memory BEFORE the first collective: allocate() then initialise()."""
     from niwqg_amd import _lib, slab
@@ -162,25 +180,38 @@ def build_slab(model, nx, grp, local_rank):
         kappa2 = (kw["m"] * kw["f"] / kw["N"]) ** 2
         phys.update(f=kw["f"], kappa2=kappa2, nuw=kw["nuw"], nu4w=kw["nu4w"], muw=kw["muw"])
 
+    gloo = getattr(grp, "backend", "") == "gloo"      # rehearsal: several ranks share one GPU, host-staged wire
+
     def allocate():
         ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], grp.world, device=local_rank, only_rank=grp.rank,
-                                budgets=True, **phys)
-        tr = slab.TorchTransport(grp.dist, stage_via_host=(getattr(grp, "backend", "") == "gloo"))
-        return slab.SlabSimulation(ranks, tr)
+                                budgets=True, torch_buffers=gloo, **phys)
+        return ranks
 
-    def initialise(sim):
-        class G(object):          # the grid attributes InitialConditions.LambDipole reads
-            pass
-        g = G()
-        g.nx = nx
+    def initialise(ranks):
+        # RCCL issued by the library itself (grouped send/recv per row chunk); with gloo the library calls back into
+        # Python at every exchange
+        sim = slab.SlabSimulation(ranks, "callback" if gloo else "rccl", dist=grp.dist, nchunks=nchunks,
+                                  stage_via_host=gloo)
+
+        nloc, r0 = ranks[0].nloc, ranks[0].rank * ranks[0].nloc
         cell = (np.arange(nx) + 0.5) / nx * L
-        g.x, g.y = np.meshgrid(cell, cell)
-        q, phi = initial_fields(model, nx, g)
-        sim.set_q(q)
-        if phi is not None:
-            sim.set_phi(phi)
+
+        class Rows(object):       # what SlabSimulation.set_q indexes: global row range -> the local rows
+            def __init__(self, a):
+                self.a = a
+
+            def __getitem__(self, sl):
+                assert sl.start == r0 and sl.stop == r0 + nloc
+                return self.a
+        if model == "qg" and nx == 2048:                         # BASELINE config 2: seeded white noise, row by row
+            q = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx))[r0:r0 + nloc]
+        else:
+            q = lamb_dipole_rows(cell, cell[r0:r0 + nloc], nx)
+        sim.set_q(Rows(q))
+        if model != "qg":
+            sim.set_phi(Rows((np.ones((nloc, nx)) + 1j) * (2 * U0) / np.sqrt(2)))
         sim.sync()
-        return _SlabCtxView(sim.ranks[0])
+        return sim, _SlabCtxView(ranks[0])
 
     return allocate, initialise
 
@@ -306,6 +337,7 @@ def main():
     ap.add_argument("--force-slab", action="store_true", help="use the slab path (and its collectives) even with one rank")
     ap.add_argument("--members", type=int, default=0, help="BASELINE config 5 instead of the headline: this many "
                     "independent UnCoupledModel 1024^2 members PER GPU (8 in the config), no collective")
+    ap.add_argument("--chunks", type=int, default=2, help="row chunks per exchange of the slab path (1, 2, 4, 8)")
     ap.add_argument("--replicas", action="store_true", help="with --gpus N > 1: N independent replicas instead of one "
                                                             "slab-decomposed simulation")
     args = ap.parse_args()
@@ -336,19 +368,19 @@ def main():
         # ONE simulation, slab-decomposed over the ranks.  Allocation is the only step allowed to fail
         # softly: the ranks agree on it BEFORE the first collective; from then on any error is fatal (a rank that
         # dropped out of a collective sequence cannot be recovered from inside the job).
-        allocate, initialise = build_slab(args.model, args.nx, grp, local_rank)
-        err = None
+        allocate, initialise = build_slab(args.model, args.nx, grp, local_rank, args.chunks)
+        err, ranks = None, None
         try:
-            sim = allocate()
+            ranks = allocate()
         except (RuntimeError, MemoryError) as e:
             err = "%s: %s" % (type(e).__name__, e)
-        ok = grp.sum([1.0 if sim is not None else 0.0])[0]
+        ok = grp.sum([1.0 if ranks is not None else 0.0])[0]
         if ok < world:
             sys.stderr.write("bench.py rank %d: slab allocation failed on %d of %d ranks (%s)\n"
                              % (rank, world - int(ok), world, err or "this rank was fine"))
             grp.close()
             sys.exit(3)
-        ctx = initialise(sim)
+        sim, ctx = initialise(ranks)
         mode = "slab x%d: %s" % (world, sim.describe())
     if sim is None:
         m = build_model(phys_model, args.nx, local_rank, kind=args.model)
@@ -374,7 +406,7 @@ def main():
     blocks = [args.steps // NBLK + (1 if i < args.steps % NBLK else 0) for i in range(NBLK)]
     ctx.profile_enable(-2)                                  # HIP events around every launch of the six kernel classes
     if sim is not None:
-        sim.reset_counters()
+        sim.counters(reset=2)                               # count host calls / exchange chunks / bytes, time the exchange stream
     barrier()
     t0 = time.perf_counter()
     ctx.event_record(0)
@@ -396,7 +428,11 @@ def main():
 
     extra = {}
     if sim is not None:
-        extra.update(sim.counters(args.steps))
+        cnt = sim.counters()
+        extra.update(host_dispatches_per_step=cnt["host_calls"] / max(cnt["steps"], 1),
+                     exchange_chunks_per_step=cnt["exchange_chunks"] / max(cnt["steps"], 1),
+                     exchange_ms_per_step=cnt["exchange_ms"] / max(cnt["steps"], 1),
+                     exchange_GB_sent_per_rank_per_step=cnt["bytes_sent"] / max(cnt["steps"], 1) / 1e9)
         if world > 1:
             # the other way to use N GPUs (config 5 style): N independent simulations, no collective.  Timed AFTER
             # and OUTSIDE the K-step region above; reported as context only, never as `value`.

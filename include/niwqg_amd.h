@@ -170,7 +170,8 @@ int nq_get_coeff(nq_ctx* ctx, int eq, int which, double* out_cplx);
  * (torch.distributed / RCCL); the library only runs the phases in between, on the stream it was given (stream ==
  * NULL: a private stream the library creates -- then the caller must order its collectives against nq_stream()).
  *   buffers[2g], buffers[2g+1] : x-side and y-side device buffers of group g (may be NULL for empty groups)
- *   buffers[8]                 : 64 doubles for the per-step budget sums (summed over ranks by the caller)  */
+ *   buffers[8]                 : 64 doubles for the per-step budget sums (summed over ranks by the caller)
+ * buffers == NULL: the library allocates all of them itself (nq_group_buffers / nq_reduce_buffer give the pointers).   */
 long long nq_group_elems(const nq_params* p, int nranks, int group);
 int nq_create_slab(const nq_params* p, const double* kk, const double* ll, const double* filtr,
                    const double* contour, int device, int nranks, int rank, void* const* buffers, void* stream,
@@ -192,6 +193,49 @@ enum {
 };
 int nq_phase(nq_ctx* ctx, int phase, int stage);
 int nq_reduce_buffer(nq_ctx* ctx, int which, void** device_ptr, int* count);
+/* host copies of those blocks (which 0..3 as above, 4 / 5: the spectral / physical half of the diagnostic sums, 16 doubles
+ * each): read, sum over ranks by any means, write back -- what an all-reduce callback does */
+int nq_reduce_read(nq_ctx* ctx, int which, double* host_out);
+int nq_reduce_write(nq_ctx* ctx, int which, const double* host_in);
+
+/* ---- the slab step INSIDE the library: one host call per nsteps, exchanges issued by the library ------------------
+ * nq_slab_step runs the phase sequence of nq_phase itself and moves the exchange groups over the link the context
+ * was given, on its own exchange stream, chunk by chunk: every group is cut into nchunks row chunks; for an x->y group
+ * the row kernel of chunk i+1 runs while chunk i is on the wire, for a y->x group the row kernel of chunk i starts as
+ * soon as chunk i has arrived; the q update runs under the transfer of the phi group; the budget sums are all-reduced
+ * once per step and not at all when budgets are off.  Links:
+ *   nq_comm_init          RCCL: grouped ncclSend/ncclRecv per chunk + ncclAllReduce, communicator made from a
+ *                         128-byte unique id (rank 0: nq_comm_unique_id; hand it to the others by any means, e.g.
+ *                         torch.distributed broadcast).  librccl is taken from the process (dlopen), not linked.
+ *   nq_slab_attach_peers  all nranks contexts live in THIS process on one device (the one-GPU test double): the same
+ *                         choreography of streams and events, device-to-device copies instead of the wire.  The step is
+ *                         then driven through the rank-0 context and advances all of them.
+ *   nq_slab_set_callbacks the caller moves the data: exchange(user, group, to_y) and allreduce(user, which) are called
+ *                         with the compute stream drained and must be complete on return (gloo / host staging).
+ * nq_slab_put_rows + nq_slab_commit: Kernel.set_q / set_phi (Kernel.py:520-551) from this rank's ROWS of the physical
+ * field (nloc rows of nx values, real / complex): row transform on the device (put_rows, local), then exchange, column
+ * transform and the phases of the single-rank calls (commit, collective) -- no rank ever holds or transforms the whole plane.
+ * nq_slab_get_rows: this rank's rows (nloc, nx) of a physical field (NQ_F_Q, _P, _U, _V, _QW, _QPSI real; _PHI, _PHIX,
+ * _PHIY complex) from the mixed-space rows the last step left on the x side. */
+typedef int (*nq_exchange_fn)(void* user, int group, int to_y);
+typedef int (*nq_allreduce_fn)(void* user, int which);      /* which: as nq_reduce_buffer; 4: the 32 diagnostic sums */
+int nq_comm_unique_id(void* out128);
+int nq_comm_init(nq_ctx* ctx, const void* id128, int nranks, int rank);
+int nq_slab_attach_peers(nq_ctx* const* ctxs, int nranks);
+int nq_slab_set_callbacks(nq_ctx* ctx, nq_exchange_fn exchange, nq_allreduce_fn allreduce, void* user);
+int nq_slab_config(nq_ctx* ctx, int nchunks);               /* 1, 2, 4 or 8; reduced if the local rows do not divide */
+int nq_slab_step(nq_ctx* ctx, int nsteps);
+int nq_slab_put_rows(nq_ctx* ctx, int which /* 0: q, 1: phi */, const double* rows);   /* local: rows -> x side       */
+int nq_slab_commit(nq_ctx* ctx, int which);   /* collective: the rest of set_q / set_phi (rank-0 context in peers mode) */
+int nq_slab_get_rows(nq_ctx* ctx, int field_id, double* rows_out);
+/* nq_diagnostics of a slab-decomposed simulation: the same 32 sums, every rank's part summed over the ranks (collective);
+ * nq_slab_local_max: max|u|, max|v|, max|phi| over this rank's rows (the caller takes the max over ranks for the CFL) */
+int nq_slab_diagnostics(nq_ctx* ctx, double* out32);
+int nq_slab_local_max(nq_ctx* ctx, double* out3);
+/* counters since the last reset: out[0] host calls of nq_slab_step, [1] steps, [2] exchange chunks issued, [3] bytes this
+ * rank sent to OTHER ranks, [4] milliseconds the exchange stream spent in exchanges (HIP events; 0 unless timing was
+ * switched on with reset = 2), [5] nchunks in use */
+int nq_slab_counters(nq_ctx* ctx, double* out6, int reset);
 
 /* timing of the hot loop with HIP events on the context's stream */
 int nq_timer_start(nq_ctx* ctx);

@@ -29,7 +29,13 @@ EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "
            "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_diagnostics",
            "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
-           "nq_reduce_buffer", "nq_device_bytes", "nq_stream"]
+           "nq_reduce_buffer", "nq_reduce_read", "nq_reduce_write", "nq_device_bytes", "nq_stream",
+           "nq_comm_unique_id", "nq_comm_init", "nq_slab_attach_peers", "nq_slab_set_callbacks", "nq_slab_config",
+           "nq_slab_step", "nq_slab_put_rows", "nq_slab_commit", "nq_slab_get_rows", "nq_slab_diagnostics",
+           "nq_slab_local_max", "nq_slab_counters"]
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
 
 
 class Params(ctypes.Structure):
@@ -108,6 +114,20 @@ def lib():
     L.nq_download_spectral.argtypes = [vp, ctypes.c_int, dp]
     L.nq_phase.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.nq_reduce_buffer.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
+    L.nq_reduce_read.argtypes = [vp, ctypes.c_int, dp]
+    L.nq_reduce_write.argtypes = [vp, ctypes.c_int, dp]
+    L.nq_comm_unique_id.argtypes = [vp]
+    L.nq_comm_init.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int]
+    L.nq_slab_attach_peers.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    L.nq_slab_set_callbacks.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp]
+    L.nq_slab_config.argtypes = [vp, ctypes.c_int]
+    L.nq_slab_step.argtypes = [vp, ctypes.c_int]
+    L.nq_slab_put_rows.argtypes = [vp, ctypes.c_int, dp]
+    L.nq_slab_commit.argtypes = [vp, ctypes.c_int]
+    L.nq_slab_get_rows.argtypes = [vp, ctypes.c_int, dp]
+    L.nq_slab_diagnostics.argtypes = [vp, dp]
+    L.nq_slab_local_max.argtypes = [vp, dp]
+    L.nq_slab_counters.argtypes = [vp, dp, ctypes.c_int]
     L.nq_device_bytes.argtypes = [vp]
     L.nq_device_bytes.restype = ctypes.c_longlong
     L.nq_stream.argtypes = [vp]

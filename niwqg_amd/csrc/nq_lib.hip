@@ -1,6 +1,7 @@
 // niwqg_amd: context, precompute kernels and the C ABI (include/niwqg_amd.h).
 // gfx950 only; build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC nq_lib.hip -o libniwqg_amd.so
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -77,6 +78,7 @@ struct nq_ctx {
   // slab decomposition; P == 1: one rank owns everything
   int P = 1, rank = 0;
   int Nloc = 0;          // local rows on the X side
+  int row0 = 0, nrows = 0;   // row window of the next row-kernel launch (a chunk of the local rows; whole slab by default)
   int Wf = 0, kf0 = 0;   // full-width planes: local columns, first global column
   int Wl = 0, kh0 = 0;   // half-spectrum planes: columns per rank, first global column of this rank
   // exchange groups: G[0] X->Y {Muq,Mvq,Mw}, G[1] Y->X {Mphi,Mphiy}, G[2] X->Y {Ma,Mb},
@@ -110,6 +112,22 @@ struct nq_ctx {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int overlap_cus = 0;
+  // ---- slab step inside the library: how the exchange groups cross between the ranks
+  int link = 0;                        // LINK_*: 0 none, 1 peers in this process, 2 RCCL, 3 caller's callbacks
+  std::vector<nq_ctx*> peers;          // LINK_PEERS: every rank's context (index = rank), the same list on all of them
+  void* comm = nullptr;                // LINK_RCCL: ncclComm_t
+  nq_exchange_fn xcb = nullptr;        // LINK_CALLBACK
+  nq_allreduce_fn rcb = nullptr;
+  void* cb_user = nullptr;
+  int nchunk = 1;                      // row chunks per exchange (producer / consumer row kernels run chunk by chunk)
+  hipStream_t mstream = nullptr;       // exchanges run here, beside the compute stream
+  hipEvent_t ev_prod[8] = {}, ev_arr[4][8] = {}, ev_col = nullptr, ev_done = nullptr, ev_red = nullptr;
+  bool arr_pending[4] = {false, false, false, false};   // group g is arriving chunk by chunk (ev_arr[g][*] recorded)
+  long long n_exch = 0, n_calls = 0, n_steps = 0;       // counters since nq_slab_counters(reset)
+  double bytes_sent = 0.0;
+  std::vector<hipEvent_t> xev;         // timing pairs around every exchange chunk on mstream (when counting)
+  size_t xev_used = 0;
+  bool xtime = false;
   bool ybj = false;
   bool passive = false;  // QGModel with its passive scalar: state cq, spectrum emitted through the qw slots of G3 / G0
   EqState cq;
@@ -236,6 +254,8 @@ __global__ void k_mul_minus_i(cd* __restrict__ a, size_t n) {
   if (i < n) a[i] = cmul_mi(a[i]);
 }
 
+__global__ void k_axpy1(double* y, const double* x, double a) { y[0] += a * x[0]; }
+
 // out = a - b on a half-spectrum plane (q_psi = q - qw, ref CoupledModel.py:145-152)
 __global__ void k_sub_half(const cd* __restrict__ a, const cd* __restrict__ b, cd* __restrict__ out, int width, int pitch) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
@@ -350,19 +370,19 @@ __global__ void k_diag_phi(const cd* __restrict__ phih, int N, int width, int pi
 // half spectra qh, qwh (may be null), ph; nine sums (see nq_diagnostics).  On the two self-mirrored columns the sums
 // that stand for means of REAL fields use the Hermitian part H(l) = (X(l) + conj X(-l))/2 (what `.real` keeps).
 __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, const cd* __restrict__ ph, int N,
-                         int width, int pitch, const double* __restrict__ kk, const double* __restrict__ ll,
+                         int width, int pitch, int k0, const double* __restrict__ kk, const double* __restrict__ ll,
                          double* __restrict__ part) {
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const size_t total = (size_t)N * width;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int l = (int)(i / width), k = (int)(i - (size_t)l * width);
-    const size_t idx = (size_t)l * pitch + k;
+    const int l = (int)(i / width), kl = (int)(i - (size_t)l * width), k = k0 + kl;      // kl: local column, k: global
+    const size_t idx = (size_t)l * pitch + kl;
     const cd q = qh[idx], w = qwh ? qwh[idx] : cmake(0, 0), p = ph[idx];
     cd hq = q, hw = w, hp = p;
     double wt = 2.0;
     if (k == 0 || k == N / 2) {
       wt = 1.0;
-      const size_t im = (size_t)((N - l) % N) * pitch + k;
+      const size_t im = (size_t)((N - l) % N) * pitch + kl;
       const cd qm = qh[im], wm = qwh ? qwh[im] : cmake(0, 0), pm = ph[im];
       hq = cmake(0.5 * (q.x + qm.x), 0.5 * (q.y - qm.y));
       hw = cmake(0.5 * (w.x + wm.x), 0.5 * (w.y - wm.y));
@@ -668,28 +688,37 @@ static YGeom geom_full(const nq_ctx* c) {
 }
 
 // fused-stage launches ----------------------------------------------------------------------------
+// X-side view of a mixed-space array that starts at local row c->row0: a row kernel launched on such views with
+// c->nrows rows processes one CHUNK of the slab (the slab driver overlaps the exchange of chunk i with the kernel of
+// chunk i+1); everything a row kernel addresses is relative to the row, so the kernels themselves do not change
+static MArr rw(const nq_ctx* c, const MArr& m) {
+  MArr r = m;
+  if (r.xs) r.xs += (size_t)c->row0 * m.pitch;
+  return r;
+}
 template <bool SLAB>
 static void launch_wavepv_t(nq_ctx* c) {
+  const MArr mPhi = rw(c, c->mPhi), mPhiy = rw(c, c->mPhiy), mA = rw(c, c->mA), mB = rw(c, c->mB);
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n, SLAB>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx1, c->kk); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n, SLAB>), dim3(c->nrows / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, mPhi, mPhiy, mA, mB, c->twx1, c->kk); } break;
     case 8192:
       if (c->eo_scratch) {                            // even / odd samples as two 4096-point problems (no spills)
         typedef XPlan<4096> X;
-        const int nb = c->Nloc, grid = nb < c->num_cu ? nb : c->num_cu;
+        const int nb = c->nrows, grid = nb < c->num_cu ? nb : c->num_cu;
         const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd);
-        hipLaunchKernelGGL((k_x_wavepv_eo<8192, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx_half, c->tw, c->kk, nb, c->eo_scratch);
+        hipLaunchKernelGGL((k_x_wavepv_eo<8192, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mPhi, mPhiy, mA, mB, c->twx_half, c->tw, c->kk, nb, c->eo_scratch);
       } else {
         typedef XPlan1<8192> X;
-        hipLaunchKernelGGL((k_x_wavepv<8192, SLAB>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx1, c->kk);
+        hipLaunchKernelGGL((k_x_wavepv<8192, SLAB>), dim3(c->nrows / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, mPhi, mPhiy, mA, mB, c->twx1, c->kk);
       }
       break;
     case 4096: {                                      // long rows: two transforms in flight, no spills
       typedef XPlan<4096> X;
       const size_t ldsb = X::LDS_BYTES + X::F::LDS_ELEMS * sizeof(cd);
       int grid = c->num_cu - (c->stream2 ? c->overlap_cus : 0);                    // one persistent workgroup per CU
-      const int nb = c->Nloc / X::C;
+      const int nb = c->nrows / X::C;
       if (grid > nb) grid = nb;
-      hipLaunchKernelGGL((k_x_wavepv2<4096, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mPhi, c->mPhiy, c->mA, c->mB, c->twx, c->kk, nb);
+      hipLaunchKernelGGL((k_x_wavepv2<4096, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mPhi, mPhiy, mA, mB, c->twx, c->kk, nb);
     } break;
     M_SMALL(CASE_)
 #undef CASE_
@@ -704,23 +733,26 @@ static void launch_wavepv(nq_ctx* c) {
 template <int MODE, bool SLAB>
 static void launch_products_t(nq_ctx* c, double cj, double cr, bool fresh_grad) {
   const int vz = c->kernel_family ? 1 : 0;
+  const MArr mU = rw(c, c->mU), mP = rw(c, c->mP), mQ = rw(c, c->mQ), mQw = rw(c, c->mQw), mPhi = rw(c, c->mPhi);
+  const MArr mUq = rw(c, c->mUq), mVq = rw(c, c->mVq), mW = rw(c, c->mW), mPhiy = rw(c, c->mPhiy);
+  const MArr mGx = rw(c, c->mGx), mGy = rw(c, c->mGy), mUc = rw(c, c->mUc), mVc = rw(c, c->mVc);
   if (c->N == 8192 && MODE != MODE_QGC && c->eo_scratch) {
     // rows too long for the register budget as one transform: even / odd samples as two 4096-point problems
     typedef XPlan<4096> X;
-    const MArr& gx8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGx : c->mPhi;
-    const MArr& gy8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGy : c->mPhiy;
-    const int nb = c->Nloc, grid = nb < c->num_cu ? nb : c->num_cu;
+    const MArr& gx8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? mGx : mPhi;
+    const MArr& gy8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? mGy : mPhiy;
+    const int nb = c->nrows, grid = nb < c->num_cu ? nb : c->num_cu;
     const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd);
-    hipLaunchKernelGGL((k_x_products_eo<8192, MODE, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx8, gy8, c->mUq, c->mVq, c->mW, c->twx_half, c->tw, c->kk, vz, cj, cr, nb, c->eo_scratch);
+    hipLaunchKernelGGL((k_x_products_eo<8192, MODE, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mU, mP, mQ, mQw, mPhi, gx8, gy8, mUq, mVq, mW, c->twx_half, c->tw, c->kk, vz, cj, cr, nb, c->eo_scratch);
     return;
   }
-  const MArr& gx = (MODE == MODE_QGC) ? c->mUc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGx : c->mPhi);
-  const MArr& gy = (MODE == MODE_QGC) ? c->mVc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? c->mGy : c->mPhiy);
+  const MArr& gx = (MODE == MODE_QGC) ? mUc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? mGx : mPhi);
+  const MArr& gy = (MODE == MODE_QGC) ? mVc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? mGy : mPhiy);
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; const int nb = c->Nloc / X::C; \
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; const int nb = c->nrows / X::C; \
     /* one workgroup fits per CU (LDS) and does not spill: persistent; 8192-point rows spill and do better with dynamic dispatch */ \
     const int grid = (X::LDS_BYTES > 80 * 1024 && X::THREADS <= 512 && nb > c->num_cu) ? c->num_cu : nb; \
-    hipLaunchKernelGGL((k_x_products<n, MODE, SLAB>), dim3(grid), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mU, c->mP, c->mQ, c->mQw, c->mPhi, gx, gy, c->mUq, c->mVq, c->mW, c->twx, c->kk, vz, cj, cr, nb); } break;
+    hipLaunchKernelGGL((k_x_products<n, MODE, SLAB>), dim3(grid), dim3(X::THREADS), X::LDS_BYTES, c->stream, mU, mP, mQ, mQw, mPhi, gx, gy, mUq, mVq, mW, c->twx, c->kk, vz, cj, cr, nb); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
@@ -1012,6 +1044,361 @@ static void do_step(nq_ctx* c) {      // P == 1
   phase_budget_finish(c);
 }
 
+
+// ==================================================================================================================
+// The slab step inside the library (include/niwqg_amd.h: nq_slab_step)
+// ==================================================================================================================
+enum { LINK_NONE = 0, LINK_PEERS = 1, LINK_RCCL = 2, LINK_CALLBACK = 3 };
+
+// RCCL, taken from the process at run time (torch ships its own librccl and has usually loaded it already)
+struct NcclId { char internal[128]; };
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(NcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static const int kNcclDouble = 8, kNcclSum = 0, kNcclMax = 2;
+static bool rccl_load(std::string* err) {
+  if (g_rccl.handle) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // the copy the process already uses, if any
+  for (const char* n : names) {
+    if (h) break;
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  }
+  if (!h) {
+    *err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+    return false;
+  }
+#define SYM_(field, name)                                                  \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+  if (!g_rccl.field) {                                                     \
+    *err = std::string("librccl lacks ") + name;                           \
+    return false;                                                          \
+  }
+  SYM_(GetUniqueId, "ncclGetUniqueId") SYM_(CommInitRank, "ncclCommInitRank") SYM_(CommDestroy, "ncclCommDestroy")
+  SYM_(GroupStart, "ncclGroupStart") SYM_(GroupEnd, "ncclGroupEnd") SYM_(Send, "ncclSend") SYM_(Recv, "ncclRecv")
+  SYM_(AllReduce, "ncclAllReduce") SYM_(GetErrorString, "ncclGetErrorString")
+#undef SYM_
+  g_rccl.handle = h;
+  return true;
+}
+#define NCCLCHK(ctx, call)                                                                                       \
+  do {                                                                                                           \
+    int r_ = (call);                                                                                             \
+    if (r_ != 0) NQ_FAIL(ctx, -6, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+  } while (0)
+
+static int slab_link_setup(nq_ctx* c) {        // exchange stream and events, once
+  if (c->mstream) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking));
+  for (int i = 0; i < 8; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_prod[i], hipEventDisableTiming));
+  for (int g = 0; g < 4; ++g)
+    for (int i = 0; i < 8; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_arr[g][i], hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_col, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_red, hipEventDisableTiming));
+  return 0;
+}
+// the contexts one call drives: every rank of the process in peers mode, otherwise this rank alone
+static int slab_group(nq_ctx* c, std::vector<nq_ctx*>* g) {
+  if (c->link == LINK_NONE) {
+    if (c->P != 1) NQ_FAIL(c, -4, "slab context without a link: call nq_comm_init, nq_slab_attach_peers or nq_slab_set_callbacks first");
+    c->peers.assign(1, c);                       // one rank: its own blocks cross by device copies
+    c->link = LINK_PEERS;
+  }
+  if (c->link == LINK_PEERS) {
+    if (c->rank != 0) NQ_FAIL(c, -4, "peers mode: drive the group through its rank-0 context");
+    *g = c->peers;
+  } else {
+    g->assign(1, c);
+  }
+  for (nq_ctx* x : *g) {
+    int rc = slab_link_setup(x);
+    if (rc) return rc;
+  }
+  return 0;
+}
+static int effective_chunks(const nq_ctx* c) {
+  if (c->link == LINK_CALLBACK) return 1;
+  int rows_per_wg = 1;
+  switch (c->N) {
+#define CASE_(n, a, b) case n: rows_per_wg = XPlan<n>::C > XPlan1<n>::C ? XPlan<n>::C : XPlan1<n>::C; break;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+  }
+  int n = c->nchunk < 1 ? 1 : (c->nchunk > 8 ? 8 : c->nchunk);
+  while (n > 1 && (c->Nloc % (n * rows_per_wg) != 0)) n >>= 1;
+  return n;
+}
+struct XTimer {                                  // optional HIP-event pair around one exchange chunk on the exchange stream
+  nq_ctx* c;
+  bool on;
+  explicit XTimer(nq_ctx* c_) : c(c_), on(c_->xtime) {
+    if (!on) return;
+    if (c->xev_used + 2 > c->xev.size())
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+        c->xev.push_back(e);
+      }
+    (void)hipEventRecord(c->xev[c->xev_used], c->mstream);
+  }
+  ~XTimer() {
+    if (!on) return;
+    (void)hipEventRecord(c->xev[c->xev_used + 1], c->mstream);
+    c->xev_used += 2;
+  }
+};
+
+// Chunk i of nch of exchange group g, for every rank of grp.  to_y: x side -> y side (the producers' row kernels recorded
+// ev_prod[i]); else y side -> x side (the column kernels recorded ev_col).  Both buffers of a group are cut into P blocks of
+// Nloc rows; chunk i is the same row range inside every block.
+static int issue_chunk(std::vector<nq_ctx*>& grp, int g, bool to_y, int i, int nch) {
+  nq_ctx* c0 = grp[0];
+  if (c0->G[g].elems == 0) return 0;
+  const size_t blk = (size_t)c0->Nloc * c0->G[g].pitch, cblk = blk / nch, off = (size_t)i * cblk;
+  for (nq_ctx* c : grp) {
+    cd* send = to_y ? c->G[g].bx : c->G[g].by;
+    cd* recv = to_y ? c->G[g].by : c->G[g].bx;
+    hipEvent_t mine = to_y ? c->ev_prod[i] : c->ev_col;
+    if (c->link == LINK_CALLBACK) {
+      if (i == 0) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!c->xcb) NQ_FAIL(c, -4, "no exchange callback");
+        const int rc = c->xcb(c->cb_user, g, to_y ? 1 : 0);
+        if (rc) NQ_FAIL(c, -6, "exchange callback failed (%d)", rc);
+        c->n_exch += 1;
+        c->bytes_sent += (double)blk * 16.0 * (c->P - 1);
+      }
+      continue;
+    }
+    HIPCHK(c, hipStreamWaitEvent(c->mstream, mine, 0));
+    {
+      XTimer xt(c);
+      if (c->link == LINK_PEERS) {
+        for (nq_ctx* s : grp) HIPCHK(c, hipStreamWaitEvent(c->mstream, to_y ? s->ev_prod[i] : s->ev_col, 0));
+        for (nq_ctx* s : grp) {
+          const cd* src = (to_y ? s->G[g].bx : s->G[g].by) + (size_t)c->rank * blk + off;
+          HIPCHK(c, hipMemcpyAsync(recv + (size_t)s->rank * blk + off, src, cblk * sizeof(cd), hipMemcpyDeviceToDevice, c->mstream));
+        }
+      } else {                                   // RCCL: one grouped send/recv pair per peer, the own block by a device copy
+        NCCLCHK(c, g_rccl.GroupStart());
+        for (int p = 0; p < c->P; ++p) {
+          if (p == c->rank) continue;
+          NCCLCHK(c, g_rccl.Send(send + (size_t)p * blk + off, 2 * cblk, kNcclDouble, p, c->comm, c->mstream));
+          NCCLCHK(c, g_rccl.Recv(recv + (size_t)p * blk + off, 2 * cblk, kNcclDouble, p, c->comm, c->mstream));
+        }
+        NCCLCHK(c, g_rccl.GroupEnd());
+        HIPCHK(c, hipMemcpyAsync(recv + (size_t)c->rank * blk + off, send + (size_t)c->rank * blk + off, cblk * sizeof(cd), hipMemcpyDeviceToDevice, c->mstream));
+      }
+    }
+    c->n_exch += 1;
+    c->bytes_sent += (double)cblk * 16.0 * (c->P - 1);
+    if (to_y) {
+      if (i == nch - 1) HIPCHK(c, hipEventRecord(c->ev_done, c->mstream));
+    } else {
+      HIPCHK(c, hipEventRecord(c->ev_arr[g][i], c->mstream));
+      c->arr_pending[g] = true;
+    }
+  }
+  return 0;
+}
+static int wait_arrival(nq_ctx* c, int g, int i, int nch_now) {
+  // the group was sent with the step's chunking; a caller that uses fewer chunks waits for all the chunks it covers
+  if (!c->arr_pending[g] || c->link == LINK_CALLBACK) return 0;
+  const int sent = effective_chunks(c);
+  const int per = sent / nch_now > 0 ? sent / nch_now : 1;
+  for (int k = i * per; k < (i + 1) * per && k < sent; ++k) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_arr[g][k], 0));
+  return 0;
+}
+static void set_window(nq_ctx* c, int i, int nch) {
+  c->nrows = c->Nloc / nch;
+  c->row0 = i * c->nrows;
+}
+#define SLABTRY(call)          \
+  do {                         \
+    int rc__ = (call);         \
+    if (rc__) return rc__;     \
+  } while (0)
+
+// whole group g at once, complete on the compute streams when this returns to the caller's next launch
+static int exchange_now(std::vector<nq_ctx*>& grp, int g, bool to_y) {
+  if (grp.size() == 1 && grp[0]->P == 1 && grp[0]->G[g].bx == grp[0]->G[g].by) return 0;      // one rank, one buffer
+  for (nq_ctx* c : grp) HIPCHK(c, hipEventRecord(to_y ? c->ev_prod[0] : c->ev_col, c->stream));
+  const int sent = effective_chunks(grp[0]);
+  if (to_y) {
+    SLABTRY(issue_chunk(grp, g, true, 0, 1));
+    for (nq_ctx* c : grp)
+      if (c->link != LINK_CALLBACK) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+  } else {
+    // arrival events are per chunk of the step's chunking: send it that way so that later waits find every event recorded
+    for (int i = 0; i < sent; ++i) SLABTRY(issue_chunk(grp, g, false, i, sent));
+    for (nq_ctx* c : grp)
+      for (int i = 0; i < sent; ++i) SLABTRY(wait_arrival(c, g, i, sent));
+  }
+  return 0;
+}
+
+struct PeerBufs { double* p[8]; };
+__global__ void k_peer_allreduce(PeerBufs b, int P, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int r = 0; r < P; ++r) s += b.p[r][i];
+  for (int r = 0; r < P; ++r) b.p[r][i] = s;
+}
+// sum over ranks of n doubles at offset `lo` of each rank's reduction block (bsums), or of its 32 diagnostic sums (which = 4)
+static double* red_ptr(nq_ctx* c, int which, int* n) {
+  switch (which) {
+    case 0: *n = 44; return c->bsums;
+    case 1: *n = 4; return c->carryW;
+    case 2: *n = 3; return c->carryQ;
+    case 3: *n = 1; return c->gradS1;
+    case 4: *n = 16; return c->diag_out;           // diagnostics tick, spectral half
+    case 5: *n = 16; return c->diag_out ? c->diag_out + 16 : nullptr;   // physical half
+    default: *n = 0; return nullptr;
+  }
+}
+static int slab_allreduce(std::vector<nq_ctx*>& grp, int which) {
+  nq_ctx* c0 = grp[0];
+  int n = 0;
+  if (!red_ptr(c0, which, &n)) NQ_FAIL(c0, -1, "slab_allreduce: which = %d", which);
+  if (c0->link == LINK_CALLBACK) {
+    for (nq_ctx* c : grp) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (!c->rcb) NQ_FAIL(c, -4, "no all-reduce callback");
+      const int rc = c->rcb(c->cb_user, which);
+      if (rc) NQ_FAIL(c, -6, "all-reduce callback failed (%d)", rc);
+    }
+    return 0;
+  }
+  if (c0->link == LINK_PEERS) {
+    if (grp.size() == 1) return 0;
+    PeerBufs pb;
+    for (size_t r = 0; r < grp.size(); ++r) {
+      pb.p[r] = red_ptr(grp[r], which, &n);
+      HIPCHK(grp[r], hipEventRecord(grp[r]->ev_red, grp[r]->stream));
+      HIPCHK(c0, hipStreamWaitEvent(c0->mstream, grp[r]->ev_red, 0));
+    }
+    hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(64), 0, c0->mstream, pb, (int)grp.size(), n);
+    HIPCHK(c0, hipEventRecord(c0->ev_done, c0->mstream));
+    for (nq_ctx* c : grp) HIPCHK(c, hipStreamWaitEvent(c->stream, c0->ev_done, 0));
+    return 0;
+  }
+  for (nq_ctx* c : grp) {                        // RCCL
+    double* p = red_ptr(c, which, &n);
+    HIPCHK(c, hipEventRecord(c->ev_red, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->mstream, c->ev_red, 0));
+    NCCLCHK(c, g_rccl.AllReduce(p, p, (size_t)n, kNcclDouble, kNcclSum, c->comm, c->mstream));
+    HIPCHK(c, hipEventRecord(c->ev_done, c->mstream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+  }
+  return 0;
+}
+
+// UPDATE split in two for the coupled model: the phi half produces exchange group 1, the q half runs under its transfer
+static void phase_update_phi(nq_ctx* c, int s) {
+  int wslot = 0;
+  launch_A_m(c, false, {&c->mW});
+  const int cur = c->w.cur;
+  const cd* y_start = (s == 0) ? c->w.y[cur] : (s == 1 ? c->w.y[(cur + 1) % 3] : c->w.y[(cur + 2) % 3]);
+  EtdArrays ew = etd_arrays(c->w, s, &wslot);
+  launch_sphi(c, ew, s, y_start);
+  launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
+}
+static void phase_update_q(nq_ctx* c, int s) {
+  int qslot = 0;
+  launch_A_m(c, false, {&c->mUq, &c->mVq});
+  EtdArrays eq = etd_arrays(c->q, s, &qslot);
+  launch_sq(c, eq, s);
+}
+
+static int slab_step_once(std::vector<nq_ctx*>& grp) {
+  nq_ctx* c0 = grp[0];
+  const bool coupled = c0->p.model == NQ_MODEL_COUPLED, waves = c0->kernel_family;
+  const int nch = effective_chunks(c0);
+  for (int s = 0; s < 4; ++s) {
+    // rows: nonlinear products, chunk by chunk; chunk i leaves as soon as it is done
+    for (int i = 0; i < nch; ++i) {
+      for (nq_ctx* c : grp) {
+        SLABTRY(wait_arrival(c, 3, i, nch));
+        if (waves) SLABTRY(wait_arrival(c, 1, i, nch));
+        set_window(c, i, nch);
+        phase_products(c, s);
+        HIPCHK(c, hipEventRecord(c->ev_prod[i], c->stream));
+      }
+      SLABTRY(issue_chunk(grp, 0, true, i, nch));
+    }
+    for (nq_ctx* c : grp) {
+      set_window(c, 0, 1);
+      if (c->link != LINK_CALLBACK) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+    }
+    if (coupled) {
+      for (nq_ctx* c : grp) {
+        phase_update_phi(c, s);
+        HIPCHK(c, hipEventRecord(c->ev_col, c->stream));
+      }
+      for (int i = 0; i < nch; ++i) SLABTRY(issue_chunk(grp, 1, false, i, nch));
+      for (nq_ctx* c : grp) phase_update_q(c, s);                    // under the transfer of group 1
+      for (int i = 0; i < nch; ++i) {
+        for (nq_ctx* c : grp) {
+          SLABTRY(wait_arrival(c, 1, i, nch));
+          set_window(c, i, nch);
+          phase_wavepv(c);
+          HIPCHK(c, hipEventRecord(c->ev_prod[i], c->stream));
+        }
+        SLABTRY(issue_chunk(grp, 2, true, i, nch));
+      }
+      for (nq_ctx* c : grp) {
+        set_window(c, 0, 1);
+        if (c->link != LINK_CALLBACK) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+        phase_invert(c, s);
+        HIPCHK(c, hipEventRecord(c->ev_col, c->stream));
+      }
+      for (int i = 0; i < nch; ++i) SLABTRY(issue_chunk(grp, 3, false, i, nch));
+    } else {
+      for (nq_ctx* c : grp) {
+        phase_update(c, s);                                            // includes the (spectral) inversion
+        HIPCHK(c, hipEventRecord(c->ev_col, c->stream));
+      }
+      if (waves)
+        for (int i = 0; i < nch; ++i) SLABTRY(issue_chunk(grp, 1, false, i, nch));
+      for (int i = 0; i < nch; ++i) SLABTRY(issue_chunk(grp, 3, false, i, nch));
+    }
+  }
+  if (c0->bud) {
+    for (nq_ctx* c : grp) phase_budget_sums(c);
+    SLABTRY(slab_allreduce(grp, 0));
+    for (nq_ctx* c : grp) phase_budget_finish(c);
+  }
+  for (nq_ctx* c : grp) c->n_steps += 1;
+  return 0;
+}
+// every arrival of the last step has to be on the compute stream before anybody else (a read, a set_q, a sync) touches the x side
+static int slab_settle(std::vector<nq_ctx*>& grp) {
+  for (nq_ctx* c : grp) {
+    const int sent = effective_chunks(c);
+    for (int g = 0; g < 4; ++g)
+      if (c->arr_pending[g]) {
+        for (int i = 0; i < sent; ++i) SLABTRY(wait_arrival(c, g, i, sent));
+        c->arr_pending[g] = false;
+      }
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // diagnostics tick launches
 template <int S>
@@ -1025,13 +1412,18 @@ static void launch_project(nq_ctx* c, double* part) {
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
-template <int MODE>
-static void launch_xdiag_m(nq_ctx* c, double qbar, double abar, double* part) {
+template <int MODE, bool SLAB>
+static void launch_xdiag_t(nq_ctx* c, double qbar, double abar, double* part) {
   switch (c->N) {
-#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_diag<n, MODE, false>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mQ, c->mQw, c->mPhi, c->twx, c->kk, qbar, abar, part); } break;
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; hipLaunchKernelGGL((k_x_diag<n, MODE, SLAB>), dim3(c->Nloc / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, c->mQ, c->mQw, c->mPhi, c->twx, c->kk, qbar, abar, part); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
   }
+}
+template <int MODE>
+static void launch_xdiag_m(nq_ctx* c, double qbar, double abar, double* part) {
+  if (c->P > 1) launch_xdiag_t<MODE, true>(c, qbar, abar, part);
+  else launch_xdiag_t<MODE, false>(c, qbar, abar, part);
 }
 static int xdiag_blocks(const nq_ctx* c) {
   switch (c->N) {
@@ -1131,7 +1523,6 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
   if (P < 1 || rank < 0 || rank >= P || (P & (P - 1)) || p->nx / P < 2 * CL ||
       (P > 1 && (p->nx / 2 + 1 + P - 1) / P >= 2048))
     NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: %d ranks unsupported for nx=%d (power of two, at least %d columns per rank)", P, p->nx, 2 * CL);
-  if (P > 1 && !ext) NQ_FAIL((nq_ctx*)nullptr, -1, "nq_create_slab: exchange buffers are required when nranks > 1");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: no HIP device available");
   if (device < 0 || device >= ndev) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: device %d out of range (%d devices)", device, ndev);
@@ -1146,6 +1537,8 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
   c->P = P;
   c->rank = rank;
   c->Nloc = sg.Nloc;
+  c->row0 = 0;
+  c->nrows = sg.Nloc;
   c->Wf = sg.Wf;
   c->kf0 = rank * sg.Wf;
   c->Wl = (P == 1) ? sg.WhG : sg.Wl;
@@ -1400,6 +1793,17 @@ int nq_destroy(nq_ctx* c) {
     if (e) hipEventDestroy(e);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  if (c->mstream) hipStreamSynchronize(c->mstream);
+  for (hipEvent_t e : c->ev_prod)
+    if (e) hipEventDestroy(e);
+  for (auto& row : c->ev_arr)
+    for (hipEvent_t e : row)
+      if (e) hipEventDestroy(e);
+  for (hipEvent_t e : {c->ev_col, c->ev_done, c->ev_red})
+    if (e) hipEventDestroy(e);
+  for (hipEvent_t e : c->xev) hipEventDestroy(e);
+  if (c->mstream) hipStreamDestroy(c->mstream);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -1657,9 +2061,343 @@ int nq_reduce_buffer(nq_ctx* c, int which, void** ptr, int* count) {
     case 1: *ptr = c->carryW; *count = 4; break;
     case 2: *ptr = c->carryQ; *count = 3; break;
     case 3: *ptr = c->gradS1; *count = 1; break;
+    case 4: *ptr = c->diag_out; *count = 16; break;
+    case 5: *ptr = c->diag_out ? c->diag_out + 16 : nullptr; *count = 16; break;
     default: NQ_FAIL(c, -1, "nq_reduce_buffer: which = %d", which);
   }
   return 0;
+}
+
+
+// ---- the slab step inside the library: API ------------------------------------------------------------------------
+int nq_comm_unique_id(void* out128) {
+  if (!out128) return -1;
+  std::string err;
+  if (!rccl_load(&err)) NQ_FAIL((nq_ctx*)nullptr, -6, "nq_comm_unique_id: %s", err.c_str());
+  NcclId id;
+  NCCLCHK((nq_ctx*)nullptr, g_rccl.GetUniqueId(&id));
+  memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+int nq_comm_init(nq_ctx* c, const void* id128, int nranks, int rank) {
+  if (!c || !id128) return -1;
+  if (nranks != c->P || rank != c->rank) NQ_FAIL(c, -1, "nq_comm_init: rank %d of %d given to a context created as rank %d of %d", rank, nranks, c->rank, c->P);
+  if (c->link != LINK_NONE) NQ_FAIL(c, -4, "nq_comm_init: the context already has a link");
+  std::string err;
+  if (!rccl_load(&err)) NQ_FAIL(c, -6, "nq_comm_init: %s", err.c_str());
+  HIPCHK(c, hipSetDevice(c->device));
+  NcclId id;
+  memcpy(&id, id128, sizeof(id));
+  NCCLCHK(c, g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+  c->link = LINK_RCCL;
+  return slab_link_setup(c);
+}
+int nq_slab_attach_peers(nq_ctx* const* ctxs, int nranks) {
+  if (!ctxs || nranks < 1 || nranks > 8) NQ_FAIL((nq_ctx*)nullptr, -1, "nq_slab_attach_peers: 1..8 contexts");
+  std::vector<nq_ctx*> all(ctxs, ctxs + nranks);
+  for (int r = 0; r < nranks; ++r) {
+    nq_ctx* c = all[r];
+    if (!c || c->P != nranks || c->rank != r || c->device != all[0]->device || c->link != LINK_NONE)
+      NQ_FAIL(c, -1, "nq_slab_attach_peers: context %d is not rank %d of %d on the common device (or already linked)", r, r, nranks);
+  }
+  for (nq_ctx* c : all) {
+    c->peers = all;
+    c->link = LINK_PEERS;
+    int rc = slab_link_setup(c);
+    if (rc) return rc;
+  }
+  return 0;
+}
+int nq_slab_set_callbacks(nq_ctx* c, nq_exchange_fn exchange, nq_allreduce_fn allreduce, void* user) {
+  if (!c || !exchange || !allreduce) return -1;
+  if (c->link != LINK_NONE && c->link != LINK_CALLBACK) NQ_FAIL(c, -4, "nq_slab_set_callbacks: the context already has a link");
+  c->xcb = exchange;
+  c->rcb = allreduce;
+  c->cb_user = user;
+  c->link = LINK_CALLBACK;
+  return slab_link_setup(c);
+}
+int nq_slab_config(nq_ctx* c, int nchunks) {
+  if (!c) return -1;
+  if (nchunks != 1 && nchunks != 2 && nchunks != 4 && nchunks != 8) NQ_FAIL(c, -1, "nq_slab_config: nchunks = %d (1, 2, 4 or 8)", nchunks);
+  std::vector<nq_ctx*> grp = c->link == LINK_PEERS ? c->peers : std::vector<nq_ctx*>(1, c);
+  int rc = slab_settle(grp);
+  if (rc) return rc;
+  for (nq_ctx* x : grp) x->nchunk = nchunks;
+  return 0;
+}
+int nq_slab_step(nq_ctx* c, int nsteps) {
+  if (!c) return -1;
+  if (c->ybj) NQ_FAIL(c, -4, "nq_slab_step: YBJModel is single-rank only");
+  if (c->passive || c->dual) NQ_FAIL(c, -4, "nq_slab_step: passive scalar / dual-copy q are single-rank only");
+  if (nsteps < 0) NQ_FAIL(c, -1, "nq_slab_step: nsteps < 0");
+  std::vector<nq_ctx*> grp;
+  SLABTRY(slab_group(c, &grp));
+  for (nq_ctx* x : grp) HIPCHK(x, hipSetDevice(x->device));
+  c->n_calls += 1;
+  for (int i = 0; i < nsteps; ++i) SLABTRY(slab_step_once(grp));
+  SLABTRY(slab_settle(grp));
+  for (nq_ctx* x : grp) HIPCHK(x, hipGetLastError());
+  return 0;
+}
+
+// rows of a physical field -> the x side of the carrier array of exchange group 0 (q: the uq slot, phi: the W slot)
+static int rows_scratch(nq_ctx* c, cd** out) {
+  if (!c->scr_f0) ALLOC(c, c->scr_f0, (size_t)c->Nloc * c->N);
+  *out = c->scr_f0;
+  return 0;
+}
+int nq_slab_put_rows(nq_ctx* c, int which, const double* rows) {
+  if (!c || !rows) return -1;
+  if (which == 1 && !c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
+  HIPCHK(c, hipSetDevice(c->device));
+  cd* scr = nullptr;
+  SLABTRY(rows_scratch(c, &scr));
+  const size_t n = (size_t)c->Nloc * c->N;
+  if (which == 0) {
+    HIPCHK(c, hipMemcpyAsync(scr, rows, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    switch (c->N) {
+#define CASE_(nn, a, b) case nn: { typedef XPlan<nn> X; hipLaunchKernelGGL((k_x_put_real<nn, true>), dim3((c->Nloc + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, (const double*)scr, c->mUq, c->Nloc, c->tw); } break;
+      NQ_FOR_SIZES(CASE_)
+#undef CASE_
+    }
+  } else if (which == 1) {
+    HIPCHK(c, hipMemcpyAsync(scr, rows, sizeof(cd) * n, hipMemcpyHostToDevice, c->stream));
+    switch (c->N) {
+#define CASE_(nn, a, b) case nn: { typedef XPlan<nn> X; hipLaunchKernelGGL((k_x_put_cplx<nn, true>), dim3((c->Nloc + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, (const cd*)scr, c->mW, c->Nloc, c->tw); } break;
+      NQ_FOR_SIZES(CASE_)
+#undef CASE_
+    }
+  } else NQ_FAIL(c, -1, "nq_slab_put_rows: which = %d", which);
+  HIPCHK(c, hipGetLastError());
+  return nq_sync(c);                            // the host rows may be released
+}
+// collective half of set_q / set_phi: exchange the carrier, finish the transform on the column slabs, then the phases of
+// Kernel.set_q (Kernel.py:520-535: inversion with the current phi, quirk Q2) / Kernel.set_phi (:538-551)
+int nq_slab_commit(nq_ctx* c, int which) {
+  if (!c) return -1;
+  std::vector<nq_ctx*> grp;
+  SLABTRY(slab_group(c, &grp));
+  for (nq_ctx* x : grp) HIPCHK(x, hipSetDevice(x->device));
+  SLABTRY(slab_settle(grp));
+  nq_ctx* c0 = grp[0];
+  if (which == 0) {
+    SLABTRY(exchange_now(grp, 0, true));
+    for (nq_ctx* x : grp) {
+      launch_A_m(x, false, {&x->mUq});
+      if (x->Wh > 0) launch_B_p(x, false, x->mUq.ys, x->mUq.pitch, x->q.y[x->q.cur], x->Ph, x->Wh, 1.0);
+    }
+    if (c0->p.model == NQ_MODEL_COUPLED) {
+      for (nq_ctx* x : grp) phase_wavepv(x);
+      SLABTRY(exchange_now(grp, 2, true));
+    }
+    for (nq_ctx* x : grp) {
+      phase_invert_y(x, x->q.y[x->q.cur], true, x->part0Q, nullptr);
+      if (x->bud && x->kernel_family)
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->part0Q, x->nwq, 3, 3, x->carryQ);
+      x->have_q = true;
+    }
+    SLABTRY(exchange_now(grp, 3, false));
+    if (c0->bud && c0->kernel_family) SLABTRY(slab_allreduce(grp, 2));
+  } else if (which == 1) {
+    if (!c0->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
+    SLABTRY(exchange_now(grp, 0, true));
+    for (nq_ctx* x : grp) {
+      launch_A_m(x, false, {&x->mW});
+      launch_B_p(x, false, x->mW.ys, x->mW.pitch, x->w.y[x->w.cur], x->Wf, x->Wf, 1.0);
+      launch_emit_phi(x, x->w.y[x->w.cur]);
+      launch_A_m(x, true, {&x->mPhi, &x->mPhiy});
+      if (x->bud) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->part0W, x->nww, NQ_PARTW, 4, x->carryW);
+      x->have_phi = true;
+    }
+    SLABTRY(exchange_now(grp, 1, false));
+    if (c0->bud) SLABTRY(slab_allreduce(grp, 1));
+    for (nq_ctx* x : grp) SLABTRY(nq_refresh_grad_phi(x));
+  } else NQ_FAIL(c, -1, "nq_slab_commit: which = %d", which);
+  SLABTRY(slab_settle(grp));
+  for (nq_ctx* x : grp) {
+    HIPCHK(x, hipGetLastError());
+    SLABTRY(nq_sync(x));
+  }
+  return 0;
+}
+// this rank's rows of a physical field, from the mixed-space rows of the last inversion / emission on the x side
+int nq_slab_get_rows(nq_ctx* c, int id, double* out) {
+  if (!c || !out) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  cd* scr = nullptr;
+  SLABTRY(rows_scratch(c, &scr));
+  const size_t n = (size_t)c->Nloc * c->N;
+  const MArr* src = nullptr;
+  int mode = 0, zero_nyq = 0, mul_ik = 0;
+  bool real = true;
+  switch (id) {
+    case NQ_F_Q: src = &c->mQ; break;
+    case NQ_F_P: src = &c->mP; break;
+    case NQ_F_U: src = &c->mU; break;
+    case NQ_F_V: src = &c->mP; mode = 1; zero_nyq = c->kernel_family ? 1 : 0; break;
+    case NQ_F_QW:
+      if (c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qw exists only in the coupled model");
+      src = &c->mQw;
+      break;
+    case NQ_F_PHI: src = &c->mPhi; real = false; break;
+    case NQ_F_PHIX: src = &c->mGx; real = false; mul_ik = 1; break;
+    case NQ_F_PHIY: src = &c->mGy; real = false; break;
+    default: NQ_FAIL(c, -1, "nq_slab_get_rows: field id %d", id);
+  }
+  if (!real && !c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
+  switch (c->N) {
+#define CASE_(nn, a, b) case nn: { typedef XPlan<nn> X; const dim3 grid((c->Nloc + X::C - 1) / X::C), blk(X::THREADS); \
+      if (real) hipLaunchKernelGGL((k_x_get_real<nn, true>), grid, blk, X::LDS_BYTES, c->stream, *src, reinterpret_cast<double*>(scr), c->Nloc, c->tw, c->kk, mode, zero_nyq); \
+      else hipLaunchKernelGGL((k_x_get_cplx<nn, true>), grid, blk, X::LDS_BYTES, c->stream, *src, scr, c->Nloc, c->tw, c->kk, mul_ik); } break;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+  }
+  HIPCHK(c, hipMemcpyAsync(out, scr, (real ? sizeof(double) : sizeof(cd)) * n, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+
+// Diagnostics tick of a slab-decomposed simulation: the 32 sums of nq_diagnostics, every rank's part summed over the ranks
+// (two all-reduces: the spectral half gives the two means the physical half is centred with).  Collective.
+int nq_slab_diagnostics(nq_ctx* c, double* out) {
+  if (!c || !out) return -1;
+  std::vector<nq_ctx*> grp;
+  SLABTRY(slab_group(c, &grp));
+  SLABTRY(slab_settle(grp));
+  nq_ctx* c0 = grp[0];
+  const int N = c0->N, NB = 1024;
+  const double M = (double)N * N;
+  const bool waves = c0->kernel_family, coupled = c0->p.model == NQ_MODEL_COUPLED;
+  if (waves && !c0->have_phi) NQ_FAIL(c, -4, "nq_slab_diagnostics: set_phi has not been called");
+  for (nq_ctx* x : grp) {
+    HIPCHK(x, hipSetDevice(x->device));
+    const int nxb = xdiag_blocks(x), nww = (x->Wf / CL) * x->S2;
+    if (!x->diag_part) {
+      size_t need = (size_t)NB * 9;
+      if ((size_t)nxb * 8 > need) need = (size_t)nxb * 8;
+      if ((size_t)nww * 4 > need) need = (size_t)nww * 4;
+      ALLOC(x, x->diag_part, need);
+      ALLOC(x, x->diag_out, (size_t)40);
+    }
+    double* d = x->diag_out;
+    HIPCHK(x, hipMemsetAsync(d, 0, sizeof(double) * 40, x->stream));
+    const cd* qh = x->q.y[x->q.cur];
+    if (waves) {
+      const cd* phih = x->w.y[x->w.cur];
+      hipLaunchKernelGGL(k_diag_phi, dim3(NB), dim3(256), 0, x->stream, phih, N, x->Wf, x->Wf, x->kf0, x->kk, x->ll, x->diag_part);
+      hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, NB, 4, 4, d);
+      if (x->kf0 == 0) HIPCHK(x, hipMemcpyAsync(d + 4, phih, sizeof(cd), hipMemcpyDeviceToDevice, x->stream));
+    }
+    if (x->Wh > 0) {
+      hipLaunchKernelGGL(k_diag_q, dim3(NB), dim3(256), 0, x->stream, qh, (const cd*)(coupled ? x->qwh : nullptr), (const cd*)x->ph, N, x->Wh, x->Ph, x->kh0, x->kk, x->ll, x->diag_part);
+      hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, NB, 9, 9, d + 6);
+    }
+    if (x->kh0 == 0) {                              // [15] <- Re(qh - qwh)[0,0] (the owner of column 0 contributes it)
+      HIPCHK(x, hipMemcpyAsync(d + 15, qh, sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+      if (coupled) {
+        HIPCHK(x, hipMemcpyAsync(d + 32, x->qwh, sizeof(double), hipMemcpyDeviceToDevice, x->stream));
+        hipLaunchKernelGGL(k_axpy1, dim3(1), dim3(1), 0, x->stream, d + 15, d + 32, -1.0);
+      }
+    }
+  }
+  SLABTRY(slab_allreduce(grp, 4));
+  double h[16];
+  HIPCHK(c0, hipMemcpyAsync(h, c0->diag_out, sizeof(double) * 16, hipMemcpyDeviceToHost, c0->stream));
+  SLABTRY(nq_sync(c0));
+  for (int i = 0; i < 15; ++i) out[i] = h[i];
+  for (int i = 15; i < 32; ++i) out[i] = 0.0;
+  const double qbar = h[15] / M, abar = h[0] / (M * M);
+  out[15] = qbar;
+  if (!waves) return 0;
+  for (nq_ctx* x : grp) {
+    if (coupled) launch_xdiag_m<MODE_COUPLED>(x, qbar, abar, x->diag_part);
+    else launch_xdiag_m<MODE_UNCOUPLED>(x, qbar, abar, x->diag_part);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, xdiag_blocks(x), 8, 8, x->diag_out + 16);
+  }
+  for (int which = 0; which < 2; ++which) {
+    for (nq_ctx* x : grp) launch_products(x, which == 0 ? 1.0 : 0.0, which == 0 ? 0.0 : 1.0);
+    SLABTRY(exchange_now(grp, 0, true));
+    for (nq_ctx* x : grp) {
+      const int nww = (x->Wf / CL) * x->S2;
+      launch_A_m(x, false, {&x->mW});
+      launch_project(x, x->diag_part);
+      hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, nww, 4, 4, x->diag_out + 24 + 4 * which);
+    }
+  }
+  SLABTRY(slab_allreduce(grp, 5));
+  HIPCHK(c0, hipMemcpyAsync(out + 16, c0->diag_out + 16, sizeof(double) * 16, hipMemcpyDeviceToHost, c0->stream));
+  for (nq_ctx* x : grp) SLABTRY(nq_sync(x));
+  return 0;
+}
+// max |u|, max |v|, max |phi| over THIS rank's rows (the caller takes the max over ranks: Kernel._calc_cfl, Kernel.py:660-662)
+int nq_slab_local_max(nq_ctx* c, double* out3) {
+  if (!c || !out3) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  cd* scr = nullptr;
+  SLABTRY(rows_scratch(c, &scr));
+  if (!c->diag_out) {
+    ALLOC(c, c->diag_out, (size_t)40);
+  }
+  double* d = c->diag_out + 34;
+  HIPCHK(c, hipMemsetAsync(d, 0, sizeof(double) * 3, c->stream));
+  const size_t n = (size_t)c->Nloc * c->N;
+  for (int which = 0; which < (c->kernel_family ? 3 : 2); ++which) {
+    const MArr& src = which == 0 ? c->mU : (which == 1 ? c->mP : c->mPhi);
+    switch (c->N) {
+#define CASE_(nn, a, b) case nn: { typedef XPlan<nn> X; const dim3 grid((c->Nloc + X::C - 1) / X::C), blk(X::THREADS); \
+        if (which < 2) hipLaunchKernelGGL((k_x_get_real<nn, true>), grid, blk, X::LDS_BYTES, c->stream, src, reinterpret_cast<double*>(scr), c->Nloc, c->tw, c->kk, which, (which == 1 && c->kernel_family) ? 1 : 0); \
+        else hipLaunchKernelGGL((k_x_get_cplx<nn, true>), grid, blk, X::LDS_BYTES, c->stream, src, scr, c->Nloc, c->tw, c->kk, 0); } break;
+      NQ_FOR_SIZES(CASE_)
+#undef CASE_
+    }
+    if (which < 2) hipLaunchKernelGGL(k_reduce_real_max, dim3(1024), dim3(256), 0, c->stream, reinterpret_cast<const double*>(scr), n, d + which);
+    else hipLaunchKernelGGL(k_reduce, dim3((c->N + 255) / 256, c->Nloc), dim3(256), 0, c->stream, (const cd*)scr, c->N, c->N, c->N, 3, c->kk, c->ll, d + 2);
+  }
+  HIPCHK(c, hipMemcpyAsync(out3, d, sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+int nq_slab_counters(nq_ctx* c, double* out, int reset) {
+  if (!c || !out) return -1;
+  SLABTRY(nq_sync(c));
+  if (c->mstream) HIPCHK(c, hipStreamSynchronize(c->mstream));
+  float tot = 0.f;
+  for (size_t i = 0; i + 1 < c->xev_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->xev[i], c->xev[i + 1]) == hipSuccess) tot += ms;
+  }
+  out[0] = (double)c->n_calls;
+  out[1] = (double)c->n_steps;
+  out[2] = (double)c->n_exch;
+  out[3] = c->bytes_sent;
+  out[4] = (double)tot;
+  out[5] = (double)effective_chunks(c);
+  if (reset) {
+    c->n_calls = c->n_steps = c->n_exch = 0;
+    c->bytes_sent = 0.0;
+    c->xev_used = 0;
+    c->xtime = reset == 2;
+  }
+  return 0;
+}
+
+// host copies of the blocks that are summed over ranks (nq_reduce_buffer): what a callback link reduces
+int nq_reduce_read(nq_ctx* c, int which, double* host_out) {
+  if (!c || !host_out) return -1;
+  int n = 0;
+  double* p = red_ptr(c, which, &n);
+  if (!p) NQ_FAIL(c, -1, "nq_reduce_read: block %d does not exist (yet)", which);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(host_out, p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
+int nq_reduce_write(nq_ctx* c, int which, const double* host_in) {
+  if (!c || !host_in) return -1;
+  int n = 0;
+  double* p = red_ptr(c, which, &n);
+  if (!p) NQ_FAIL(c, -1, "nq_reduce_write: block %d does not exist (yet)", which);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(p, host_in, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  return nq_sync(c);
 }
 
 // ---- FFT seam ----------------------------------------------------------------------------------
@@ -1947,7 +2685,7 @@ int nq_diagnostics(nq_ctx* c, double* out) {
     if ((size_t)nxb * 8 > need) need = (size_t)nxb * 8;
     if ((size_t)nww * 4 > need) need = (size_t)nww * 4;
     ALLOC(c, c->diag_part, need);
-    ALLOC(c, c->diag_out, (size_t)32);
+    ALLOC(c, c->diag_out, (size_t)40);
   }
   double* d = c->diag_out;
   HIPCHK(c, hipMemsetAsync(d, 0, sizeof(double) * 32, c->stream));
@@ -1963,7 +2701,7 @@ int nq_diagnostics(nq_ctx* c, double* out) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, NB, 4, 4, d);
     HIPCHK(c, hipMemcpyAsync(d + 4, phih, sizeof(cd), hipMemcpyDeviceToDevice, c->stream));
   }
-  hipLaunchKernelGGL(k_diag_q, dim3(NB), dim3(256), 0, c->stream, qh, (const cd*)(c->p.model == NQ_MODEL_COUPLED ? c->qwh : nullptr), (const cd*)c->ph, N, c->Wh, c->Ph, c->kk, c->ll, c->diag_part);
+  hipLaunchKernelGGL(k_diag_q, dim3(NB), dim3(256), 0, c->stream, qh, (const cd*)(c->p.model == NQ_MODEL_COUPLED ? c->qwh : nullptr), (const cd*)c->ph, N, c->Wh, c->Ph, 0, c->kk, c->ll, c->diag_part);
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, NB, 9, 9, d + 6);
   double h[32];
   HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));

@@ -1350,4 +1350,116 @@ k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict
   if (bud_part && MODE == MODE_QGC) block_sum_store<3>(sc, red, bud_part + NB * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 3);
 }
 
+
+// ---- physical rows <-> mixed-space rows of the slab layout (set_q / set_phi / field reads of a slab context) --------
+// Same transforms as k_x_r2c / k_x_c2c / k_x_c2r (nq_generic.hpp), addressed through MArr so that the rows land in / come
+// from the x side of an exchange group.  `rows` are this rank's local rows, contiguous (nrows, N).
+template <int N, bool SLAB>
+__global__ void __launch_bounds__(XPlan<N>::THREADS)
+k_x_put_real(const double* __restrict__ rows, MArr out, int nrows, const cd* __restrict__ tw) {
+  typedef XPlan<N> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const int row = blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename X::F::Tw twr;
+  X::F::load_tw(twr, j, tw, 1);
+  cd r[P];
+  const bool ok = row < nrows;
+#pragma unroll
+  for (int t = 0; t < P; ++t) r[t] = cmake(ok ? rows[(size_t)row * N + j + t * T] : 0.0, 0.0);
+  X::F::template run<false>(r, j, c, lds, twr);
+  if (ok) {
+    const XRowT<SLAB> o = xrow<SLAB>(out, (size_t)row);
+#pragma unroll
+    for (int t = 0; t <= P / 2; ++t) {
+      const int kx = j + t * T;
+      if (kx <= N / 2) *o.at(kx) = r[t];
+    }
+  }
+}
+template <int N, bool SLAB>
+__global__ void __launch_bounds__(XPlan<N>::THREADS)
+k_x_put_cplx(const cd* __restrict__ rows, MArr out, int nrows, const cd* __restrict__ tw) {
+  typedef XPlan<N> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const int row = blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename X::F::Tw twr;
+  X::F::load_tw(twr, j, tw, 1);
+  cd r[P];
+  const bool ok = row < nrows;
+#pragma unroll
+  for (int t = 0; t < P; ++t) r[t] = ok ? rows[(size_t)row * N + j + t * T] : cmake(0, 0);
+  X::F::template run<false>(r, j, c, lds, twr);
+  if (ok) {
+    const XRowT<SLAB> o = xrow<SLAB>(out, (size_t)row);
+#pragma unroll
+    for (int t = 0; t < P; ++t) *o.at(j + t * T) = r[t];
+  }
+}
+// half-spectrum rows -> real rows (numpy.fft.irfft along x: imaginary parts of kx = 0 and N/2 ignored); mode 1: the rows are
+// multiplied by i*kk first (v = Re ifft(ik psi)), zero_nyq drops column N/2 (Kernel family, DESIGN.md "Nyquist lines")
+template <int N, bool SLAB>
+__global__ void __launch_bounds__(XPlan<N>::THREADS)
+k_x_get_real(MArr in, double* __restrict__ rows, int nrows, const cd* __restrict__ tw, const double* __restrict__ kk,
+             int mode, int zero_nyq) {
+  typedef XPlan<N> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const int row = blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename X::F::Tw twr;
+  X::F::load_tw(twr, j, tw, 1);
+  cd r[P];
+  const bool ok = row < nrows;
+  const XRowT<SLAB> src = xrow<SLAB>(in, (size_t)(ok ? row : 0));
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int kx = j + t * T;
+    cd v = cmake(0, 0);
+    if (ok) {
+      const int m = kx <= N / 2 ? kx : N - kx;
+      v = *src.at(m);
+      if (mode == 1) v = cscale(cmul_i(v), kk[m]);
+      if (m == 0 || m == N / 2) v.y = 0.0;
+      if (zero_nyq && m == N / 2) v.x = 0.0;
+      if (kx > N / 2) v = cconj(v);
+    }
+    r[t] = v;
+  }
+  X::F::template run<true>(r, j, c, lds, twr);
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) rows[(size_t)row * N + j + t * T] = r[t].x;
+  }
+}
+template <int N, bool SLAB>
+__global__ void __launch_bounds__(XPlan<N>::THREADS)
+k_x_get_cplx(MArr in, cd* __restrict__ rows, int nrows, const cd* __restrict__ tw, const double* __restrict__ kk, int mul_ik) {
+  typedef XPlan<N> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const int row = blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename X::F::Tw twr;
+  X::F::load_tw(twr, j, tw, 1);
+  cd r[P];
+  const bool ok = row < nrows;
+  const XRowT<SLAB> src = xrow<SLAB>(in, (size_t)(ok ? row : 0));
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int kx = j + t * T;
+    cd v = ok ? *src.at(kx) : cmake(0, 0);
+    if (mul_ik) v = cscale(cmul_i(v), kk[kx]);
+    r[t] = v;
+  }
+  X::F::template run<true>(r, j, c, lds, twr);
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) rows[(size_t)row * N + j + t * T] = r[t];
+  }
+}
+
 }  // namespace nq

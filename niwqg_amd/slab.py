@@ -1,15 +1,20 @@
 """1-D slab decomposition of ONE simulation over several GPUs (one process per GPU, RCCL over xGMI).
 
-Physical / mixed-space rows are split over ranks on the "x side" (row kernels), spectral / mixed-space
-columns on the "y side" (spectral kernels); the arrays that cross together form four exchange groups, each
-moved by ONE ``all_to_all_single`` per transition: 4 per ETDRK4 stage for CoupledModel, 16 per step (SURVEY
-section 8e).  The device library lays its buffers out so that the x-side buffer *is* the send/receive
-buffer (blocked rows) and the y-side buffer *is* the column slab: no pack or unpack passes.
+Physical / mixed-space rows are split over ranks on the "x side" (row kernels), spectral / mixed-space columns on the
+"y side" (spectral kernels); the arrays that cross together form four exchange groups.  The whole
+step -- phases AND exchanges -- runs inside the library (``nq_slab_step``): one host call per ``step(n)``, the exchanges on
+a second HIP stream, cut into row chunks so that row kernels run under the transfers.  How the blocks cross is the
+context's *link*:
 
-Two transports share all of the logic:
-  * ``TorchTransport``  -- real ranks, ``torch.distributed`` (backend "nccl" = RCCL on ROCm);
-  * ``VirtualTransport`` -- P ranks inside one process on one GPU, blocks moved with tensor copies; this is how
-    the decomposition is tested on a single-GPU box (tests/test_gpu_slab.py).
+  * ``"rccl"``      real ranks: grouped ncclSend/ncclRecv issued by the library itself; ``torch.distributed`` is used
+                    once, to hand rank 0's 128-byte unique id to the other ranks;
+  * ``"peers"``     all ranks live in this process on one GPU (the one-GPU test double): the same choreography of
+                    streams and events with device-to-device copies for the wire;
+  * ``"callback"``  the library calls back into Python at every exchange and ``torch.distributed`` moves the buffers
+                    (``all_to_all_single`` / ``all_reduce``), optionally staged through host memory so that a CPU-only
+                    backend (gloo) can carry them: how two processes sharing ONE GPU rehearse the multi-process path.
+
+``set_q`` / ``set_phi`` take physical fields and transform them on the devices: every rank uploads only its own rows.
 """
 import ctypes
 
@@ -20,48 +25,51 @@ from . import _lib
 (PH_PRODUCTS, PH_UPDATE, PH_WAVEPV, PH_INVERT, PH_EMIT_PHI, PH_INVERT_NOW, PH_BUDGET_SUMS,
  PH_BUDGET_FINISH) = range(8)
 
+_REAL_ROWS = (_lib.F_Q, _lib.F_P, _lib.F_U, _lib.F_V, _lib.F_QW)
+_CPLX_ROWS = (_lib.F_PHI, _lib.F_PHIX, _lib.F_PHIY)
+
 
 class SlabRank(object):
-    """One rank's device context plus its torch-owned exchange buffers."""
+    """One rank's device context.  The exchange buffers belong to the library unless ``torch_buffers`` asks for torch
+    tensors (the callback link moves them with torch.distributed)."""
 
-    def __init__(self, model, nx, kk, ll, filtr, dt, nranks, rank, device, stream=None, budgets=True, **phys):
-        import torch
-        self.torch = torch
+    def __init__(self, model, nx, kk, ll, filtr, dt, nranks, rank, device, budgets=True, torch_buffers=False, **phys):
         self.L = _lib.lib()
-        self.model, self.nx, self.nranks, self.rank = model, int(nx), int(nranks), int(rank)
-        self.dev = torch.device("cuda", device)
+        self.model, self.nx, self.nranks, self.rank, self.device = model, int(nx), int(nranks), int(rank), int(device)
         p = _lib.Params(model=model, nx=nx, budgets=int(bool(budgets)), dual_q=0, dt=dt,
                         U=phys.get("U", 0.0), f=phys.get("f", 1e-4), kappa2=phys.get("kappa2", 1.0),
                         nu=phys.get("nu", 0.0), nu4=phys.get("nu4", 0.0), mu=phys.get("mu", 0.0),
                         nuw=phys.get("nuw", 0.0), nu4w=phys.get("nu4w", 0.0), muw=phys.get("muw", 0.0),
                         beta=phys.get("beta", 0.0))
         self.budgets = bool(budgets)
-        self.gx, self.gy = [], []            # x-side / y-side tensors of the four groups (None when empty)
-        ext = (ctypes.c_void_p * 9)()
-        for g in range(4):
-            n = self.L.nq_group_elems(ctypes.byref(p), nranks, g)
-            if n < 0:
-                raise RuntimeError("nq_group_elems: nx=%d not divisible over %d ranks" % (nx, nranks))
-            if n == 0:
-                self.gx.append(None)
-                self.gy.append(None)
-                continue
-            tx = torch.zeros(n, dtype=torch.complex128, device=self.dev)
-            ty = torch.zeros(n, dtype=torch.complex128, device=self.dev)
-            self.gx.append(tx)
-            self.gy.append(ty)
-            ext[2 * g], ext[2 * g + 1] = tx.data_ptr(), ty.data_ptr()
-        self.sums = torch.zeros(64, dtype=torch.float64, device=self.dev)     # see nq_reduce_buffer
-        ext[8] = self.sums.data_ptr()
-        if stream is None:
-            stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.gx, self.gy, self.sums = [None] * 4, [None] * 4, None
+        ext = None
+        if torch_buffers:
+            import torch
+            self.torch = torch
+            dev = torch.device("cuda", device)
+            ext = (ctypes.c_void_p * 9)()
+            for g in range(4):
+                n = self.L.nq_group_elems(ctypes.byref(p), nranks, g)
+                if n < 0:
+                    raise RuntimeError("nq_group_elems: nx=%d not divisible over %d ranks" % (nx, nranks))
+                if n == 0:
+                    continue
+                self.gx[g] = torch.zeros(n, dtype=torch.complex128, device=dev)
+                self.gy[g] = torch.zeros(n, dtype=torch.complex128, device=dev)
+                ext[2 * g], ext[2 * g + 1] = self.gx[g].data_ptr(), self.gy[g].data_ptr()
+            self.sums = torch.zeros(64, dtype=torch.float64, device=dev)     # see nq_reduce_buffer
+            ext[8] = self.sums.data_ptr()
+            torch.cuda.synchronize(dev)          # the zero fills ran on torch's stream; the library has its own
         kk = np.ascontiguousarray(kk, np.float64)
         ll = np.ascontiguousarray(ll, np.float64)
         filtr = np.ascontiguousarray(filtr, np.float64)
         r = np.ascontiguousarray(np.exp(2j * np.pi * (np.arange(1.0, 33.0) / 32.0))).view(np.float64)
         h = ctypes.c_void_p()
+        # stream NULL: the context makes its own compute stream; everything that has to be ordered against it goes
+        # through the library (exchange stream + events) or happens with that stream drained (callbacks)
         rc = self.L.nq_create_slab(ctypes.byref(p), _lib._dptr(kk), _lib._dptr(ll), _lib._dptr(filtr), _lib._dptr(r),
-                                   device, nranks, rank, ext, ctypes.c_void_p(stream), ctypes.byref(h))
+                                   device, nranks, rank, ext, None, ctypes.byref(h))
         if rc != 0:
             raise RuntimeError("nq_create_slab failed (%d): %s" % (rc, self.L.nq_last_error(None).decode()))
         self.h = h
@@ -84,6 +92,21 @@ class SlabRank(object):
         w = self.wh if which == 0 else self.wf
         out = np.empty((self.nx, w), np.complex128)
         self._chk(self.L.nq_download_spectral(self.h, which, _lib._dptr(out.view(np.float64))), "nq_download_spectral")
+        return out
+
+    def put_rows(self, which, rows):
+        rows = np.ascontiguousarray(rows, np.float64 if which == 0 else np.complex128)
+        assert rows.shape == (self.nloc, self.nx), rows.shape
+        self._chk(self.L.nq_slab_put_rows(self.h, which, _lib._dptr(rows.view(np.float64))), "nq_slab_put_rows")
+
+    def get_rows(self, fid):
+        out = np.empty((self.nloc, self.nx), np.float64 if fid in _REAL_ROWS else np.complex128)
+        self._chk(self.L.nq_slab_get_rows(self.h, fid, _lib._dptr(out.view(np.float64))), "nq_slab_get_rows(%d)" % fid)
+        return out
+
+    def local_max(self):
+        out = np.zeros(3)
+        self._chk(self.L.nq_slab_local_max(self.h, _lib._dptr(out)), "nq_slab_local_max")
         return out
 
     def refresh_grad_phi(self):
@@ -112,156 +135,184 @@ class SlabRank(object):
             pass
 
 
-class TorchTransport(object):
-    """Real ranks: one SlabRank per process; collectives through torch.distributed (RCCL).
-
-    ``stage_via_host=True`` bounces every buffer through host memory so that a CPU-only backend (gloo) can carry
-    the collectives: that is how two processes sharing ONE GPU rehearse the multi-process path in the tests."""
-
-    def __init__(self, dist, stage_via_host=False):
-        self.dist = dist
-        self.host = bool(stage_via_host)
-
-    def exchange(self, ranks, g, to_y):
-        r = ranks[0]
-        if r.gx[g] is None:
-            return
-        send, recv = (r.gx[g], r.gy[g]) if to_y else (r.gy[g], r.gx[g])
-        if send.is_complex():                     # RCCL has no complex type: move (re, im) pairs as float64 rows
-            send, recv = r.torch.view_as_real(send), r.torch.view_as_real(recv)
-        if self.host:
-            hs = send.cpu()
-            hr = r.torch.empty_like(hs)
-            self.dist.all_to_all_single(hr, hs)
-            recv.copy_(hr)
-            return
-        self.dist.all_to_all_single(recv, send)
-
-    def allreduce(self, ranks, lo, hi):
-        part = ranks[0].sums[lo:hi]
-        if self.host:
-            h = part.cpu()
-            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
-            part.copy_(h)
-            return
-        self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM)
+def all_to_all_blocks(dist, torch, send, recv, stage_via_host):
+    """one exchange group: P equal blocks of ``send`` go to the P ranks, block s of ``recv`` comes from rank s"""
+    if send.is_complex():                     # RCCL / gloo have no complex type: move (re, im) pairs as float64 rows
+        send, recv = torch.view_as_real(send), torch.view_as_real(recv)
+    if stage_via_host:
+        hs = send.cpu()
+        hr = torch.empty_like(hs)
+        dist.all_to_all_single(hr, hs)
+        recv.copy_(hr)
+    else:
+        dist.all_to_all_single(recv, send)
 
 
-class VirtualTransport(object):
-    """All ranks in this process (same GPU): block (s -> d) copies stand in for the all-to-all."""
-
-    def exchange(self, ranks, g, to_y):
-        P = len(ranks)
-        if ranks[0].gx[g] is None:
-            return
-        for d in range(P):
-            dst = (ranks[d].gy[g] if to_y else ranks[d].gx[g]).view(P, -1)
-            for s in range(P):
-                src = (ranks[s].gx[g] if to_y else ranks[s].gy[g]).view(P, -1)
-                dst[s].copy_(src[d])
-
-    def allreduce(self, ranks, lo, hi):
-        tot = sum(r.sums[lo:hi] for r in ranks)
-        for r in ranks:
-            r.sums[lo:hi].copy_(tot)
+def reference_all_to_all(sends):
+    """what P ranks hold after an all-to-all of their ``sends`` (list of 1-D arrays of P equal blocks): pure numpy"""
+    P = len(sends)
+    blocks = [np.asarray(s).reshape(P, -1) for s in sends]
+    return [np.concatenate([blocks[s][d] for s in range(P)]) for d in range(P)]
 
 
 class SlabSimulation(object):
-    """Drives the phases and exchanges of one slab-decomposed simulation.
+    """One slab-decomposed simulation: this process's ranks (one real rank, or all of them as peers) and their link."""
 
-    ``ranks`` holds this process's SlabRank objects: one for real runs, all of them for virtual runs.
-    """
-
-    def __init__(self, ranks, transport):
-        self.ranks, self.tr = ranks, transport
+    def __init__(self, ranks, link="peers", dist=None, nchunks=2, stage_via_host=False):
+        self.ranks, self.link, self.dist = ranks, link, dist
+        self.L = ranks[0].L
         self.model = ranks[0].model
         self.coupled = self.model == _lib.COUPLED
         self.waves = self.model != _lib.QG
         self.budgets = ranks[0].budgets
+        self.nranks, self.nx = ranks[0].nranks, ranks[0].nx
+        self.lead = ranks[0]
+        if link == "peers":
+            if len(ranks) != self.nranks:
+                raise ValueError("peers link: this process must hold all %d ranks" % self.nranks)
+            arr = (ctypes.c_void_p * self.nranks)(*[r.h for r in ranks])
+            self.lead._chk(self.L.nq_slab_attach_peers(arr, self.nranks), "nq_slab_attach_peers")
+        elif link == "rccl":
+            import torch
+            assert len(ranks) == 1 and dist is not None
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if self.lead.rank == 0:
+                buf = (ctypes.c_ubyte * 128)()
+                self.lead._chk(self.L.nq_comm_unique_id(buf), "nq_comm_unique_id")
+                uid = torch.tensor(list(buf), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                uid = uid.to(torch.device("cuda", self.lead.device))
+            dist.broadcast(uid, src=0)
+            buf = (ctypes.c_ubyte * 128)(*[int(v) for v in uid.cpu()])
+            self.lead._chk(self.L.nq_comm_init(self.lead.h, buf, self.nranks, self.lead.rank), "nq_comm_init")
+        elif link == "callback":
+            import torch
+            assert len(ranks) == 1 and dist is not None and self.lead.gx[0] is not None, "callback link needs torch buffers"
+            r, host = self.lead, bool(stage_via_host)
+            dev = torch.device("cuda", r.device)
 
-    def _all(self, ph, stage=0):
-        for r in self.ranks:
-            r.phase(ph, stage)
+            def exchange(user, g, to_y):
+                try:
+                    send, recv = (r.gx[g], r.gy[g]) if to_y else (r.gy[g], r.gx[g])
+                    all_to_all_blocks(dist, torch, send, recv, host)
+                    torch.cuda.synchronize(dev)          # complete before the library's stream goes on
+                    return 0
+                except Exception as e:                   # never let an exception cross the C boundary
+                    self._cb_error = e
+                    return 1
+
+            def allreduce(user, which):
+                try:
+                    n = {0: 44, 1: 4, 2: 3, 3: 1, 4: 16, 5: 16}[which]
+                    buf = np.zeros(n)
+                    r._chk(self.L.nq_reduce_read(r.h, which, _lib._dptr(buf)), "nq_reduce_read")
+                    t = torch.from_numpy(buf)
+                    if not host:
+                        t = t.to(dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    buf = np.ascontiguousarray(t.cpu().numpy())
+                    r._chk(self.L.nq_reduce_write(r.h, which, _lib._dptr(buf)), "nq_reduce_write")
+                    return 0
+                except Exception as e:
+                    self._cb_error = e
+                    return 1
+
+            self._cb_error = None
+            self._xcb = _lib.EXCHANGE_FN(exchange)       # keep the trampolines alive as long as the simulation
+            self._rcb = _lib.ALLREDUCE_FN(allreduce)
+            r._chk(self.L.nq_slab_set_callbacks(r.h, self._xcb, self._rcb, None), "nq_slab_set_callbacks")
+        else:
+            raise ValueError("link %r" % (link,))
+        for r in ranks:
+            r._chk(self.L.nq_slab_config(r.h, int(nchunks)), "nq_slab_config")
+
+    def _lead_chk(self, rc, what):
+        if rc != 0 and getattr(self, "_cb_error", None) is not None:
+            e, self._cb_error = self._cb_error, None
+            raise RuntimeError("%s: the exchange callback failed: %r" % (what, e))
+        self.lead._chk(rc, what)
+
+    def describe(self):
+        how = {"rccl": "grouped ncclSend/ncclRecv issued inside the library",
+               "peers": "peer ranks in one process (device copies)",
+               "callback": "torch.distributed all_to_all_single from a library callback"}[self.link]
+        return "in-library step, %s, %d row chunks per exchange" % (how, int(self.counters()["nchunks"]))
 
     # --- initial state (same order semantics as Kernel.set_q / set_phi, quirk Q2) -------------------------
-    def set_q_spectrum(self, qh_half):
-        """qh_half: full (ny, nx/2+1) half spectrum of q on the host (numpy.fft.rfft2(q))."""
+    def _set(self, which, field):
         for r in self.ranks:
-            r.upload(0, qh_half[:, r.kh0:r.kh0 + r.wh])
-        if self.coupled:
-            self._all(PH_WAVEPV)
-            self.tr.exchange(self.ranks, 2, True)
-        self._all(PH_INVERT_NOW)
-        self.tr.exchange(self.ranks, 3, False)
-        if self.budgets and self.waves:
-            self.tr.allreduce(self.ranks, 48, 51)
+            r.put_rows(which, field[r.rank * r.nloc:(r.rank + 1) * r.nloc])
+        self._lead_chk(self.L.nq_slab_commit(self.lead.h, which), "nq_slab_commit")
 
-    def set_phi_spectrum(self, phih):
-        """phih: full (ny, nx) spectrum of phi on the host (numpy.fft.fft2(phi))."""
-        for r in self.ranks:
-            r.upload(1, phih[:, r.kf0:r.kf0 + r.wf])
-        self._all(PH_EMIT_PHI)
-        self.tr.exchange(self.ranks, 1, False)
-        if self.budgets:
-            self.tr.allreduce(self.ranks, 44, 48)
-        self.refresh_grad_phi()
+    def set_q(self, q):
+        """physical q (ny, nx); every rank uploads only its own rows (the argument may also be a view of them: anything
+        indexable by the global row range of the local ranks)"""
+        self._set(0, q)
+
+    def set_phi(self, phi):
+        self._set(1, phi)
 
     def refresh_grad_phi(self):
         for r in self.ranks:
             r.refresh_grad_phi()
 
-    def set_q(self, q):
-        """physical q (ny, nx) on the host (every rank holds the same array)"""
-        self.set_q_spectrum(np.fft.rfft2(q))
-
-    def set_phi(self, phi):
-        self.set_phi_spectrum(np.fft.fft2(phi))
-
-    def describe(self):
-        return "one all_to_all_single per transition (16 per Coupled step), phases dispatched from Python"
-
-    def reset_counters(self):
-        pass
-
-    def counters(self, nsteps):
-        """volume this rank hands to the all-to-alls per step (off-rank part), for the xGMI arithmetic in DESIGN.md 9"""
-        P = self.ranks[0].nranks
-        per_stage = sum(t.numel() * 16 for t in self.ranks[0].gx if t is not None)
-        return {"exchange_GB_sent_per_rank_per_step": 4 * per_stage * (P - 1) / max(P, 1) / 1e9}
-
     # --- time stepping --------------------------------------------------------------------------------------
     def step(self, nsteps=1):
-        tr, ranks = self.tr, self.ranks
-        for _ in range(nsteps):
-            for s in range(4):
-                self._all(PH_PRODUCTS, s)
-                tr.exchange(ranks, 0, True)
-                self._all(PH_UPDATE, s)
-                if self.waves:
-                    tr.exchange(ranks, 1, False)
-                if self.coupled:
-                    self._all(PH_WAVEPV)
-                    tr.exchange(ranks, 2, True)
-                    self._all(PH_INVERT, s)
-                tr.exchange(ranks, 3, False)
-            if self.budgets:
-                self._all(PH_BUDGET_SUMS)
-                tr.allreduce(ranks, 0, 44)
-                self._all(PH_BUDGET_FINISH)
+        self._lead_chk(self.L.nq_slab_step(self.lead.h, int(nsteps)), "nq_slab_step")
 
     def sync(self):
         for r in self.ranks:
             r.sync()
 
-    # --- gathering (tests / output): only meaningful when this process holds every rank --------------------
+    def diagnostics(self):
+        out = np.zeros(32)
+        self._lead_chk(self.L.nq_slab_diagnostics(self.lead.h, _lib._dptr(out)), "nq_slab_diagnostics")
+        return out
+
+    def max_over_ranks(self, values):
+        """element-wise max over all ranks of the simulation of a small vector this process computed for its ranks"""
+        v = np.max(np.asarray(values, float).reshape(len(self.ranks), -1), axis=0)
+        if self.link != "peers":
+            import torch
+            t = torch.from_numpy(v.copy())
+            if self.dist.get_backend() == "nccl":
+                t = t.to(torch.device("cuda", self.lead.device))
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            v = t.cpu().numpy()
+        return v
+
+    def cfl_max(self):
+        """max over the whole grid of |u|, |v|, |phi| (Kernel._calc_cfl without dt/dx)"""
+        return float(np.max(self.max_over_ranks([r.local_max() for r in self.ranks])))
+
+    def counters(self, reset=0):
+        out = np.zeros(6)
+        self.lead._chk(self.L.nq_slab_counters(self.lead.h, _lib._dptr(out), int(reset)), "nq_slab_counters")
+        return dict(host_calls=out[0], steps=out[1], exchange_chunks=out[2], bytes_sent=out[3], exchange_ms=out[4], nchunks=out[5])
+
+    # --- gathering -----------------------------------------------------------------------------------------
+    def _gather(self, parts, axis):
+        """parts: this process's pieces in rank order -> the whole array on every rank"""
+        if self.link == "peers":
+            return np.concatenate(parts, axis=axis)
+        import torch
+        mine = np.ascontiguousarray(parts[0])
+        bufs = [None] * self.nranks
+        self.dist.all_gather_object(bufs, mine)
+        return np.concatenate(bufs, axis=axis)
+
+    def gather_rows(self, fid):
+        return self._gather([r.get_rows(fid) for r in self.ranks], 0)
+
     def gather_qh(self):
-        return np.concatenate([r.download(0) for r in self.ranks], axis=1)
+        return self._gather([r.download(0) for r in self.ranks], 1)
 
     def gather_phih(self):
-        return np.concatenate([r.download(1) for r in self.ranks], axis=1)
+        return self._gather([r.download(1) for r in self.ranks], 1)
 
 
-def make_ranks(model, nx, kk, ll, filtr, dt, nranks, device=0, only_rank=None, budgets=True, **phys):
-    """All ranks on one device (virtual) or just `only_rank` (real run, one process per GPU)."""
+def make_ranks(model, nx, kk, ll, filtr, dt, nranks, device=0, only_rank=None, budgets=True, torch_buffers=False, **phys):
+    """All ranks on one device (peers) or just `only_rank` (real run, one process per GPU)."""
     which = range(nranks) if only_rank is None else [only_rank]
-    return [SlabRank(model, nx, kk, ll, filtr, dt, nranks, r, device, budgets=budgets, **phys) for r in which]
+    return [SlabRank(model, nx, kk, ll, filtr, dt, nranks, r, device, budgets=budgets, torch_buffers=torch_buffers, **phys)
+            for r in which]

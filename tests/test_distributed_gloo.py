@@ -52,36 +52,30 @@ def test_member_sharding_covers_everything_once():
 SLAB_WORKER = textwrap.dedent("""
     import sys
     sys.path.insert(0, %r)
+    import numpy as np
     import torch
     from niwqg_amd.distributed import Group
     from niwqg_amd import slab
 
-    class FakeRank(object):          # only the buffers: what the transports touch
-        def __init__(self, P, rank, n):
-            self.torch = torch
-            c = torch.complex(torch.arange(n, dtype=torch.float64) + 10.0 * rank, -torch.arange(n, dtype=torch.float64))
-            self.gx = [torch.arange(n, dtype=torch.float64) + 1000.0 * rank, torch.zeros(n, dtype=torch.complex128), None, None]
-            self.gy = [torch.zeros(n, dtype=torch.float64), c, None, None]
-            self.sums = torch.full((64,), float(rank + 1), dtype=torch.float64)
-
     g = Group(backend="gloo")
     P, n = g.world, 12
-    mine = FakeRank(P, g.rank, n)
-    tr = slab.TorchTransport(g.dist)
-    tr.exchange([mine], 0, True)                  # x -> y through all_to_all_single
-    tr.allreduce([mine], 0, 44)
-    # the same thing with every rank in one process
-    allr = [FakeRank(P, r, n) for r in range(P)]
-    vt = slab.VirtualTransport()
-    vt.exchange(allr, 0, True)
-    vt.allreduce(allr, 0, 44)
-    assert torch.equal(mine.gy[0], allr[g.rank].gy[0]), (mine.gy[0], allr[g.rank].gy[0])
-    assert torch.equal(mine.sums, allr[g.rank].sums)
-    assert float(mine.sums[0]) == P * (P + 1) / 2 and float(mine.sums[50]) == g.rank + 1
-    tr.exchange([mine], 1, False)                 # complex128 group, y -> x
-    vt.exchange(allr, 1, False)
-    assert torch.equal(mine.gx[1], allr[g.rank].gx[1]) and mine.gx[1].abs().sum() > 0
-    tr.exchange([mine], 2, False)                 # empty group: no-op
+
+    def buf(rank, cplx):
+        a = torch.arange(n, dtype=torch.float64) + 1000.0 * rank
+        return torch.complex(a, -a - 1.0) if cplx else a
+
+    for cplx in (False, True):                    # float64 group and complex128 group (moved as (re, im) rows)
+        for host in (False, True):                # direct and staged through a host copy
+            send, recv = buf(g.rank, cplx), torch.zeros(n, dtype=torch.complex128 if cplx else torch.float64)
+            slab.all_to_all_blocks(g.dist, torch, send, recv, host)
+            want = slab.reference_all_to_all([buf(r, cplx).numpy() for r in range(P)])[g.rank]
+            assert np.array_equal(recv.numpy(), want), (recv, want)
+    # the block algebra of the library's exchange: block d of rank s lands as block s of rank d
+    sends = [np.arange(P * 3) + 100 * r for r in range(P)]
+    got = slab.reference_all_to_all(sends)
+    for d in range(P):
+        for s_ in range(P):
+            assert np.array_equal(got[d].reshape(P, -1)[s_], sends[s_].reshape(P, -1)[d])
     if g.rank == 0:
         print("slab transports agree")
     g.close()
@@ -89,8 +83,9 @@ SLAB_WORKER = textwrap.dedent("""
 
 
 def test_torch_transport_equals_virtual_transport(tmp_path):
-    """The real transport (all_to_all_single / all_reduce) and the single-process stand-in used by the GPU
-    tests move the same blocks: 2 gloo ranks on CPU tensors."""
+    """What the callback link hands to torch.distributed (all_to_all_single on the blocked group buffers, complex groups
+    as (re, im) rows, optionally through a host copy) moves exactly the blocks of the reference permutation, which is
+    also what the library's own links implement (block d of rank s -> block s of rank d): 2 gloo ranks on CPU tensors."""
     from conftest import free_port
     port = free_port()
     script = tmp_path / "slab_worker.py"

@@ -1,7 +1,8 @@
-"""Slab decomposition on ONE GPU: P virtual ranks in one process, block copies instead of the RCCL
-all-to-all (niwqg_amd.slab.VirtualTransport).  Everything except the collective call itself is the code that
-runs with one process per GPU: blocked-row addressing in the row kernels, column-slab geometry in the spectral
-kernels, the phase sequence, the cross-rank sums of the budget integrals."""
+"""Slab decomposition on ONE GPU: P peer ranks in one process (the library's "peers" link: device copies for the wire).
+Everything except the wire itself is the code that runs with one process per GPU: the step inside the library
+(nq_slab_step: phases, chunked exchanges on a second stream, events), blocked-row addressing in the row kernels,
+column-slab geometry in the spectral kernels, set_q / set_phi from each rank's own rows, the cross-rank sums of the
+budget integrals and of the diagnostics tick."""
 import numpy as np
 import pytest
 
@@ -30,10 +31,10 @@ def setup_case(kind, nx, use_filter=True):
 
 
 @pytest.mark.parametrize("kind", ["coupled", "uncoupled", "qg"])
-@pytest.mark.parametrize("nranks", [2, 4])
-def test_virtual_ranks_match_single_context(kind, nranks):
+@pytest.mark.parametrize("nranks,nchunks", [(2, 1), (2, 2), (4, 4), (8, 2)])
+def test_virtual_ranks_match_single_context(kind, nranks, nchunks):
     from niwqg_amd import _lib, slab
-    nx, nsteps = 256, 3
+    nx, nsteps = (256 if nranks < 8 else 512), 3        # a rank needs at least 64 columns
     model, o, dt, phys, q0, phi0 = setup_case(kind, nx)
     # single context
     one = _lib.Context(model, nx, o.kk, o.ll, o.filtr, dt, budgets=True, **phys)
@@ -47,14 +48,21 @@ def test_virtual_ranks_match_single_context(kind, nranks):
     inc1 = one.take_budget_increments() if model != _lib.QG else (one.scalar(_lib.S_KE),)
     # P virtual ranks
     ranks = slab.make_ranks(model, nx, o.kk, o.ll, o.filtr, dt, nranks, budgets=True, **phys)
-    sim = slab.SlabSimulation(ranks, slab.VirtualTransport())
-    sim.set_q_spectrum(np.fft.rfft2(q0))
+    sim = slab.SlabSimulation(ranks, "peers", nchunks=nchunks)
+    assert sim.counters()["nchunks"] == nchunks
+    sim.set_q(q0)                          # physical fields: every rank transforms its own rows on the device
     if phi0 is not None:
-        sim.set_phi_spectrum(np.fft.fft2(phi0))
+        sim.set_phi(phi0)
     for r in ranks:
         r.budget_increments()
-    sim.step(nsteps)
+    sim.counters(reset=1)
+    sim.step(2)
+    sim.step(nsteps - 2)                   # two host calls for three steps
     sim.sync()
+    cnt = sim.counters()
+    assert cnt["host_calls"] == 2 and cnt["steps"] == nsteps
+    groups = {"coupled": 4, "uncoupled": 3, "qg": 2}[kind]
+    assert cnt["exchange_chunks"] == nsteps * 4 * groups * nchunks
     qhP = sim.gather_qh()
     assert qhP.shape == qh1.shape
     assert rel(qhP, qh1) < 1e-13
@@ -63,6 +71,20 @@ def test_virtual_ranks_match_single_context(kind, nranks):
     for r in ranks:                      # every rank ends up with the global increments
         inc = r.budget_increments()
         assert np.allclose(inc[:len(inc1)], inc1, rtol=1e-10, atol=1e-30), (r.rank, inc, inc1)
+    # physical rows of every rank against the single context's fields
+    assert rel(sim.gather_rows(_lib.F_Q), one.field(_lib.F_Q)) < 1e-13
+    assert rel(sim.gather_rows(_lib.F_U), one.field(_lib.F_U)) < 1e-12
+    assert rel(sim.gather_rows(_lib.F_V), one.field(_lib.F_V)) < 1e-12
+    assert rel(sim.gather_rows(_lib.F_P), one.field(_lib.F_P)) < 1e-12
+    assert abs(sim.cfl_max() - one.scalar(_lib.S_CFL)) < 1e-12 * one.scalar(_lib.S_CFL)
+    if phi0 is not None:
+        assert rel(sim.gather_rows(_lib.F_PHI), one.field(_lib.F_PHI)) < 1e-13
+        assert rel(sim.gather_rows(_lib.F_PHIX), one.field(_lib.F_PHIX)) < 1e-12
+        assert rel(sim.gather_rows(_lib.F_PHIY), one.field(_lib.F_PHIY)) < 1e-12
+        d1, dP = one.diagnostic_sums(), sim.diagnostics()
+        assert np.allclose(dP, d1, rtol=1e-10, atol=1e-13 * np.abs(d1).max()), (dP, d1)
+    if kind == "coupled":
+        assert rel(sim.gather_rows(_lib.F_QW), one.field(_lib.F_QW)) < 1e-11
 
 
 def test_virtual_ranks_against_the_oracle_with_quirk_q2():
@@ -75,14 +97,55 @@ def test_virtual_ranks_against_the_oracle_with_quirk_q2():
     for _ in range(3):
         o._step_forward()
     ranks = slab.make_ranks(model, nx, o.kk, o.ll, o.filtr, dt, nranks, budgets=False, **phys)
-    sim = slab.SlabSimulation(ranks, slab.VirtualTransport())
-    sim.set_q_spectrum(np.fft.rfft2(q0))
-    sim.set_phi_spectrum(np.fft.fft2(phi0))
+    sim = slab.SlabSimulation(ranks, "peers", nchunks=2)
+    sim.set_q(q0)
+    sim.set_phi(phi0)
     sim.step(3)
     sim.sync()
     assert rel(sim.gather_phih(), o.phih) < 1e-12
     qh = sim.gather_qh()
     assert rel(np.fft.irfft2(qh), o.q) < 1e-12
+
+
+def test_rccl_link_with_one_rank():
+    """The RCCL link end to end with the only world size a one-GPU box can host: unique id, ncclCommInitRank, the
+    grouped send/recv path (no peers: the own block crosses by a device copy), ncclAllReduce of the budget sums, the
+    exchange stream and its events.  A one-rank slab context keeps SEPARATE x-side and y-side buffers, so every exchange
+    really copies."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from conftest import free_port
+    from niwqg_amd import _lib, slab
+    nx, nsteps = 256, 3
+    model, o, dt, phys, q0, phi0 = setup_case("coupled", nx)
+    one = _lib.Context(model, nx, o.kk, o.ll, o.filtr, dt, budgets=True, **phys)
+    one.set_q(q0)
+    one.set_phi(phi0)
+    one.take_budget_increments()
+    one.step(nsteps)
+    created = not dist.is_initialized()
+    if created:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(free_port())
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        ranks = slab.make_ranks(model, nx, o.kk, o.ll, o.filtr, dt, 1, only_rank=0, budgets=True, **phys)
+        sim = slab.SlabSimulation(ranks, "rccl", dist=dist, nchunks=2)
+        sim.set_q(q0)
+        sim.set_phi(phi0)
+        ranks[0].budget_increments()
+        sim.counters(reset=2)                  # with exchange timing
+        sim.step(nsteps)
+        sim.sync()
+        cnt = sim.counters()
+        assert cnt["exchange_chunks"] == nsteps * 16 * 2 and cnt["exchange_ms"] > 0 and cnt["bytes_sent"] == 0
+        assert rel(sim.gather_qh(), one.field(_lib.F_QH)) < 1e-13
+        assert rel(sim.gather_phih(), one.field(_lib.F_PHIH)) < 1e-13
+        assert np.allclose(ranks[0].budget_increments(), one.take_budget_increments(), rtol=1e-10, atol=1e-30)
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 TWO_PROCESS_WORKER = """
@@ -98,14 +161,17 @@ from test_gpu_slab import setup_case, rel
 g = Group(backend="gloo")                      # both processes share GPU 0; the wire is host-staged gloo
 nx, nsteps = 256, 3
 model, o, dt, phys, q0, phi0 = setup_case("coupled", nx)
-ranks = slab.make_ranks(model, nx, o.kk, o.ll, o.filtr, dt, g.world, device=0, only_rank=g.rank, budgets=True, **phys)
-sim = slab.SlabSimulation(ranks, slab.TorchTransport(g.dist, stage_via_host=True))
-sim.set_q_spectrum(np.fft.rfft2(q0))
-sim.set_phi_spectrum(np.fft.fft2(phi0))
+ranks = slab.make_ranks(model, nx, o.kk, o.ll, o.filtr, dt, g.world, device=0, only_rank=g.rank, budgets=True,
+                        torch_buffers=True, **phys)
+sim = slab.SlabSimulation(ranks, "callback", dist=g.dist, stage_via_host=True)
+sim.set_q(q0)
+sim.set_phi(phi0)
 ranks[0].budget_increments()
 sim.step(nsteps)
 sim.sync()
 inc = ranks[0].budget_increments()
+dsum = sim.diagnostics()
+cfl = sim.cfl_max()
 mine = [torch.from_numpy(ranks[0].download(0)), torch.from_numpy(ranks[0].download(1))]
 parts = [None] * g.world
 g.dist.all_gather_object(parts, (g.rank, mine[0].numpy(), mine[1].numpy(), inc))
@@ -123,14 +189,18 @@ if g.rank == 0:
     inc1 = one.take_budget_increments()
     for t in parts:
         assert np.allclose(t[3], inc1, rtol=1e-10, atol=1e-30), (t[0], t[3], inc1)
+    d1 = one.diagnostic_sums()
+    assert np.allclose(dsum, d1, rtol=1e-10, atol=1e-13 * np.abs(d1).max()), (dsum, d1)
+    assert abs(cfl - one.scalar(_lib.S_CFL)) < 1e-12 * cfl
     print("two processes agree with one context")
 g.close()
 """
 
 
 def test_two_processes_one_gpu_host_staged_collectives(tmp_path):
-    """The real multi-process driver (one SlabRank per process, TorchTransport) with two processes sharing the
-    one GPU of the test box; RCCL refuses two ranks on one device, so the collectives are staged through gloo."""
+    """The real multi-process driver (one SlabRank per process, the step inside the library) with two processes sharing
+    the one GPU of the test box; RCCL refuses two ranks on one device, so the library calls back into Python at every
+    exchange and gloo carries the buffers through host memory (the "callback" link)."""
     from conftest import free_port
     port = free_port()
     import os
@@ -168,9 +238,9 @@ def test_config4_8192_on_8_virtual_ranks_against_the_oracle():
                 nu4w=kw["nu4w"], muw=kw["muw"])
     filtr = np.ones((nx, nx))
     ranks = slab.make_ranks(_lib.COUPLED, nx, big.kk, big.ll, filtr, kw["dt"], nranks, budgets=True, **phys)
-    sim = slab.SlabSimulation(ranks, slab.VirtualTransport())
-    sim.set_q_spectrum(np.fft.rfft2(q1))
-    sim.set_phi_spectrum(np.fft.fft2(phi1))
+    sim = slab.SlabSimulation(ranks, "peers", nchunks=4)
+    sim.set_q(q1)
+    sim.set_phi(phi1)
     del q1, phi1
     for r in ranks:
         r.budget_increments()
@@ -208,13 +278,14 @@ def test_bench_contract_with_two_ranks_rehearsed_over_gloo():
     env = dict(os.environ, NIWQG_AMD_DIST_BACKEND="gloo")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "256"],
+                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--nx", "256"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines                      # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["host_dispatches_per_step"] <= 1.0 and d["config"]["exchange_GB_sent_per_rank_per_step"] > 0
     assert "slab x2" in d["config"]["parallelism"]        # no silent fallback exists any more: a failed slab run exits non-zero
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])

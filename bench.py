@@ -141,7 +141,7 @@ def build_model(model, nx, device, kind=None):
     import niwqg_amd
     mod = {"coupled": niwqg_amd.CoupledModel, "uncoupled": niwqg_amd.UnCoupledModel, "qg": niwqg_amd.QGModel,
            "ybj": niwqg_amd.YBJModel}[kind or model]
-    m = mod.Model(device=device, **c3_kwargs(nx, model))
+    m = mod.Model(device=device, slab=False, **c3_kwargs(nx, model))     # one whole problem on this GPU
     q, phi = initial_fields(model, nx, m)
     m.set_q(q)
     if phi is not None:

@@ -178,7 +178,8 @@ int nq_create_slab(const nq_params* p, const double* kk, const double* ll, const
                    nq_ctx** out);
 int nq_slab_info(const nq_ctx* ctx, int* info8);
 int nq_group_buffers(nq_ctx* ctx, int group, void** x_side, void** y_side, long long* elems);
-/* local column slab of qh (which 0: (ny, local half-spectrum columns)) or phih (which 1: (ny, nx/nranks)) */
+/* local column slab of qh (which 0: (ny, local half-spectrum columns)) or phih (which 1: (ny, nx/nranks)); download also
+ * which 2: ph, 3: qwh (half-spectrum slabs like qh) */
 int nq_upload_spectral(nq_ctx* ctx, int which, const double* host);
 int nq_download_spectral(nq_ctx* ctx, int which, double* host);
 enum {
@@ -226,7 +227,8 @@ int nq_slab_set_callbacks(nq_ctx* ctx, nq_exchange_fn exchange, nq_allreduce_fn 
 int nq_slab_config(nq_ctx* ctx, int nchunks);               /* 1, 2, 4 or 8; reduced if the local rows do not divide */
 int nq_slab_step(nq_ctx* ctx, int nsteps);
 int nq_slab_put_rows(nq_ctx* ctx, int which /* 0: q, 1: phi */, const double* rows);   /* local: rows -> x side       */
-int nq_slab_commit(nq_ctx* ctx, int which);   /* collective: the rest of set_q / set_phi (rank-0 context in peers mode) */
+int nq_slab_commit(nq_ctx* ctx, int which);   /* collective: the rest of set_q / set_phi (rank-0 context in peers mode);
+                                                  which 2: Kernel._invert on the current state, nothing uploaded */
 int nq_slab_get_rows(nq_ctx* ctx, int field_id, double* rows_out);
 /* nq_diagnostics of a slab-decomposed simulation: the same 32 sums, every rank's part summed over the ranks (collective);
  * nq_slab_local_max: max|u|, max|v|, max|phi| over this rank's rows (the caller takes the max over ranks for the CFL) */

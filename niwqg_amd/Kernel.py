@@ -44,7 +44,8 @@ class Kernel(object):
     def __init__(self, nx=128, ny=None, L=5e5, dt=10000., twrite=1000., tmax=250000., use_filter=True,
                  cflmax=0.8, U=.0, f=1.e-4, N=0.01, m=0.025, g=9.81, nu4=0, nu4w=0, nu=20, nuw=50., mu=0,
                  muw=0, dealias=False, save_to_disk=False, overwrite=True, tsave_snapshots=10, tdiags=10,
-                 path='output/', use_mkl=False, nthreads=1, device=0, budgets=True, exact_qh=False):
+                 path='output/', use_mkl=False, nthreads=1, device=0, budgets=True, exact_qh=False, slab=None,
+                 nchunks=2):
         # ref: niwqg/Kernel.py:100-137 -- note ny is ignored there too (quirk Q3)
         self.nx = nx
         self.ny = nx
@@ -79,9 +80,25 @@ class Kernel(object):
         self.logger.info(self.model)
         self._initialize_grid()
         self._initialize_filter()
-        self._ctx = _lib.Context(self.model_id, nx, self.kk, self.ll, self.filtr, dt, U=U, f=f, kappa2=self.kappa2,
-                                 nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw, budgets=budgets, device=device,
-                                 dual_q=self._dual)
+        # One simulation over several GPUs: under torch.distributed.run (WORLD_SIZE > 1) the model
+        # is slab-decomposed over the ranks, every rank constructing the same Model(...); slab=P puts P peer ranks into
+        # this process on one GPU (the test double); slab=False forces a single-GPU model inside a multi-process job
+        # (ensemble members, replicas).
+        import os
+        if slab is None:
+            slab = int(os.environ.get("WORLD_SIZE", "1")) > 1
+        phys = dict(U=U, f=f, kappa2=self.kappa2, nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw)
+        if slab:
+            if self._dual:
+                raise NotImplementedError("dealias=True / exact_qh=True need the dual-copy q equation: single-rank only")
+            if self.model_id == _lib.YBJ:
+                raise NotImplementedError("YBJModel is single-rank only")
+            from .slab import SlabContext
+            self._ctx = SlabContext(self.model_id, nx, self.kk, self.ll, self.filtr, dt, peers=(slab if slab is not True else None),
+                                    nchunks=nchunks, device=(device if slab is not True else None), budgets=budgets, **phys)
+        else:
+            self._ctx = _lib.Context(self.model_id, nx, self.kk, self.ll, self.filtr, dt, budgets=budgets, device=device,
+                                     dual_q=self._dual, **phys)
         self._cache = {}
         self._user = {}
         self._initialize_time()

@@ -19,7 +19,7 @@ class Model(object):
     def __init__(self, nx=128, ny=None, L=5e5, dt=10000., twrite=1000, tswrite=10, tmax=250000.,
                  use_filter=True, U=.0, nu4=5.e9, nu=0, mu=0, beta=0, passive_scalar=False, nu4c=5.e9,
                  nuc=0, muc=0, dealias=False, save_to_disk=False, overwrite=True, tsave_snapshots=10,
-                 tdiags=10, path='output/', use_mkl=False, nthreads=1, device=0, budgets=True):
+                 tdiags=10, path='output/', use_mkl=False, nthreads=1, device=0, budgets=True, slab=None, nchunks=2):
         # ref: niwqg/QGModel.py:93-139
         self.nx = nx
         self.ny = nx
@@ -41,9 +41,20 @@ class Model(object):
         self._initialize_logger()
         self._initialize_grid()
         self._initialize_filter()
-        self._ctx = _lib.Context(_lib.QG, nx, self.kk, self.ll, self.filtr, dt, U=U, nu=nu, nu4=nu4, mu=mu,
-                                 beta=beta, budgets=budgets, device=device, passive_scalar=passive_scalar,
-                                 nu4c=nu4c, nuc=nuc, muc=muc)
+        import os
+        if slab is None:                 # under torch.distributed.run the model is slab-decomposed over the ranks (Kernel.py)
+            slab = int(os.environ.get("WORLD_SIZE", "1")) > 1
+        if slab:
+            if passive_scalar:
+                raise NotImplementedError("passive_scalar=True is single-rank only")
+            from .slab import SlabContext
+            self._ctx = SlabContext(_lib.QG, nx, self.kk, self.ll, self.filtr, dt, peers=(slab if slab is not True else None),
+                                    nchunks=nchunks, device=(device if slab is not True else None), budgets=budgets,
+                                    U=U, nu=nu, nu4=nu4, mu=mu, beta=beta)
+        else:
+            self._ctx = _lib.Context(_lib.QG, nx, self.kk, self.ll, self.filtr, dt, U=U, nu=nu, nu4=nu4, mu=mu,
+                                     beta=beta, budgets=budgets, device=device, passive_scalar=passive_scalar,
+                                     nu4c=nu4c, nuc=nuc, muc=muc)
         self._cache, self._user = {}, {}
         self.t, self.tc = 0, 0
         self.cflmax = .5

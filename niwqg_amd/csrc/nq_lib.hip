@@ -1520,9 +1520,9 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
   int S1, S2;
   if (!plan_for(p->nx, &S1, &S2)) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d unsupported (power of two in [64, 8192])", p->nx);
   if (p->model < 0 || p->model > 2) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: unknown model %d", p->model);
-  if (P < 1 || rank < 0 || rank >= P || (P & (P - 1)) || p->nx / P < 2 * CL ||
+  if (P < 1 || rank < 0 || rank >= P || (P & (P - 1)) || p->nx / P < CL ||
       (P > 1 && (p->nx / 2 + 1 + P - 1) / P >= 2048))
-    NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: %d ranks unsupported for nx=%d (power of two, at least %d columns per rank)", P, p->nx, 2 * CL);
+    NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: %d ranks unsupported for nx=%d (power of two, at least %d columns per rank)", P, p->nx, CL);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: no HIP device available");
   if (device < 0 || device >= ndev) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: device %d out of range (%d devices)", device, ndev);
@@ -2001,8 +2001,10 @@ int nq_upload_spectral(nq_ctx* c, int which, const double* host) {
 int nq_download_spectral(nq_ctx* c, int which, double* host) {
   if (!c || !host) return -1;
   HIPCHK(c, hipSetDevice(c->device));
-  if (which == 0) {
-    if (c->Wh > 0) HIPCHK(c, hipMemcpy2DAsync(host, sizeof(cd) * c->Wh, c->q.y[c->q.cur], sizeof(cd) * c->Ph, sizeof(cd) * c->Wh, c->N, hipMemcpyDeviceToHost, c->stream));
+  if (which == 0 || which == 2 || which == 3) {      // half-spectrum planes: qh, ph, qwh
+    if (which == 3 && c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qwh exists only in the coupled model");
+    const cd* src = which == 0 ? c->q.y[c->q.cur] : (which == 2 ? c->ph : c->qwh);
+    if (c->Wh > 0) HIPCHK(c, hipMemcpy2DAsync(host, sizeof(cd) * c->Wh, src, sizeof(cd) * c->Ph, sizeof(cd) * c->Wh, c->N, hipMemcpyDeviceToHost, c->stream));
   } else if (which == 1) {
     if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
     HIPCHK(c, hipMemcpyAsync(host, c->w.y[c->w.cur], sizeof(cd) * (size_t)c->N * c->Wf, hipMemcpyDeviceToHost, c->stream));
@@ -2213,6 +2215,18 @@ int nq_slab_commit(nq_ctx* c, int which) {
     SLABTRY(exchange_now(grp, 1, false));
     if (c0->bud) SLABTRY(slab_allreduce(grp, 1));
     for (nq_ctx* x : grp) SLABTRY(nq_refresh_grad_phi(x));
+  } else if (which == 2) {                      // Kernel._invert on the current state (CoupledModel.py:75-97 / UnCoupledModel.py:54-64)
+    if (c0->p.model == NQ_MODEL_COUPLED) {
+      for (nq_ctx* x : grp) phase_wavepv(x);
+      SLABTRY(exchange_now(grp, 2, true));
+    }
+    for (nq_ctx* x : grp) {
+      phase_invert_y(x, x->q.y[x->q.cur], true, x->part0Q, nullptr);
+      if (x->bud && x->kernel_family)
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->part0Q, x->nwq, 3, 3, x->carryQ);
+    }
+    SLABTRY(exchange_now(grp, 3, false));
+    if (c0->bud && c0->kernel_family) SLABTRY(slab_allreduce(grp, 2));
   } else NQ_FAIL(c, -1, "nq_slab_commit: which = %d", which);
   SLABTRY(slab_settle(grp));
   for (nq_ctx* x : grp) {
@@ -2268,7 +2282,6 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
   const int N = c0->N, NB = 1024;
   const double M = (double)N * N;
   const bool waves = c0->kernel_family, coupled = c0->p.model == NQ_MODEL_COUPLED;
-  if (waves && !c0->have_phi) NQ_FAIL(c, -4, "nq_slab_diagnostics: set_phi has not been called");
   for (nq_ctx* x : grp) {
     HIPCHK(x, hipSetDevice(x->device));
     const int nxb = xdiag_blocks(x), nww = (x->Wf / CL) * x->S2;

@@ -59,7 +59,7 @@ def config5_member(j, nx=1024, device=0, **overrides):
     Te = 1.0 / (U0 * k0)
     kw = dict(L=L, nx=nx, tmax=1e30, dt=0.025 * Te * 128 / nx, m=2 * np.pi / 280.0, N=0.01, f=1e-4, twrite=10 ** 9,
               tdiags=10 ** 9, nu4=5e11 * (128.0 / nx) ** 4, nu4w=0.0, nu=20, nuw=50.0, mu=0.0, muw=0.0,
-              use_filter=True, U=-U0, device=device)
+              use_filter=True, U=-U0, device=device, slab=False)      # members never share a simulation
     kw.update(overrides)
     m = UnCoupledModel.Model(**kw)
     m.set_q(1e-5 * np.random.default_rng(j).standard_normal((nx, nx)))

@@ -89,7 +89,7 @@ class SlabRank(object):
         self._chk(self.L.nq_upload_spectral(self.h, which, _lib._dptr(arr.view(np.float64))), "nq_upload_spectral")
 
     def download(self, which):
-        w = self.wh if which == 0 else self.wf
+        w = self.wf if which == 1 else self.wh          # 0: qh, 2: ph, 3: qwh (half-spectrum slabs); 1: phih
         out = np.empty((self.nx, w), np.complex128)
         self._chk(self.L.nq_download_spectral(self.h, which, _lib._dptr(out.view(np.float64))), "nq_download_spectral")
         return out
@@ -304,6 +304,14 @@ class SlabSimulation(object):
     def gather_rows(self, fid):
         return self._gather([r.get_rows(fid) for r in self.ranks], 0)
 
+    def invert(self):
+        """Kernel._invert on the current state"""
+        self._lead_chk(self.L.nq_slab_commit(self.lead.h, 2), "nq_slab_commit(invert)")
+
+    def gather_spectral(self, which):
+        """0: qh, 1: phih, 2: ph, 3: qwh -- the column slabs of all ranks side by side"""
+        return self._gather([r.download(which) for r in self.ranks], 1)
+
     def gather_qh(self):
         return self._gather([r.download(0) for r in self.ranks], 1)
 
@@ -316,3 +324,113 @@ def make_ranks(model, nx, kk, ll, filtr, dt, nranks, device=0, only_rank=None, b
     which = range(nranks) if only_rank is None else [only_rank]
     return [SlabRank(model, nx, kk, ll, filtr, dt, nranks, r, device, budgets=budgets, torch_buffers=torch_buffers, **phys)
             for r in which]
+
+
+class SlabContext(object):
+    """What the model classes (niwqg_amd.Kernel / QGModel) need from a device context, on top of a slab-decomposed
+    simulation: the same methods as ``_lib.Context``, fields gathered over the ranks on demand.  ``peers`` = P puts all P
+    ranks into this process on one GPU (tests); otherwise one rank per process, launched with torch.distributed.run."""
+
+    def __init__(self, model, nx, kk, ll, filtr, dt, peers=None, nchunks=2, device=None, budgets=True, **phys):
+        self.model, self.nx = model, int(nx)
+        self.budgets_enabled = bool(budgets)
+        self.kappa2 = phys.get("kappa2", 1.0)
+        if peers:
+            ranks = make_ranks(model, nx, kk, ll, filtr, dt, int(peers), device=device or 0, budgets=budgets, **phys)
+            self.sim = SlabSimulation(ranks, "peers", nchunks=nchunks)
+            self.group = None
+        else:
+            from .distributed import Group
+            g = self.group = Group()
+            if g.dist is None:
+                raise RuntimeError("slab model: no process group -- launch with torch.distributed.run (WORLD_SIZE > 1) or pass slab=P")
+            gloo = getattr(g, "backend", "") == "gloo"
+            import torch
+            dev = g.local_rank % max(torch.cuda.device_count(), 1) if device is None else device
+            ranks = make_ranks(model, nx, kk, ll, filtr, dt, g.world, device=dev, only_rank=g.rank, budgets=budgets,
+                               torch_buffers=gloo, **phys)
+            self.sim = SlabSimulation(ranks, "callback" if gloo else "rccl", dist=g.dist, nchunks=nchunks, stage_via_host=gloo)
+        self._ds = None
+
+    # --- state
+    def _touch(self):
+        self._ds = None
+
+    def set_q(self, q):
+        self.sim.set_q(np.asarray(q, np.float64))
+        self._touch()
+
+    def set_phi(self, phi):
+        self.sim.set_phi(np.asarray(phi, np.complex128))
+        self._touch()
+
+    def set_c(self, c):
+        raise NotImplementedError("the passive scalar is single-rank only")
+
+    def invert(self):
+        self.sim.invert()
+        self._touch()
+
+    def refresh_grad_phi(self):
+        self.sim.refresh_grad_phi()
+
+    def step(self, n=1):
+        self.sim.step(n)
+        self._touch()
+
+    def sync(self):
+        self.sim.sync()
+
+    def take_budget_increments(self):
+        incs = [r.budget_increments() for r in self.sim.ranks]       # identical on every rank; reading resets each
+        return tuple(incs[0])
+
+    # --- reads
+    def field(self, fid):
+        L = _lib
+        if fid in _REAL_ROWS or fid in _CPLX_ROWS:
+            return self.sim.gather_rows(fid)
+        if fid == L.F_QPSI:
+            q = self.sim.gather_rows(L.F_Q)
+            return q - self.sim.gather_rows(L.F_QW) if self.model == L.COUPLED else q
+        which = {L.F_QH: 0, L.F_PHIH: 1, L.F_PH: 2, L.F_QWH: 3}.get(fid)
+        if which is None:
+            raise RuntimeError("field %d is not available on a slab-decomposed model" % fid)
+        return self.sim.gather_spectral(which)
+
+    def diagnostic_sums(self):
+        if self._ds is None:
+            self._ds = self.sim.diagnostics()
+        return self._ds
+
+    def scalar(self, sid):
+        L = _lib
+        M2 = float(self.nx) ** 4
+        if sid in (L.S_KE, L.S_PW, L.S_KW):
+            out = None
+            for r in self.sim.ranks:                                    # read (and reset) on every local rank
+                v = ctypes.c_double()
+                r._chk(r.L.nq_get_scalar(r.h, sid, ctypes.byref(v)), "nq_get_scalar(%d)" % sid)
+                out = v.value if out is None else out
+            return out
+        if sid == L.S_CFL:
+            return self.sim.cfl_max()
+        ds = self.diagnostic_sums()
+        if sid == L.S_KE_QG:
+            return 0.5 * ds[11] / M2
+        if sid == L.S_KE_NIW:
+            return 0.5 * ds[0] / M2
+        if sid == L.S_PE_NIW:
+            return 0.25 * ds[1] / M2 / self.kappa2
+        raise RuntimeError("scalar %d is not available on a slab-decomposed model" % sid)
+
+    def _single_rank_only(self, *a, **k):
+        raise NotImplementedError("this call needs the whole plane on one device: not available on a slab-decomposed model "
+                                  "(use a single-GPU model of the same parameters)")
+
+    fft2 = ifft2 = rfft2 = irfft2 = coeff = _single_rank_only
+    jacobian_psi_q = jacobian_psi_phi = jacobian_phic_phi = products_uq_vq = refraction = _single_rank_only
+
+    def close(self):
+        for r in self.sim.ranks:
+            r.close()

@@ -1,0 +1,168 @@
+"""The reference's class API on a slab-decomposed simulation: ``Model(..., slab=P)`` runs ONE simulation on P peer ranks
+(all on the one GPU of the test box; under torch.distributed.run the same classes take one rank per process), with the
+constructor / set_q / set_phi / run() surface of niwqg.Kernel (ref: niwqg/Kernel.py:70-98, :183-203, :520-551), the status
+line and CFL of :568-598 / :660-662 reduced over the ranks, the diagnostics tick of Diagnostics.py:41-58 from per-rank
+partial sums, and m.q / m.phi / m.qh gathered on demand.  Expected values: the reference's own goldens and logged lines."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from test_oracle_golden import notebook_kwargs, rel, L, K0, U0, TE, F0, NB, MZ
+from test_gpu_models import rel_no_passenger, steps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_notebook_run_through_the_model_api_on_slabs(golden, P):
+    """examples/LambDipole_CoupledModel.ipynb: the 33 logged status lines (g5) and the diagnostics series (g6) of the
+    reference, through CoupledModel.Model(...).run() on P ranks."""
+    import niwqg_amd
+    from niwqg_amd import InitialConditions as ic
+    g = golden("g6_notebook_diags.npz")
+    dt = 0.025 * TE
+    m = niwqg_amd.CoupledModel.Model(L=L, nx=128, tmax=10 * TE, dt=dt, m=MZ, N=NB, f=F0,
+                                     twrite=int((2 * np.pi / F0) / dt), nu4=5e11, nu4w=0e10, nu=20, nuw=50e0,
+                                     mu=0.e-7, muw=0e-7, use_filter=False, U=-U0, tdiags=1,
+                                     save_to_disk=False, dealias=False, slab=P, nchunks=2)
+    lines = []
+
+    class Grab(object):
+        def info(self, fmt, *a):
+            lines.append("INFO: " + fmt % a)
+
+        def error(self, *a):
+            return "error"
+
+    m.logger = Grab()
+    m.set_q(ic.LambDipole(m, U=U0, R=2 * np.pi / K0))
+    m.set_phi((np.ones((128, 128)) + 1j) * (2 * U0) / np.sqrt(2))
+    m.run()
+    logged = open(os.path.join(os.path.dirname(__file__), "golden", "g5_notebook_cell9_log.txt")).read()
+    logged = [re.sub(r"\s+$", "", s) for s in logged.splitlines() if s.strip()]
+    assert lines == logged
+    for name in ("time", "Ke", "Pw", "Kw", "ke_qg", "ke_niw", "pe_niw", "gamma_r", "gamma_a", "xi_r", "xi_a",
+                 "ep_psi", "chi_phi", "ep_phi", "pi", "ens", "ke_qg_q", "ke_qg_w", "ke_qg_qw", "chi_q"):
+        assert np.allclose(m.diagnostics[name]['value'], g[name], rtol=1e-8, atol=1e-22), name
+    assert rel(m.q, g["final_q"]) < 1e-11 and rel(m.phi, g["final_phi"]) < 1e-11
+
+
+@pytest.mark.parametrize("use_filter", [False, True])
+@pytest.mark.parametrize("nx,P", [(64, 2), (128, 2), (128, 4)])
+def test_coupled_goldens_through_the_model_api_on_slabs(golden, nx, P, use_filter):
+    import niwqg_amd
+    g = golden("g2_coupled_%d_%s.npz" % (nx, "filter" if use_filter else "nofilter"))
+    m = niwqg_amd.CoupledModel.Model(slab=P, **notebook_kwargs(nx, use_filter))
+    m.set_q(g["q0"])
+    m.set_phi(g["phi0"])
+    for n in g["snaps"]:
+        m.tmax = (int(n) - 0.5) * m.dt
+        m.run()
+        assert m.tc == n
+        assert rel(m.q, g["q_%d" % n]) < 1e-12
+        assert rel(m.phi, g["phi_%d" % n]) < 1e-12
+        if "phih_%d" % n in g.files:
+            assert rel(m.phih, g["phih_%d" % n]) < 1e-12
+            assert rel(m.ph, g["ph_%d" % n]) < 1e-12
+            assert rel_no_passenger(m.qh, g["qh_%d" % n]) < 1e-12
+        assert np.allclose([m.Ke, m.Pw, m.Kw], g["budgets_%d" % n], rtol=1e-9)
+
+
+def test_quirks_q1_q2_through_the_model_api_on_slabs(golden):
+    """g4: UnCoupledModel's stale phix / phiy (tdiags 1 vs inf) and the set_q / set_phi order dependence, on 2 ranks."""
+    import niwqg_amd
+    g = golden("g4_quirks_64.npz")
+    res = {}
+    for tag, td in (("td1", 1), ("tdinf", 10 ** 9)):
+        m = niwqg_amd.UnCoupledModel.Model(slab=2, **notebook_kwargs(64, True, tdiags=td))
+        m.set_q(g["unc_q0"])
+        m.set_phi(g["unc_phi0"])
+        m.tmax = 19.5 * m.dt
+        m.run()
+        assert m.tc == 20
+        assert rel(m.phi, g["unc_phi_" + tag]) < 1e-12
+        assert rel(m.q, g["unc_q_" + tag]) < 1e-12
+        assert np.allclose([m.Ke, m.Pw, m.Kw], g["unc_budgets_" + tag], rtol=1e-9)
+        res[tag] = m.phi
+    assert rel(res["td1"], res["tdinf"]) > 1e-3
+    for tag in ("q_then_phi", "phi_then_q"):
+        m = niwqg_amd.CoupledModel.Model(slab=2, **notebook_kwargs(64, True))
+        if tag == "q_then_phi":
+            m.set_q(g["order_q0"]); m.set_phi(g["order_phi0"])
+        else:
+            m.set_phi(g["order_phi0"]); m.set_q(g["order_q0"])
+        assert rel(m.ph, g["order_ph0_" + tag]) < 1e-13
+        steps(m, 1)
+        assert rel(m.q, g["order_q_" + tag]) < 1e-13
+        assert rel(m.phi, g["order_phi_" + tag]) < 1e-12
+
+
+def test_qgmodel_golden_through_the_model_api_on_slabs(golden):
+    import niwqg_amd
+    g = golden("g3_qg_256.npz")
+    m = niwqg_amd.QGModel.Model(L=L, nx=256, tmax=1e30, dt=float(g["dt"]), twrite=10 ** 9, nu4=7.5e8, use_filter=False,
+                                U=-U0, tdiags=10 ** 9, beta=0.0, slab=4)
+    m.set_q(g["q0"])
+    n = int(g["snaps"][-1])
+    m.tmax = (n - 0.5) * m.dt
+    m.run()
+    assert m.tc == n
+    assert rel(m.q, g["q_%d" % n]) < 1e-11 and rel(m.qh, g["qh_%d" % n]) < 1e-11
+    assert abs(m.Ke - float(g["Ke_%d" % n])) < 1e-9 * abs(float(g["Ke_%d" % n]))
+
+
+def test_whole_plane_calls_fail_loudly_on_slabs():
+    import niwqg_amd
+    m = niwqg_amd.CoupledModel.Model(slab=2, **notebook_kwargs(128, True))
+    with pytest.raises(NotImplementedError):
+        m.fft(np.zeros((128, 128), complex))
+    with pytest.raises(NotImplementedError):
+        m.jacobian_psi_q()
+    with pytest.raises(NotImplementedError):
+        niwqg_amd.CoupledModel.Model(slab=2, dealias=True, use_filter=False, nx=128)
+
+
+MODEL_WORKER = """
+import sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import numpy as np
+import niwqg_amd
+from test_oracle_golden import notebook_kwargs, rel
+
+g = np.load(%r, allow_pickle=False)
+m = niwqg_amd.CoupledModel.Model(**notebook_kwargs(128, True))        # WORLD_SIZE = 2: slab-decomposed by itself
+assert type(m._ctx).__name__ == "SlabContext" and m._ctx.sim.nranks == 2
+m.set_q(g["q0"])
+m.set_phi(g["phi0"])
+m.tmax = 99.5 * m.dt
+m.run()
+assert m.tc == 100
+eq, ep = rel(m.q, g["q_100"]), rel(m.phi, g["phi_100"])
+assert eq < 1e-12 and ep < 1e-12, (eq, ep)
+assert np.allclose([m.Ke, m.Pw, m.Kw], g["budgets_100"], rtol=1e-9)
+assert abs(m._calc_cfl() - float(np.max([np.abs(m.u).max(), np.abs(m.v).max(), np.abs(m.phi).max()])) * m.dt / m.dx) < 1e-12
+if m._ctx.group.rank == 0:
+    print("two-process model agrees with the reference golden")
+m._ctx.group.close()
+"""
+
+
+def test_model_api_in_two_processes_over_gloo(tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 script.py` where the script just builds CoupledModel.Model(...) and calls
+    run(): every rank executes the reference's API, the model is slab-decomposed over the two processes (both on the one
+    GPU of the test box, callbacks + gloo for the wire), and the 100-step golden of the reference is reproduced."""
+    import subprocess
+    import sys
+    from conftest import free_port, GOLDEN
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "model_worker.py"
+    script.write_text(MODEL_WORKER % (root, os.path.join(root, "tests"), os.path.join(GOLDEN, "g2_coupled_128_filter.npz")))
+    env = dict(os.environ, NIWQG_AMD_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "two-process model agrees with the reference golden" in out.stdout

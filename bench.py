@@ -180,18 +180,15 @@ def build_slab(model, nx, grp, local_rank, nchunks=2):
         kappa2 = (kw["m"] * kw["f"] / kw["N"]) ** 2
         phys.update(f=kw["f"], kappa2=kappa2, nuw=kw["nuw"], nu4w=kw["nu4w"], muw=kw["muw"])
 
-    gloo = getattr(grp, "backend", "") == "gloo"      # rehearsal: several ranks share one GPU, host-staged wire
-
     def allocate():
         ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], grp.world, device=local_rank, only_rank=grp.rank,
-                                budgets=True, torch_buffers=gloo, **phys)
+                                budgets=True, torch_buffers=True, **phys)
         return ranks
 
     def initialise(ranks):
         # RCCL issued by the library itself (grouped send/recv per row chunk); with gloo the library calls back into
         # Python at every exchange
-        sim = slab.SlabSimulation(ranks, "callback" if gloo else "rccl", dist=grp.dist, nchunks=nchunks,
-                                  stage_via_host=gloo)
+        sim = slab.connect(ranks, grp.dist, nchunks)
 
         nloc, r0 = ranks[0].nloc, ranks[0].rank * ranks[0].nloc
         cell = (np.arange(nx) + 0.5) / nx * L

@@ -115,6 +115,13 @@ int nq_get_field(nq_ctx* ctx, int field_id, double* host_out);
 long long nq_field_doubles(const nq_ctx* ctx, int field_id);
 int nq_get_scalar(nq_ctx* ctx, int scalar_id, double* out);
 
+/* Snapshots that do not stall the stepper (niwqg/Saving.py:59-86 saves t, q, phi every tsave_snapshots steps):
+ * nq_snapshot_begin forms q (real (ny,nx)) and, with_phi != 0, phi (cplx (ny,nx)) of the CURRENT state in device buffers of
+ * their own and starts their copy to pinned host memory on a second stream; further nq_step calls may be queued at once.
+ * nq_snapshot_end waits for that copy only and writes the arrays to q_out / phi_out (either may be NULL).  One in flight. */
+int nq_snapshot_begin(nq_ctx* ctx, int with_phi);
+int nq_snapshot_end(nq_ctx* ctx, double* q_out, double* phi_out);
+
 /* the FFT seam, Kernel.fft / Kernel.ifft (Kernel.py:562-566): complex (ny,nx) -> complex (ny,nx);
  * QGModel.fft / ifft (QGModel.py:551-552): real (ny,nx) <-> complex (ny,nx/2+1).                     */
 int nq_fft2(nq_ctx* ctx, const double* in_cplx, double* out_cplx);
@@ -155,7 +162,10 @@ int nq_refraction(nq_ctx* ctx, double* out_cplx);
  *            ups = |phi|^2 - mean|phi|^2     (conc_niw, skew, pi; Kernel.py:613-623, :701)
  *   [24..27] sum {Re, Im}(conj(lap_h) J), {Re, Im}(conj(diss_h) J),  J = F[u phix + v phiy]        (gamma2, xi1)
  *   [28..31] the same four with i F[phi q_psi] in place of J                                        (gamma1, xi2)
- * Sums over the half spectrum carry weight 2 on the interior columns.  QGModel: entries [6..15] only.          */
+ * Sums over the half spectrum carry weight 2 on the interior columns.  QGModel: entries [6..15] only; with its passive
+ * scalar also [16..19] sum w wv2^n |ch|^2, n = 0..3 (n = 0 without [0,0]; C2, gradC2, ep_c, chi_c of QGModel.py:595-604,
+ * :724-726) and [20] sum w Re(conj(-wv2 ch)(ik F[u c] + il F[v c])) (Gamma_c, QGModel.py:727-731; u, v of the state at
+ * which the last step evaluated its fourth stage, as the reference's are at a tick).                          */
 int nq_diagnostics(nq_ctx* ctx, double* out32);
 
 /* copy of one ETDRK4 coefficient plane (0:E 1:Eh 2:Q 3:f0 4:fab 5:fc) of equation eq (0:q 1:phi),

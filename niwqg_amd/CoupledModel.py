@@ -25,6 +25,20 @@ class Model(Kernel.Kernel):
         self._cache.pop("phiy", None)
         return self._ctx.jacobian_phic_phi()
 
+    # Fields the reference leaves behind after a diagnostics tick (CoupledModel.py:105-112): formed on demand from the
+    # gathered spectra with the device FFT seam, never inside the tick (whose scalars come from the device sums).
+    _TICK_FIELDS = ("phq", "phw", "uq", "vq", "uw", "vw")
+
+    def __getattr__(self, name):
+        if name in Model._TICK_FIELDS:
+            if name == "phq":
+                return -self.wv2i * self.qh
+            if name == "phw":
+                return self.wv2i * self.qwh
+            ph = self.phq if name[1] == "q" else self.phw
+            return self.ifft((-self.il if name[0] == "u" else self.ik) * ph).real
+        return super(Model, self).__getattr__(name)
+
     def _calc_ke_qg_decomp(self):
         """ref: niwqg/CoupledModel.py:99-113 from the half-spectrum sums of the device tick (Parseval)"""
         s = self._dsums()

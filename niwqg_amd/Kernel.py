@@ -12,6 +12,7 @@ from numpy import pi
 
 from . import _lib
 from .Diagnostics import add_diagnostic, increment_diagnostics
+from .Saving import (initialize_save_snapshots, save_setup, save_snapshots, save_diagnostics, flush_snapshots)
 
 _DEVICE_FIELDS = {"q": _lib.F_Q, "p": _lib.F_P, "phi": _lib.F_PHI, "phih": _lib.F_PHIH, "u": _lib.F_U,
                   "v": _lib.F_V, "phix": _lib.F_PHIX, "phiy": _lib.F_PHIY}
@@ -69,8 +70,6 @@ class Kernel(object):
         self.path = path
         self.use_filter = use_filter
         self.use_mkl, self.nthreads = use_mkl, nthreads
-        if save_to_disk:
-            raise NotImplementedError("save_to_disk: HDF5 output is outside the accelerated path (SURVEY 8f)")
         # The reference's 2/3 mask (Kernel.py:277-281) is not mirror-symmetric, so its q-hat is not Hermitian:
         # the device then keeps a second half-spectrum copy ("dual copy").  exact_qh=True asks for
         # the same with symmetric filters, which reproduces the reference's qh on the Nyquist row as well.
@@ -102,6 +101,9 @@ class Kernel(object):
         self._cache = {}
         self._user = {}
         self._initialize_time()
+        # ref: niwqg/Kernel.py:145-148 (set-up file, snapshot directory); raises if no writer exists (Saving.py)
+        initialize_save_snapshots(self, self.path)
+        save_setup(self)
         self._initialize_diagnostics()
         self.Ke = self.ke = 0.0
         self.Pw = self.Kw = 0.0
@@ -272,10 +274,11 @@ class Kernel(object):
             self.Kw += dKw
 
     def _step_forward(self):
-        """ref: niwqg/Kernel.py:205-217 (snapshots are out of scope)"""
+        """ref: niwqg/Kernel.py:205-217"""
         self._step_etdrk4()
         increment_diagnostics(self)
         self._print_status()
+        save_snapshots(self, fields=['t', 'q', 'phi'])
 
     def _quiet_steps(self, n_left):
         """How many of the next ``n_left`` steps need no host attention before the first one that
@@ -284,6 +287,8 @@ class Kernel(object):
         for j in range(n_left):
             tcb = self.tc + j
             if (tcb % self.tdiags) == 0 or ((tcb + 1) % self.twrite) == 0:
+                return j
+            if self.save_to_disk and ((tcb + 1) % self.tsnaps) == 0:      # a snapshot after this step (Saving.py:70)
                 return j
         return n_left - 1
 
@@ -298,15 +303,21 @@ class Kernel(object):
     def run(self):
         """ref: niwqg/Kernel.py:183-203.  Steps between host-visible events are batched into one
         nq_step call; the sequence of diagnostics ticks and status lines is the reference's."""
+        if self.save_to_disk:                     # the initial condition (Kernel.py:194-195)
+            save_snapshots(self, fields=['t', 'q', 'phi'])
         while self.t < self.tmax:
             quiet = self._quiet_steps(self._steps_left(4096))
             if quiet > 0:
-                self._ctx.step(quiet)
+                self._ctx.step(quiet)             # asynchronous: a pending snapshot is written while these steps run
+                flush_snapshots(self)
                 for _ in range(quiet):
                     self.tc += 1
                     self.t += self.dt
                 self._after_steps()
             self._step_forward()
+        flush_snapshots(self)
+        if self.save_to_disk:                     # Kernel.py:202-203
+            save_diagnostics(self)
 
     def run_with_snapshots(self, tsnapstart=0., tsnapint=432000.):
         """ref: niwqg/Kernel.py:161-181"""

@@ -12,6 +12,7 @@ from numpy import pi
 
 from . import _lib
 from .Diagnostics import add_diagnostic, increment_diagnostics
+from .Saving import (initialize_save_snapshots, save_setup, save_snapshots, save_diagnostics, flush_snapshots)
 
 
 class Model(object):
@@ -33,8 +34,6 @@ class Model(object):
         self.save_to_disk, self.overwrite, self.tsnaps, self.path = save_to_disk, overwrite, tsave_snapshots, path
         self.use_filter = use_filter
         self.use_mkl, self.nthreads = use_mkl, nthreads
-        if save_to_disk:
-            raise NotImplementedError("save_to_disk: HDF5 output is outside the accelerated path (SURVEY 8f)")
         if dealias and not use_filter:
             raise TypeError("dealias=True: the reference itself fails here (float slice indices, "
                             "niwqg/QGModel.py:295-296)")
@@ -57,6 +56,8 @@ class Model(object):
                                      nu4c=nu4c, nuc=nuc, muc=muc)
         self._cache, self._user = {}, {}
         self.t, self.tc = 0, 0
+        initialize_save_snapshots(self, self.path)      # ref: niwqg/QGModel.py:133-134; raises if no writer exists
+        save_setup(self)
         self.cflmax = .5
         self.Ke = 0.0
         self._initialize_diagnostics()
@@ -98,6 +99,8 @@ class Model(object):
             d["wv2i"] = np.zeros_like(d["wv2"])
             d["wv2i"][nz] = d["wv2"][nz] ** -1
             return d[name]
+        if name == "lapc" and self.__dict__.get("passive_scalar"):      # the array the reference leaves behind after a tick
+            return self.ifft(-self.wv2 * self.ch)
         fields = {"q": _lib.F_Q, "qh": _lib.F_QH, "p": _lib.F_P, "ph": _lib.F_PH, "u": _lib.F_U, "v": _lib.F_V}
         if self.__dict__.get("passive_scalar"):
             fields.update(c=_lib.F_C, ch=_lib.F_CH)
@@ -196,15 +199,22 @@ class Model(object):
             if self.passive_scalar:
                 self.cvar += self._ctx.scalar(_lib.S_PW)        # ref: niwqg/QGModel.py:394
 
+    def _snapshot_fields(self):
+        """the reference always asks for 't', 'q', 'c' (niwqg/QGModel.py:221); c exists only with the passive scalar"""
+        return ['t', 'q', 'c'] if self.passive_scalar else ['t', 'q']
+
     def _step_forward(self):
         self._step_etdrk4()
         increment_diagnostics(self)
         self._print_status()
+        save_snapshots(self, fields=self._snapshot_fields())
 
     def _quiet_steps(self, n_left):
         for j in range(n_left):
             tcb = self.tc + j
             if (tcb % self.tdiags) == 0 or ((tcb + 1) % self.twrite) == 0:
+                return j
+            if self.save_to_disk and ((tcb + 1) % self.tsnaps) == 0:
                 return j
         return n_left - 1
 
@@ -217,15 +227,21 @@ class Model(object):
 
     def run(self):
         """ref: niwqg/QGModel.py:184-207"""
+        if self.save_to_disk:
+            save_snapshots(self, fields=self._snapshot_fields())
         while self.t < self.tmax:
             quiet = self._quiet_steps(self._steps_left(4096))
             if quiet > 0:
                 self._ctx.step(quiet)
+                flush_snapshots(self)
                 for _ in range(quiet):
                     self.tc += 1
                     self.t += self.dt
                 self._after_steps()
             self._step_forward()
+        flush_snapshots(self)
+        if self.save_to_disk:
+            save_diagnostics(self)
 
     def run_with_snapshots(self, tsnapstart=0., tsnapint=432000.):
         tsnapints = np.ceil(tsnapint / self.dt)
@@ -272,24 +288,28 @@ class Model(object):
     def _calc_cfl(self):
         return self._ctx.scalar(_lib.S_CFL) * self.dt / self.dx      # max reduction on the device
 
+    # The passive scalar's tick entries come from five more device sums (nq_diagnostics [16..20]): nothing of c is
+    # downloaded at a tick.  M2 = (nx ny)^2; mean(lap c ^2) = s[18]/M2, mean(lap^2 c lap c) = -s[19]/M2 by Parseval.
     def _calc_ep_c(self):
         """ref: niwqg/QGModel.py:595-598 (nu, not nuc, multiplies gradC2 there)"""
-        return -2 * self.nu4c * (self.lapc ** 2).mean() - 2 * self.nu * self.gradC2 - 2 * self.muc * self.C2
+        if not self.passive_scalar:
+            return -2 * self.nu4c * 0. - 2 * self.nu * self.gradC2 - 2 * self.muc * self.C2
+        return -2 * self.nu4c * self._dsums()[18] / float(self.M) ** 2 - 2 * self.nu * self.gradC2 - 2 * self.muc * self.C2
 
     def _calc_chi_c(self):
         """ref: niwqg/QGModel.py:600-604"""
         if not self.passive_scalar:
             return 0.0
-        lap2c = self.ifft(self.wv4 * self.ch)
-        return (2 * self.nu4c * (lap2c * self.lapc).mean() - 2 * self.nu * (self.lapc ** 2).mean()
-                - 2 * self.muc * self.gradC2)
+        s, M2 = self._dsums(), float(self.M) ** 2
+        return -2 * self.nu4c * s[19] / M2 - 2 * self.nu * s[18] / M2 - 2 * self.muc * self.gradC2
 
     def _initialize_diagnostics(self):
         """ref: niwqg/QGModel.py:632-722 (the passive-scalar entries report zeros, as the reference
         does when passive_scalar=False, QGModel.py:734-737)"""
         self.diagnostics = dict()
         self.C2, self.gradC2, self.cvar, self.Gamma_c = 0., 0., 0., 0.
-        self.lapc = np.array([0.])
+        if not self.passive_scalar:
+            self.lapc = np.array([0.])
         table = [
             ('time', 'Time', 'seconds', lambda s: s.t),
             ('ke_qg', 'Quasigeostrophic Kinetic Energy', r'm^2 s^{-2}', lambda s: s._calc_ke_qg()),
@@ -310,12 +330,13 @@ class Model(object):
             add_diagnostic(self, name, description=desc, units=units, types='scalar', function=fn)
 
     def _calc_derived_fields(self):
-        """ref: niwqg/QGModel.py:724-737 (diagnostics ticks; host arithmetic on the downloaded scalar spectrum)"""
+        """ref: niwqg/QGModel.py:724-737 from the device sums (Parseval); ``lapc`` is left as an on-demand attribute"""
         if self.passive_scalar:
-            self.C2 = self.spec_var(self.ch)
-            self.gradC2 = self.spec_var(self.wv * self.ch)
-            self.lapc = self.ifft(-self.wv2 * self.ch)
-            self.Gamma_c = 2 * (self.lapc * self.ifft(self.jacobian_psi_c())).mean()
+            s, M2 = self._dsums(), float(self.M) ** 2
+            self.C2 = s[16] / M2
+            self.gradC2 = s[17] / M2
+            self.Gamma_c = 2 * s[20] / M2
+            self.__dict__.pop("lapc", None)
         else:
             self.C2, self.gradC2, self.cvar, self.Gamma_c = 0., 0., 0., 0.
             self.lapc = np.array([0.])

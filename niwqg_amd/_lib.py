@@ -32,7 +32,7 @@ EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "
            "nq_reduce_buffer", "nq_reduce_read", "nq_reduce_write", "nq_device_bytes", "nq_stream",
            "nq_comm_unique_id", "nq_comm_init", "nq_slab_attach_peers", "nq_slab_set_callbacks", "nq_slab_config",
            "nq_slab_step", "nq_slab_put_rows", "nq_slab_commit", "nq_slab_get_rows", "nq_slab_diagnostics",
-           "nq_slab_local_max", "nq_slab_counters"]
+           "nq_slab_local_max", "nq_slab_counters", "nq_snapshot_begin", "nq_snapshot_end"]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
@@ -128,6 +128,8 @@ def lib():
     L.nq_slab_diagnostics.argtypes = [vp, dp]
     L.nq_slab_local_max.argtypes = [vp, dp]
     L.nq_slab_counters.argtypes = [vp, dp, ctypes.c_int]
+    L.nq_snapshot_begin.argtypes = [vp, ctypes.c_int]
+    L.nq_snapshot_end.argtypes = [vp, dp, dp]
     L.nq_device_bytes.argtypes = [vp]
     L.nq_device_bytes.restype = ctypes.c_longlong
     L.nq_stream.argtypes = [vp]
@@ -251,6 +253,17 @@ class Context:
         out = np.empty((n, w), np.complex128)
         self._chk(self.L.nq_get_coeff(self.h, eq, which, _dptr(out.view(np.float64))), "nq_get_coeff")
         return out
+
+    # --- snapshots (niwqg_amd/Saving.py)
+    def snapshot_begin(self, with_phi=True):
+        self._chk(self.L.nq_snapshot_begin(self.h, int(bool(with_phi))), "nq_snapshot_begin")
+
+    def snapshot_end(self, with_phi=True):
+        n = self.nx
+        q = np.empty((n, n), np.float64)
+        phi = np.empty((n, n), np.complex128) if with_phi else None
+        self._chk(self.L.nq_snapshot_end(self.h, _dptr(q), _dptr(phi.view(np.float64)) if with_phi else None), "nq_snapshot_end")
+        return q, phi
 
     # --- FFT seam
     def _xf(self, fn, a, in_dtype, out_shape, out_dtype):

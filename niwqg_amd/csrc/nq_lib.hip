@@ -106,7 +106,15 @@ struct nq_ctx {
   std::vector<hipEvent_t> prof_ev;               // pairs
   std::vector<int> prof_cls;                     // kernel class of each pair
   size_t prof_used = 0;
-  bool have_q = false, have_phi = false;
+  bool have_q = false, have_phi = false, stepped = false;
+  // snapshots (ref niwqg/Saving.py:59-86): physical q, phi in buffers of their own, copied out on a second stream
+  double* snap_q = nullptr;
+  cd* snap_phi = nullptr;
+  double* snap_hq = nullptr;       // pinned host
+  cd* snap_hphi = nullptr;
+  hipStream_t snap_stream = nullptr;
+  hipEvent_t ev_snap = nullptr;
+  bool snap_busy = false;
   // single-rank CoupledModel: the q update (memory-bound) runs on a second stream beside the wave-PV row kernel
   // (transform-engine bound), which then leaves `overlap_cus` CUs free for it (0 = off)
   hipStream_t stream2 = nullptr;
@@ -403,6 +411,34 @@ __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, 
     v[8] += wt * pq;                                              // -> mean(psi q)
   }
   diag_block_store<9>(v, part);
+}
+
+// passive scalar of QGModel: S_n = sum w wv2^n |c-hat|^2, n = 0..3, over the half spectrum (w = 1 on the self-mirrored columns,
+// 2 elsewhere; n = 0 without the [0,0] entry, like spec_var): C2, gradC2, mean(lap c ^2), -mean(lap^2 c lap c)
+__global__ void k_diag_c(const cd* __restrict__ ch, int N, int width, int pitch, const double* __restrict__ kk,
+                         const double* __restrict__ ll, double* __restrict__ part) {
+  // n = 0, 1 are spec_var sums of c-hat as it is (C2, gradC2); n = 2, 3 stand for physical-space means of lap c, which only
+  // sees the Hermitian part (in l) of the two self-mirrored columns -- what irfft2 keeps
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  const size_t total = (size_t)N * width;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i / width), k = (int)(i - (size_t)l * width);
+    const cd z = ch[(size_t)l * pitch + k];
+    cd h = z;
+    double wt = 2.0;
+    if (k == 0 || k == N / 2) {
+      wt = 1.0;
+      const cd zm = ch[(size_t)((N - l) % N) * pitch + k];
+      h = cmake(0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y));
+    }
+    const double kx = kk[k], ly = ll[l], wv2 = kx * kx + ly * ly;
+    const double m2 = wt * (z.x * z.x + z.y * z.y), m2h = wt * (h.x * h.x + h.y * h.y);
+    v[0] += (l == 0 && k == 0) ? 0.0 : m2;
+    v[1] += wv2 * m2;
+    v[2] += wv2 * wv2 * m2h;
+    v[3] += wv2 * wv2 * wv2 * m2h;
+  }
+  diag_block_store<4>(v, part);
 }
 
 // budget bookkeeping ----------------------------------------------------------------------------
@@ -1793,6 +1829,13 @@ int nq_destroy(nq_ctx* c) {
     if (e) hipEventDestroy(e);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->snap_stream) {
+    hipStreamSynchronize(c->snap_stream);
+    hipStreamDestroy(c->snap_stream);
+  }
+  if (c->ev_snap) hipEventDestroy(c->ev_snap);
+  if (c->snap_hq) hipHostFree(c->snap_hq);
+  if (c->snap_hphi) hipHostFree(c->snap_hphi);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   if (c->mstream) hipStreamSynchronize(c->mstream);
   for (hipEvent_t e : c->ev_prod)
@@ -1962,6 +2005,7 @@ int nq_step(nq_ctx* c, int nsteps) {
   if (nsteps < 0) NQ_FAIL(c, -1, "nq_step: nsteps < 0");
   HIPCHK(c, hipSetDevice(c->device));
   for (int i = 0; i < nsteps; ++i) do_step(c);
+  if (nsteps > 0) c->stepped = true;
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -2393,6 +2437,57 @@ int nq_slab_counters(nq_ctx* c, double* out, int reset) {
   return 0;
 }
 
+
+// ---- snapshots without stalling the stepper (ref niwqg/Saving.py:59-86: t, q, phi every tsave_snapshots steps) ---------
+// nq_snapshot_begin: q = Re ifft(qh) (and phi = ifft(phih)) of the CURRENT state into device buffers of their own, on the
+// context's stream; a second stream copies them to pinned host memory as soon as they are formed.  The caller may queue
+// further steps at once.  nq_snapshot_end waits for that copy only and hands the arrays over.
+int nq_snapshot_begin(nq_ctx* c, int with_phi) {
+  NQ_SINGLE_RANK(c, "nq_snapshot_begin");
+  if (with_phi && !c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
+  if (c->snap_busy) NQ_FAIL(c, -4, "nq_snapshot_begin: the previous snapshot has not been collected (nq_snapshot_end)");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t full = (size_t)c->N * c->N;
+  if (!c->snap_stream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->snap_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_snap, hipEventDisableTiming));
+    ALLOC(c, c->snap_q, full);
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->snap_hq), sizeof(double) * full, hipHostMallocDefault));
+  }
+  if (with_phi && !c->snap_phi) {
+    ALLOC(c, c->snap_phi, full);
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->snap_hphi), sizeof(cd) * full, hipHostMallocDefault));
+  }
+  const cd* qh = c->q.y[c->q.cur];
+  if (c->dual) {
+    hipLaunchKernelGGL(k_avg_interior, dim3((c->Wh + 63) / 64, c->N), dim3(64), 0, c->stream, qh, (const cd*)c->q2.y[c->q2.cur], c->scr_f1, c->Wh, c->Ph, c->N);
+    qh = c->scr_f1;
+  }
+  inv2d_half(c, qh, c->snap_q, c->scr_h0);
+  if (with_phi) launch_x_c2c(c, true, c->mPhi.xs, c->snap_phi, c->mPhi.pitch, c->N, 1.0);
+  HIPCHK(c, hipEventRecord(c->ev_snap, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->snap_stream, c->ev_snap, 0));
+  HIPCHK(c, hipMemcpyAsync(c->snap_hq, c->snap_q, sizeof(double) * full, hipMemcpyDeviceToHost, c->snap_stream));
+  if (with_phi) HIPCHK(c, hipMemcpyAsync(c->snap_hphi, c->snap_phi, sizeof(cd) * full, hipMemcpyDeviceToHost, c->snap_stream));
+  c->snap_busy = true;
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int nq_snapshot_end(nq_ctx* c, double* q_out, double* phi_out) {
+  NQ_SINGLE_RANK(c, "nq_snapshot_end");
+  if (!c->snap_busy) NQ_FAIL(c, -4, "nq_snapshot_end: no snapshot in flight");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->snap_stream));
+  const size_t full = (size_t)c->N * c->N;
+  if (q_out) memcpy(q_out, c->snap_hq, sizeof(double) * full);
+  if (phi_out) {
+    if (!c->snap_hphi) NQ_FAIL(c, -4, "nq_snapshot_end: the snapshot was taken without phi");
+    memcpy(phi_out, c->snap_hphi, sizeof(cd) * full);
+  }
+  c->snap_busy = false;
+  return 0;
+}
+
 // host copies of the blocks that are summed over ranks (nq_reduce_buffer): what a callback link reduces
 int nq_reduce_read(nq_ctx* c, int which, double* host_out) {
   if (!c || !host_out) return -1;
@@ -2729,6 +2824,27 @@ int nq_diagnostics(nq_ctx* c, double* out) {
   for (int i = 15; i < 32; ++i) out[i] = 0.0;
   const double qbar = (q00.x - w00.x) / M, abar = h[0] / (M * M);
   out[15] = qbar;
+  if (!waves && c->passive) {
+    // QGModel's passive scalar (ref QGModel.py:724-737, :595-604): [16..19] the four |c-hat|^2 sums, [20] the Gamma_c projection
+    const cd* ch = c->cq.y[c->cq.cur];
+    hipLaunchKernelGGL(k_diag_c, dim3(NB), dim3(256), 0, c->stream, ch, N, c->Wh, c->Ph, c->kk, c->ll, c->diag_part);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, NB, 4, 4, d + 16);
+    // jacobian_psi_c with the u, v the reference still holds at a tick: those of the state at which the last step evaluated
+    // its fourth stage (QGModel.py:375 vs :396); before any step, those of the current state
+    const cd* qh4 = c->stepped ? c->q.y[(c->q.cur + 2) % 3] : c->q.y[c->q.cur];
+    phase_invert_y(c, qh4, false, c->part0Q, nullptr, ch);
+    launch_products(c);
+    launch_A_m(c, false, {&c->mUc, &c->mVc});
+    const YGeom g = geom_half(c);
+    const int nwc = ((g.width + CL - 1) / CL) * c->S2;
+#define CALL_(sz) hipLaunchKernelGGL((k_s_project_c<sz>), dim3((g.width + CL - 1) / CL, c->S2), dim3(YPlan<sz>::THREADS), YPlan<sz>::LDS_BYTES, c->stream, c->mUc, c->mVc, ch, g, c->kk, c->ll, c->tw, 1, c->diag_part)
+    NQ_S1_SWITCH(c, CALL_)
+#undef CALL_
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, nwc, 1, 1, d + 20);
+    do_invert_now(c);                                 // the mixed-space rows of the CURRENT state again, for the next step
+    HIPCHK(c, hipMemcpyAsync(out + 16, d + 16, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
+    return nq_sync(c);
+  }
   if (!waves) return 0;
   // physical-space statistics: [16,24)
   if (c->p.model == NQ_MODEL_COUPLED) launch_xdiag_m<MODE_COUPLED>(c, qbar, abar, c->diag_part);

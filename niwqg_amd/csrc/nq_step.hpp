@@ -953,6 +953,52 @@ k_s_project(MArr Hw, const cd* __restrict__ phih, YGeom g, const double* __restr
   block_sum_store<4>(s, red, part + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
 }
 
+// ---- diagnostics tick of QGModel's passive scalar: Gamma_c = 2 mean(lap c * J(psi, c)) (ref QGModel.py:727-731) by Parseval ----
+// part[workgroup] = sum over the tile of w * Re(conj(-wv2 c-hat) * (i k F[u c] + i l F[v c])), w = 1 on the two self-mirrored
+// columns, 2 elsewhere; Huc, Hvc already went through the A sub-pass.
+template <int S1>
+__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+k_s_project_c(MArr Huc, MArr Hvc, const cd* __restrict__ ch, YGeom g, const double* __restrict__ kk,
+              const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N, double* __restrict__ part) {
+  typedef YPlan<S1> Y;
+  constexpr int P = Y::P, T = Y::T;
+  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
+  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int kg = g.k0 + k, S2 = g.S2;
+  const bool ok = k < g.width;
+  const int N = S1 * S2;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename Y::F::Tw twr;
+  Y::F::load_tw(twr, j, tw, tw_step_N * (N / S1));
+  double* red = reinterpret_cast<double*>(nq_smem + Y::LDS_BYTES - 512);
+  cd f1[P], f2[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const size_t at = (size_t)(l1 * S1 + j + t * T) * Huc.pitch + k;
+    f1[t] = ok ? Huc.ys[at] : cmake(0, 0);
+    f2[t] = ok ? Hvc.ys[at] : cmake(0, 0);
+  }
+  Y::F::template run<false>(f1, j, c, lds, twr);
+  Y::F::template run<false>(f2, j, c, lds, twr);
+  double s[1] = {0.0};
+  if (ok) {
+    const double kx = kk[kg], wt = (kg == 0 || kg == N / 2) ? 1.0 : 2.0;
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const int l = l1 + S2 * (j + t * T);
+      const double ly = ll[l], wv2 = kx * kx + ly * ly;
+      cd cc = ch[(size_t)l * g.pitch_s + k];
+      if (wt == 1.0) {      // lap c in physical space sees only the Hermitian part (in l) of the self-mirrored columns
+        const cd cm = ch[(size_t)((N - l) % N) * g.pitch_s + k];
+        cc = cmake(0.5 * (cc.x + cm.x), 0.5 * (cc.y - cm.y));
+      }
+      const double jx = -(kx * f1[t].y + ly * f2[t].y), jy = kx * f1[t].x + ly * f2[t].x;      // i k F1 + i l F2
+      s[0] += wt * (-wv2) * (cc.x * jx + cc.y * jy);
+    }
+  }
+  block_sum_store<1>(s, red, part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+}
+
 // ---- ETDRK4 stage update of one spectral element -----------------------------------------------
 // ref Kernel.py:327,:347,:364,:381-382 (q) and :333,:351,:368,:386-387 (phi).  The filter is folded
 // into the coefficient planes (Ef = E*filtr ...), which is the same arithmetic up to rounding.

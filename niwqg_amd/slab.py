@@ -326,6 +326,31 @@ def make_ranks(model, nx, kk, ll, filtr, dt, nranks, device=0, only_rank=None, b
             for r in which]
 
 
+def connect(ranks, dist, nchunks=2):
+    """The multi-process simulation of this rank: RCCL issued by the library when it can be set up on EVERY rank, else
+    (or with NIWQG_AMD_SLAB_LINK=callback, or on a gloo group) torch.distributed moves the buffers from library callbacks.
+    All ranks end up on the same link: the outcome of the RCCL set-up is agreed on through the process group."""
+    import os
+    import torch
+    gloo = dist.get_backend() == "gloo"
+    if gloo:
+        return SlabSimulation(ranks, "callback", dist=dist, nchunks=nchunks, stage_via_host=True)
+    sim, err = None, None
+    if os.environ.get("NIWQG_AMD_SLAB_LINK", "rccl") == "rccl":
+        try:
+            sim = SlabSimulation(ranks, "rccl", dist=dist, nchunks=nchunks)
+        except RuntimeError as e:
+            err = e
+        flag = torch.tensor([1.0 if sim is not None else 0.0], device=torch.device("cuda", ranks[0].device))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag[0]) == 1.0:
+            return sim
+        import sys
+        sys.stderr.write("niwqg_amd.slab rank %d: RCCL link not available on every rank (%s): falling back to "
+                         "torch.distributed callbacks\n" % (ranks[0].rank, err or "another rank failed"))
+    return SlabSimulation(ranks, "callback", dist=dist, nchunks=nchunks, stage_via_host=False)
+
+
 class SlabContext(object):
     """What the model classes (niwqg_amd.Kernel / QGModel) need from a device context, on top of a slab-decomposed
     simulation: the same methods as ``_lib.Context``, fields gathered over the ranks on demand.  ``peers`` = P puts all P
@@ -344,12 +369,11 @@ class SlabContext(object):
             g = self.group = Group()
             if g.dist is None:
                 raise RuntimeError("slab model: no process group -- launch with torch.distributed.run (WORLD_SIZE > 1) or pass slab=P")
-            gloo = getattr(g, "backend", "") == "gloo"
             import torch
             dev = g.local_rank % max(torch.cuda.device_count(), 1) if device is None else device
             ranks = make_ranks(model, nx, kk, ll, filtr, dt, g.world, device=dev, only_rank=g.rank, budgets=budgets,
-                               torch_buffers=gloo, **phys)
-            self.sim = SlabSimulation(ranks, "callback" if gloo else "rccl", dist=g.dist, nchunks=nchunks, stage_via_host=gloo)
+                               torch_buffers=True, **phys)          # torch tensors: usable by either link
+            self.sim = connect(ranks, g.dist, nchunks)
         self._ds = None
 
     # --- state

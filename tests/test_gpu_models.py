@@ -543,3 +543,92 @@ def test_long_run_500_steps_stays_within_the_baseline_tolerance():
     assert m.tc == 500
     assert rel(m.q, o.q) < 1e-10 and rel(m.phi, o.phi) < 1e-10
     assert np.allclose([m.Ke, m.Pw, m.Kw], [o.Ke, o.Pw, o.Kw], rtol=1e-9)
+
+
+def test_run_with_save_to_disk_writes_the_references_files(tmp_path):
+    """save_to_disk=True (ref: niwqg/Saving.py:38-101, hooks niwqg/Kernel.py:194-217): setup.h5, one snapshot of t, q, phi
+    every tsave_snapshots steps named by the model time, diagnostics.h5 -- with a recording writer in place of h5py.  The
+    snapshots leave the device asynchronously (nq_snapshot_begin / _end) while the next steps run: their content must still
+    be the state at exactly that step."""
+    from niwqg_amd import Saving, InitialConditions as ic
+
+    class Rec(object):
+        files = {}
+
+        def __init__(self, fno):
+            self.fno, self.data = fno, {}
+
+        def create_dataset(self, name, data=None, dtype=None):
+            self.data[name] = np.array(data)
+
+        def close(self):
+            open(self.fno, "w").write("stub")
+            Rec.files[self.fno] = self.data
+
+    Saving.set_writer(Rec)
+    try:
+        kw = notebook_kwargs(128, True, tdiags=4)
+        kw.update(tmax=None)
+        path = str(tmp_path / "out")
+        mk = lambda **extra: models().CoupledModel.Model(**dict(kw, tmax=24.5 * kw["dt"], **extra))
+        m = mk(save_to_disk=True, tsave_snapshots=6, path=path)
+        q0 = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+        phi0 = (np.ones((128, 128)) + 1j) * (2 * U0) / np.sqrt(2)
+        m.set_q(q0)
+        m.set_phi(phi0)
+        m.run()
+        assert m.tc == 25
+        names = sorted(os.listdir(path + "/snapshots"))
+        want = ['{:015.0f}.h5'.format(n * m.dt) for n in (0, 6, 12, 18, 24)]
+        assert names == sorted(want), (names, want)
+        assert set(Rec.files[path + "/setup.h5"]) == {"grid/nx", "grid/x", "grid/y", "grid/wv", "grid/k", "grid/l"}
+        d = Rec.files[path + "/diagnostics.h5"]
+        assert set(d) == set(m.diagnostics) and len(d["time"]) == len(m.diagnostics["time"]["value"])
+        # the same run without output, stopped at two of the snapshot steps
+        r = mk()
+        r.set_q(q0)
+        r.set_phi(phi0)
+        s0 = Rec.files[path + "/snapshots/" + want[0]]
+        assert np.array_equal(s0["q"], q0) or rel(s0["q"], q0) < 1e-14
+        for n in (12, 24):
+            steps(r, n)
+            snap = Rec.files[path + "/snapshots/" + '{:015.0f}.h5'.format(n * m.dt)]
+            assert float(snap["t"]) == r.t
+            assert rel(snap["q"], r.q) < 1e-14 and rel(snap["phi"], r.phi) < 1e-14
+        # QGModel: t and q (no c without the passive scalar)
+        pq = str(tmp_path / "outqg")
+        qg = models().QGModel.Model(L=L, nx=64, tmax=4.5 * 1000.0, dt=1000.0, twrite=10 ** 9, nu4=7.5e8, use_filter=False,
+                                    U=-U0, tdiags=10 ** 9, save_to_disk=True, tsave_snapshots=2, path=pq)
+        qg.set_q(1e-6 * np.random.default_rng(0).standard_normal((64, 64)))
+        qg.run()
+        assert sorted(os.listdir(pq + "/snapshots")) == ['{:015.0f}.h5'.format(n * 1000.0) for n in (0, 2, 4)]
+        assert set(Rec.files[pq + "/snapshots/" + '{:015.0f}.h5'.format(4000.0)]) == {"t", "q"}
+    finally:
+        Saving.set_writer(None)
+    if not Saving.writer_available():
+        with pytest.raises(NotImplementedError):
+            models().CoupledModel.Model(save_to_disk=True, path=str(tmp_path / "nowriter"), **notebook_kwargs(64, True))
+
+
+def test_tick_side_effect_fields_on_demand():
+    """phq, phw, uq, vq, uw, vw (ref: niwqg/CoupledModel.py:105-112) exist as on-demand attributes and reproduce the
+    cross term of the kinetic-energy decomposition that the device tick reports."""
+    kw = notebook_kwargs(64, True, tdiags=1)
+    o = O.NIWQGOracle("coupled", **kw)
+    m = models().CoupledModel.Model(**kw)
+    q0 = O.lamb_dipole(o.grid, U=U0, R=2 * np.pi / K0)
+    phi0 = 0.2 * O.wave_packet(o.grid, k=3 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2)
+    for x in (o, m):
+        x.set_phi(phi0)
+        x.set_q(q0)
+    steps(m, 2)
+    for _ in range(2):
+        o._step_forward()
+    want = dict(phq=o.phq, phw=o.phw)
+    for tag, ph in (("q", o.phq), ("w", o.phw)):
+        want["u" + tag] = np.fft.ifft2(-o.il * ph).real
+        want["v" + tag] = np.fft.ifft2(o.ik * ph).real
+    for name in ("phq", "phw", "uq", "vq", "uw", "vw"):
+        assert rel(getattr(m, name), want[name]) < 1e-10, name      # qh's Nyquist-row passenger (DESIGN.md) is in phq
+    cross = (m.uq * m.uw).mean() + (m.vq * m.vw).mean()
+    assert abs(cross - m.diagnostics["ke_qg_qw"]["value"][-1]) < 1e-10 * abs(cross)

@@ -77,7 +77,7 @@ def _bare_kernel(tdiags, twrite, dt, tmax):
     from niwqg_amd import Kernel
     k = object.__new__(Kernel.Kernel)
     k.__dict__.update(tdiags=tdiags, twrite=twrite, dt=dt, tmax=tmax, t=0, tc=0, _cache={}, _user={},
-                      _ctx=_FakeCtx(), diagnostics={})
+                      _ctx=_FakeCtx(), diagnostics={}, save_to_disk=False, tsnaps=10, _pending_snapshots=[])
     k.ticks, k.status = [], []
     k._calc_derived_fields = lambda: k.ticks.append(k.tc)
     k._print_status_orig = Kernel.Kernel._print_status
@@ -164,3 +164,64 @@ def test_exchange_group_sizes_without_a_gpu(built):
     p = built.Params(model=0, nx=4096, budgets=1, dual_q=0, dt=1.0, U=0, f=1e-4, kappa2=1, nu=0, nu4=0, mu=0, nuw=0, nu4w=0,
                      muw=0, beta=0, passive_scalar=0, nu4c=0, nuc=0, muc=0)
     assert L.nq_group_elems(ctypes.byref(p), 3, 0) < 0             # 4096 rows do not split over 3 ranks
+
+
+class _Recorder(object):
+    """stand-in for h5py.File(fno, 'w'): records what would have been written"""
+    files = {}
+
+    def __init__(self, fno):
+        self.fno, self.data = fno, {}
+
+    def create_dataset(self, name, data=None, dtype=None):
+        self.data[name] = np.array(data)
+
+    def close(self):
+        open(self.fno, "w").write("stub")
+        _Recorder.files[self.fno] = self.data
+
+
+def test_saving_layout_names_and_overwrite_rules(tmp_path):
+    """niwqg_amd/Saving.py against ref niwqg/Saving.py:6-101 with a recording writer: directory layout, the %015.0f snapshot
+    names, dataset names, the tc % tsnaps rule, overwrite=False raising IOError, and loud failure without any writer."""
+    from niwqg_amd import Saving
+
+    class M(object):
+        pass
+    m = M()
+    m.save_to_disk, m.overwrite, m.tsnaps = True, True, 5
+    m.nx, m.kk, m.ll = 4, np.arange(4.), np.arange(4.)
+    m.x = m.y = m.wv = np.zeros((4, 4))
+    m._ctx = object()                                  # no snapshot_begin: fields are read synchronously
+    m.q, m.phi = np.ones((4, 4)), 1j * np.ones((4, 4))
+    m.diagnostics = {"Ke": {"value": np.arange(3.)}, "time": {"value": np.arange(3.)}}
+    Saving.set_writer(None)
+    if not Saving.writer_available():
+        with pytest.raises(NotImplementedError):
+            Saving.initialize_save_snapshots(m, str(tmp_path / "out0"))
+    Saving.set_writer(_Recorder)
+    try:
+        path = str(tmp_path / "out")
+        Saving.initialize_save_snapshots(m, path)
+        assert os.path.isdir(path + "/snapshots")
+        Saving.save_setup(m)
+        assert set(_Recorder.files[path + "/setup.h5"]) == {"grid/nx", "grid/x", "grid/y", "grid/wv", "grid/k", "grid/l"}
+        for tc, t in ((0, 0.0), (3, 300.0), (5, 500.0), (10, 123456.7)):
+            m.tc, m.t = tc, t
+            Saving.save_snapshots(m, fields=['t', 'q', 'phi'])
+        Saving.flush_snapshots(m)
+        names = sorted(os.listdir(path + "/snapshots"))
+        assert names == ["000000000000000.h5", "000000000000500.h5", "000000000123457.h5"]      # tc = 3 is no snapshot step
+        snap = _Recorder.files[path + "/snapshots/000000000000500.h5"]
+        assert set(snap) == {"t", "q", "phi"} and float(snap["t"]) == 500.0 and np.array_equal(snap["phi"], m.phi)
+        Saving.save_diagnostics(m)
+        assert set(_Recorder.files[path + "/diagnostics.h5"]) == {"Ke", "time"}
+        m.overwrite = False
+        with pytest.raises(IOError):
+            Saving.save_setup(m)
+        w = Saving.NpzWriter(str(tmp_path / "x.h5"))
+        w.create_dataset("grid/nx", data=4, dtype=int)
+        w.close()
+        assert int(np.load(str(tmp_path / "x.h5"))["grid__nx"]) == 4
+    finally:
+        Saving.set_writer(None)

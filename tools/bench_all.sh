@@ -25,10 +25,14 @@ for cfg in $CONFIGS; do
   echo "== $cfg: bench.py $args"
   W=/tmp/ball_$cfg
   rm -rf "$W"
-  timeout -k 10 420 rocprofv3 --kernel-trace --stats -d "$W" -o run --output-format csv -- python3 "$ROOT/bench.py" $args --no-cpu-baseline > "$W.out" 2> "$DST/${TAG}_${cfg}.stderr"
+  # the quoted number: a plain run (rocprofv3 slows launch-bound configurations down by 10-30 %) ...
+  timeout -k 10 420 python3 "$ROOT/bench.py" $args --no-cpu-baseline > "$W.out" 2> "$DST/${TAG}_${cfg}.stderr"
   rc=$?
   echo $rc > "$DST/${TAG}_${cfg}.rc"
   grep '^{' "$W.out" | tail -1 > "$DST/${TAG}_${cfg}_bench_line.json"
+  # ... and the kernel statistics of the same command under rocprofv3
+  timeout -k 10 420 rocprofv3 --kernel-trace --stats -d "$W" -o run --output-format csv -- python3 "$ROOT/bench.py" $args --no-cpu-baseline > "$W.prof.out" 2>> "$DST/${TAG}_${cfg}.stderr"
+  echo "$rc $?" > "$DST/${TAG}_${cfg}.rc"
   f=$(find "$W" -name '*kernel_stats.csv' 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" "$DST/${TAG}_${cfg}_kernel_stats.csv"
   echo "   rc=$rc $(python3 -c "

@@ -10,6 +10,9 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/gpurun_out/profiles_$TAG"
 cd /tmp && export TMPDIR=/tmp
+# the headline line itself, un-profiled, with the measured CPU sample
+python3 "$ROOT/bench.py" > "$OUT/bench_plain.json" 2> "$OUT/bench_plain_stderr.log"
+grep '^{' "$OUT/bench_plain.json" | tail -1 > "$ROOT/gpurun_out/profiles_$TAG/${TAG}_bench_line_plain.json"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run --output-format csv -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_line.json" 2> "$OUT/bench_stderr.log"
 echo "stats rc=$?"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$ROOT/gpurun_out/profiles_$TAG/${TAG}_kernel_stats.csv"

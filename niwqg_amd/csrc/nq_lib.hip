@@ -128,6 +128,8 @@ struct nq_ctx {
   nq_allreduce_fn rcb = nullptr;
   void* cb_user = nullptr;
   int nchunk = 1;                      // row chunks per exchange (producer / consumer row kernels run chunk by chunk)
+  int reserve_cus = 0;                 // CUs the persistent row kernels leave free (RCCL's copy kernels need somewhere to run:
+                                       // a row-kernel workgroup owns the whole register file of its CU)
   hipStream_t mstream = nullptr;       // exchanges run here, beside the compute stream
   hipEvent_t ev_prod[8] = {}, ev_arr[4][8] = {}, ev_col = nullptr, ev_done = nullptr, ev_red = nullptr;
   bool arr_pending[4] = {false, false, false, false};   // group g is arriving chunk by chunk (ev_arr[g][*] recorded)
@@ -740,7 +742,7 @@ static void launch_wavepv_t(nq_ctx* c) {
     case 8192:
       if (c->eo_scratch) {                            // even / odd samples as two 4096-point problems (no spills)
         typedef XPlan<4096> X;
-        const int nb = c->nrows, grid = nb < c->num_cu ? nb : c->num_cu;
+        const int ncu = c->num_cu - c->reserve_cus, nb = c->nrows, grid = nb < ncu ? nb : ncu;
         const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd);
         hipLaunchKernelGGL((k_x_wavepv_eo<8192, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mPhi, mPhiy, mA, mB, c->twx_half, c->tw, c->kk, nb, c->eo_scratch);
       } else {
@@ -751,7 +753,7 @@ static void launch_wavepv_t(nq_ctx* c) {
     case 4096: {                                      // long rows: two transforms in flight, no spills
       typedef XPlan<4096> X;
       const size_t ldsb = X::LDS_BYTES + X::F::LDS_ELEMS * sizeof(cd);
-      int grid = c->num_cu - (c->stream2 ? c->overlap_cus : 0);                    // one persistent workgroup per CU
+      int grid = c->num_cu - (c->stream2 ? c->overlap_cus : 0) - c->reserve_cus;   // one persistent workgroup per CU
       const int nb = c->nrows / X::C;
       if (grid > nb) grid = nb;
       hipLaunchKernelGGL((k_x_wavepv2<4096, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mPhi, mPhiy, mA, mB, c->twx, c->kk, nb);
@@ -777,7 +779,7 @@ static void launch_products_t(nq_ctx* c, double cj, double cr, bool fresh_grad) 
     typedef XPlan<4096> X;
     const MArr& gx8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? mGx : mPhi;
     const MArr& gy8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? mGy : mPhiy;
-    const int nb = c->nrows, grid = nb < c->num_cu ? nb : c->num_cu;
+    const int ncu = c->num_cu - c->reserve_cus, nb = c->nrows, grid = nb < ncu ? nb : ncu;
     const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd);
     hipLaunchKernelGGL((k_x_products_eo<8192, MODE, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mU, mP, mQ, mQw, mPhi, gx8, gy8, mUq, mVq, mW, c->twx_half, c->tw, c->kk, vz, cj, cr, nb, c->eo_scratch);
     return;
@@ -787,7 +789,8 @@ static void launch_products_t(nq_ctx* c, double cj, double cr, bool fresh_grad) 
   switch (c->N) {
 #define CASE_(n, a, b) case n: { typedef XPlan<n> X; const int nb = c->nrows / X::C; \
     /* one workgroup fits per CU (LDS) and does not spill: persistent; 8192-point rows spill and do better with dynamic dispatch */ \
-    const int grid = (X::LDS_BYTES > 80 * 1024 && X::THREADS <= 512 && nb > c->num_cu) ? c->num_cu : nb; \
+    const int ncu = c->num_cu - c->reserve_cus; \
+    const int grid = (X::LDS_BYTES > 80 * 1024 && X::THREADS <= 512 && nb > ncu) ? ncu : nb; \
     hipLaunchKernelGGL((k_x_products<n, MODE, SLAB>), dim3(grid), dim3(X::THREADS), X::LDS_BYTES, c->stream, mU, mP, mQ, mQw, mPhi, gx, gy, mUq, mVq, mW, c->twx, c->kk, vz, cj, cr, nb); } break;
     NQ_FOR_SIZES(CASE_)
 #undef CASE_
@@ -2136,6 +2139,16 @@ int nq_comm_init(nq_ctx* c, const void* id128, int nranks, int rank) {
   memcpy(&id, id128, sizeof(id));
   NCCLCHK(c, g_rccl.CommInitRank(&c->comm, nranks, id, rank));
   c->link = LINK_RCCL;
+  if (nranks > 1) {
+    // RCCL's send/recv kernels run BESIDE the chunked row kernels, and a persistent row-kernel workgroup (512 threads x
+    // ~250 VGPRs) fills its CU's register file, so they compete for whole CUs.  NIWQG_AMD_SLAB_RESERVE_CUS=R keeps R CUs
+    // out of the row kernels' persistent grids.  Off by default: with 256 or 512 rows per chunk a grid of 256-R
+    // workgroups needs an extra round of rows, which costs what the overlap gains -- to be settled
+    // by measurement on a multi-GPU node.
+    const char* e = getenv("NIWQG_AMD_SLAB_RESERVE_CUS");
+    c->reserve_cus = e ? atoi(e) : 0;
+    if (c->reserve_cus < 0 || c->reserve_cus >= c->num_cu) c->reserve_cus = 0;
+  }
   return slab_link_setup(c);
 }
 int nq_slab_attach_peers(nq_ctx* const* ctxs, int nranks) {

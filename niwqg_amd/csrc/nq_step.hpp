@@ -139,6 +139,27 @@ __device__ __forceinline__ void hs_pack(cd (&w)[P], const HsRegs<P>& r, int j, i
   wg_barrier();
 }
 
+// max of two non-negative doubles over one ROW (T threads), through the row's two LDS words mx[0..1] (zeroed, barrier
+// before).  Rows of at least one wave reduce inside the wave first: 512 lanes hitting ONE LDS address serialise
+// (9.3 % of the LDS cycles of k_x_wavepv2 were bank conflicts from exactly that, profiles/r01_pmc_summary.json).
+template <int T>
+__device__ __forceinline__ void row_atomic_max(unsigned long long* mx, double ma, double mb) {
+  if constexpr (T >= 64) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ma = fmax(ma, __shfl_xor(ma, off, 64));
+      mb = fmax(mb, __shfl_xor(mb, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
+      atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
+    }
+  } else {
+    atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
+    atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
+  }
+}
+
 // After a forward row FFT of z = a + i*b (a, b real), split into the two half spectra and store
 // kx = 0..N/2.  Needs the mirrored element Z[N-kx], fetched through LDS.
 template <int N, int P, int T, typename F, typename Row>
@@ -221,8 +242,7 @@ k_x_wavepv(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, c
     mx[1] = 0ull;
   }
   wg_barrier();
-  atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
-  atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
+  row_atomic_max<T>(mx, ma, mb);
   wg_barrier();
   ma = __longlong_as_double((long long)mx[0]);
   mb = __longlong_as_double((long long)mx[1]);
@@ -310,8 +330,7 @@ k_x_wavepv2(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, 
       mx[1] = 0ull;
     }
     wg_barrier();
-    atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
-    atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
+    row_atomic_max<T>(mx, ma, mb);
     wg_barrier();
     ma = __longlong_as_double((long long)mx[0]);
     mb = __longlong_as_double((long long)mx[1]);
@@ -393,8 +412,7 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
       mx[1] = 0ull;
     }
     wg_barrier();
-    atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
-    atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
+    row_atomic_max<T>(mx, ma, mb);
     wg_barrier();
     ma = __longlong_as_double((long long)mx[0]);
     mb = __longlong_as_double((long long)mx[1]);
@@ -826,8 +844,7 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
           mx[1] = 0ull;
         }
         wg_barrier();
-        atomicMax(&mx[0], (unsigned long long)__double_as_longlong(ma));
-        atomicMax(&mx[1], (unsigned long long)__double_as_longlong(mb));
+        row_atomic_max<T>(mx, ma, mb);
         wg_barrier();
         ma = __longlong_as_double((long long)mx[0]);
         mb = __longlong_as_double((long long)mx[1]);

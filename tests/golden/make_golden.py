@@ -20,6 +20,10 @@ Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
   g8_ybj_64.npz           YBJModel (steady psi): trajectory, diagnostics series, stale phix/phiy
   g9_initial_conditions_64.npz   all five generators of niwqg/InitialConditions.py (seeded)
   g10_qg_passive_64.npz   QGModel with passive_scalar=True: trajectory of q and c, cvar, diagnostics series
+  g11_at_size_2048.npz    the REAL reference at 2048^2 on white-noise states (BASELINE config 2: QGModel random q, 2 steps;
+                          CoupledModel rough q and phi, 1 step): not the fields (32-64 MB each) but what pins them -- 256
+                          seeded random projections, a 64x64 sub-sample, norms, budgets; the tests regenerate the same
+                          projection vectors from the seed (g11 takes ~6 minutes and 16 GB here; not in the default list)
 """
 import os
 import sys
@@ -301,6 +305,61 @@ def g10():
         for name, d in m.diagnostics.items():
             out["diag_%s_%s" % (name, key)] = np.asarray(d["value"], dtype=float)
     save("g10_qg_passive_64.npz", **out)
+
+
+# ---------------------------------------------------------------- G11: the reference itself at size
+def projections(field, seed, n=256):
+    """n inner products of the field with seeded random-sign vectors (one row of +-1 per projection would be 32 MB each at
+    2048^2: use separable signs sx[i] * sy[j], regenerated from the seed by the tests)"""
+    rng = np.random.default_rng(seed)
+    ny, nx = field.shape
+    out = np.empty(n, field.dtype)
+    for i in range(n):
+        sy = rng.integers(0, 2, ny) * 2.0 - 1.0
+        sx = rng.integers(0, 2, nx) * 2.0 - 1.0
+        out[i] = sy @ field @ sx
+    return out
+
+
+def g11():
+    nx = 2048
+    out = {}
+    # BASELINE config 2 exactly as bench.py --model qg --nx 2048 builds it
+    dt, nu4 = 0.05 * TE * 128 / nx, 7.5e8 / 64
+    m = QGModel.Model(L=L, nx=nx, tmax=1e30, dt=dt, twrite=10 ** 9, nu4=nu4, use_filter=True, save_to_disk=False,
+                      U=-U0, tdiags=10 ** 9)
+    q0 = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx))
+    m.set_q(q0)
+    step_to(m, 2)
+    out["qg_params"] = np.array([dt, nu4, L, -U0])
+    out["qg_q_proj"] = projections(m.q, 101)
+    out["qg_q_sub"] = m.q[::32, ::32].copy()
+    out["qg_q_norm"] = np.array(np.linalg.norm(m.q))
+    out["qg_qh_proj"] = projections(m.qh, 102)
+    out["qg_Ke"] = np.array(m.Ke)
+    # the noise-amplified entries of the contour-mean planes (|c dt| ~ 1: DESIGN.md section 6): the reference's own values
+    ch = (-m.nu4 * m.wv4 - 1j * m.k * m.U) * m.dt
+    near = np.argsort(np.abs(np.abs(ch) - 1.0).ravel())[:64]
+    out["qg_coef_idx"] = near
+    for nm in ("Qh", "f0", "fab", "fc"):
+        out["qg_coef_" + nm] = getattr(m, nm).ravel()[near]
+    del m
+    # CoupledModel, white-noise q and phi, every dissipation term on: one step (tests/test_gpu_at_size.py: rough_kwargs)
+    kw = notebook_kwargs(nx, True, 1, tdiags=10 ** 9)
+    kw.update(nu4w=kw["nu4"] * 0.1, mu=1e-8, muw=2e-8)
+    m = CoupledModel.Model(**kw)
+    rng = np.random.default_rng(11)
+    q0 = 1e-5 * rng.standard_normal((nx, nx))
+    phi0 = 0.05 * (rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx)))
+    m.set_q(q0)
+    m.set_phi(phi0)
+    step_to(m, 1)
+    out["cpl_q_proj"] = projections(m.q, 201)
+    out["cpl_phi_proj"] = projections(m.phi, 202)
+    out["cpl_q_sub"], out["cpl_phi_sub"] = m.q[::32, ::32].copy(), m.phi[::32, ::32].copy()
+    out["cpl_norms"] = np.array([np.linalg.norm(m.q), np.linalg.norm(m.phi)])
+    out["cpl_budgets"] = np.array([m.Ke, m.Pw, m.Kw])
+    save("g11_at_size_2048.npz", **out)
 
 
 if __name__ == "__main__":

@@ -213,3 +213,58 @@ def test_row_kernels_8192_on_a_full_spectrum_against_numpy():
     e = rel(m._ctx.refraction(), F(phi0 * q_psi))
     print("8192^2 refraction %.2e" % e)
     assert e < 1e-12
+
+
+# ---- the REAL reference at 2048^2 (golden g11: projections, sub-samples, norms; make_golden.py g11) -------------------------
+def seeded_projections(field, seed, n=256):
+    rng = np.random.default_rng(seed)
+    ny, nx = field.shape
+    out = np.empty(n, field.dtype)
+    for i in range(n):
+        sy = rng.integers(0, 2, ny) * 2.0 - 1.0
+        sx = rng.integers(0, 2, nx) * 2.0 - 1.0
+        out[i] = sy @ field @ sx
+    return out
+
+
+def l2_error_estimate(field, ref_proj, ref_norm, seed):
+    """random-sign projections of the error have standard deviation = its l2 norm: rms |delta proj| / ||ref||"""
+    d = seeded_projections(field, seed) - ref_proj
+    return float(np.sqrt(np.mean(np.abs(d) ** 2)) / ref_norm)
+
+
+def test_config2_against_the_reference_itself_at_2048(golden):
+    """BASELINE config 2 after two steps against numbers produced by RUNNING THE REFERENCE at 2048^2 (golden g11): 256 random
+    projections of q and of qh (their error estimates the relative l2 error of the whole field), a 64x64 sub-sample, Ke."""
+    import niwqg_amd
+    import bench
+    g = golden("g11_at_size_2048.npz")
+    nx = 2048
+    kw = bench.c3_kwargs(nx, "qg")
+    assert np.allclose([kw["dt"], kw["nu4"], kw["L"], kw["U"]], g["qg_params"], rtol=1e-15)
+    m = niwqg_amd.QGModel.Model(**kw)
+    m.set_q(1e-5 * np.random.default_rng(0).standard_normal((nx, nx)))
+    steps(m, 2)
+    norm = float(g["qg_q_norm"])
+    e = l2_error_estimate(m.q, g["qg_q_proj"], norm, 101)
+    es = rel(m.q[::32, ::32], g["qg_q_sub"])
+    print("config 2 vs the reference at 2048^2: l2 estimate %.2e, sub-sample %.2e" % (e, es))
+    assert e < 2e-11 and es < 2e-11            # the |c dt| ~ 1 shell of the contour-mean planes (DESIGN.md section 6)
+    assert abs(m.Ke - float(g["qg_Ke"])) < 1e-10 * abs(float(g["qg_Ke"]))
+
+
+def test_rough_coupled_step_against_the_reference_itself_at_2048(golden):
+    import niwqg_amd
+    g = golden("g11_at_size_2048.npz")
+    nx = 2048
+    m = niwqg_amd.CoupledModel.Model(**rough_kwargs(nx))
+    rng = np.random.default_rng(11)
+    m.set_q(1e-5 * rng.standard_normal((nx, nx)))
+    m.set_phi(0.05 * (rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx))))
+    steps(m, 1)
+    eq = l2_error_estimate(m.q, g["cpl_q_proj"], float(g["cpl_norms"][0]), 201)
+    ep = l2_error_estimate(m.phi, g["cpl_phi_proj"], float(g["cpl_norms"][1]), 202)
+    print("rough Coupled 2048^2 vs the reference: l2 estimates q %.2e phi %.2e" % (eq, ep))
+    assert eq < 1e-11 and ep < 1e-11
+    assert rel(m.q[::32, ::32], g["cpl_q_sub"]) < 1e-11 and rel(m.phi[::32, ::32], g["cpl_phi_sub"]) < 1e-11
+    assert np.allclose([m.Ke, m.Pw, m.Kw], g["cpl_budgets"], rtol=1e-8)

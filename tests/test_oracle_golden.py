@@ -259,3 +259,38 @@ def test_oracle_workers_option_is_arithmetic_neutral():
         o.set_q(q0)
         steps(o, 5)
     assert rel(qb.q, qa.q) < 1e-13
+
+
+def test_oracle_against_the_reference_at_2048(golden):
+    """The oracle at the size the GPU parity tests use it at, against numbers produced by RUNNING THE REFERENCE at 2048^2
+    (golden g11: BASELINE config 2 after two steps -- random projections, a sub-sample, Ke -- and the reference's own
+    contour-mean coefficients at the 64 entries closest to |c dt| = 1, where its formula cancels catastrophically)."""
+    import os
+    g = golden("g11_at_size_2048.npz")
+    nx = 2048
+    dt, nu4, L_, U_ = [float(v) for v in g["qg_params"]]
+    nw = max(1, min(7, (os.cpu_count() or 2) - 1))
+    o = O.QGOracle(L=L_, nx=nx, tmax=1e30, dt=dt, twrite=10 ** 9, nu4=nu4, use_filter=True, U=U_, tdiags=10 ** 9,
+                   coeff_chunk=8, table_workers=nw)
+    names = {"Qh": "Q", "f0": "f0", "fab": "fab", "fc": "fc"}
+    idx = g["qg_coef_idx"]
+    worst = 0.0
+    for theirs, ours in names.items():
+        # filter folded on neither side: the oracle keeps the reference's unfiltered planes
+        mine, ref = o.coef_q[ours].ravel()[idx], g["qg_coef_" + theirs]
+        worst = max(worst, float(np.max(np.abs(mine - ref) / np.abs(ref))))
+    print("contour-mean planes at the 64 entries nearest |c dt| = 1: worst relative difference oracle vs reference %.2e" % worst)
+    assert worst < 1e-9
+    o.set_q(1e-5 * np.random.default_rng(0).standard_normal((nx, nx)))
+    steps(o, 2)
+    rng_check = np.random.default_rng(101)
+    d = np.empty(256)
+    for i in range(256):
+        sy = rng_check.integers(0, 2, nx) * 2.0 - 1.0
+        sx = rng_check.integers(0, 2, nx) * 2.0 - 1.0
+        d[i] = sy @ o.q @ sx - g["qg_q_proj"][i]
+    est = float(np.sqrt(np.mean(d ** 2)) / float(g["qg_q_norm"]))
+    print("oracle vs the reference at 2048^2, config 2, two steps: l2 estimate %.2e" % est)
+    assert est < 1e-13
+    assert rel(o.q[::32, ::32], g["qg_q_sub"]) < 1e-13
+    assert abs(o.Ke - float(g["qg_Ke"])) < 1e-12 * abs(float(g["qg_Ke"]))

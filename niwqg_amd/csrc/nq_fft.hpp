@@ -167,6 +167,49 @@ __device__ __forceinline__ void twiddle_apply(cd (&v)[R], cd w1, cd w4, cd w8) {
   }
 }
 
+// ---- radix-8 butterfly WITH its stage twiddles, FMA form ------------------------------------------------------
+// X[k] = sum_u v[u] w^u w8^(uk), natural order in and out.  Decimation in time over the bits of u puts one twiddle on
+// every radix-2 butterfly (w^4 on the first layer, w^2 w4^k' on the second, w w8^k on the third), and a twiddled
+// radix-2 butterfly costs 6 fp64 instructions in FMA form (a' = a + t b by four FMAs, b' = 2a - a' by two) instead of
+// 8: 72 + 11 (derived twiddles) = 83 instructions against 48 (twiddle multiplies incl. derived powers) + 56 (DFT) =
+// 104 -- the row kernels are bound by fp64 issue + LDS store issue, adds dominate, and the FMA
+// half of the pipe was idle.
+__device__ __forceinline__ void bfly_tw(cd& a, cd& b, cd t) {
+  const double xr = __builtin_fma(-t.y, b.y, __builtin_fma(t.x, b.x, a.x));
+  const double xi = __builtin_fma(t.y, b.x, __builtin_fma(t.x, b.y, a.y));
+  b = cmake(__builtin_fma(2.0, a.x, -xr), __builtin_fma(2.0, a.y, -xi));
+  a = cmake(xr, xi);
+}
+template <bool INV>
+__device__ __forceinline__ void dft8_twiddled(cd (&v)[8], cd w1, cd w4) {
+  if (INV) {
+    w1.y = -w1.y;
+    w4.y = -w4.y;
+  }
+  const cd w2 = cmake(w1.x * w1.x - w1.y * w1.y, 2.0 * w1.x * w1.y);
+  // layer A: (u, u + 4) with w^4
+  bfly_tw(v[0], v[4], w4);
+  bfly_tw(v[2], v[6], w4);
+  bfly_tw(v[1], v[5], w4);
+  bfly_tw(v[3], v[7], w4);
+  // layer B: w^2 w4^k', k' = 0, 1 (w4 = -i forward, +i inverse)
+  const cd w2r = rot90<INV>(w2);
+  bfly_tw(v[0], v[2], w2);
+  bfly_tw(v[4], v[6], w2r);
+  bfly_tw(v[1], v[3], w2);
+  bfly_tw(v[5], v[7], w2r);
+  // layer C: w w8^k, k = 0..3 (w8 = (1 - i)/sqrt 2 forward, conjugate inverse)
+  const cd w18 = INV ? cscale(cmake(w1.x - w1.y, w1.x + w1.y), NQ_R2) : cscale(cmake(w1.x + w1.y, w1.y - w1.x), NQ_R2);
+  const cd w1r = rot90<INV>(w1);
+  const cd w38 = INV ? cscale(cmake(w1r.x - w1r.y, w1r.x + w1r.y), NQ_R2) : cscale(cmake(w1r.x + w1r.y, w1r.y - w1r.x), NQ_R2);
+  bfly_tw(v[0], v[1], w1);      // X0, X4
+  bfly_tw(v[4], v[5], w18);     // X1, X5
+  bfly_tw(v[2], v[3], w1r);     // X2, X6
+  bfly_tw(v[6], v[7], w38);     // X3, X7
+  const cd x1 = v[4], x2 = v[2], x3 = v[6], x4 = v[1], x5 = v[5], x6 = v[3];
+  v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6;
+}
+
 // ---- radix plan -----------------------------------------------------------------------------
 __host__ __device__ constexpr int nq_min(int a, int b) { return a < b ? a : b; }
 // Radices are min(P, 16) except for one smaller "remainder" radix when N is not a power of it.  The remainder
@@ -333,9 +376,15 @@ struct WgFft {
       if constexpr (NS > 1) {
         cd w1, w4, w8;
         fetch_tw<STAGE>(twr, b, jr, w1, w4, w8);
-        twiddle_apply<R, INV>(v, w1, w4, w8);
+        if constexpr (R == 8) {
+          dft8_twiddled<INV>(v, w1, w4);
+        } else {
+          twiddle_apply<R, INV>(v, w1, w4, w8);
+          Dft<R, INV>::run(v);
+        }
+      } else {
+        Dft<R, INV>::run(v);
       }
-      Dft<R, INV>::run(v);
       if (LAST) {
 #pragma unroll
         for (int u = 0; u < R; ++u) r[b + u * NB] = v[u];
@@ -403,8 +452,12 @@ struct WgFft {
       for (int u = 0; u < R; ++u) v[u] = r[b + u * NB];
       const int jj = j + b * T;
       const int jr = jj % NS;
-      if constexpr (NS > 1) twiddle_apply<R, INV>(v, tw.w1[b], tw.w4[b], tw.w8[b]);
-      Dft<R, INV>::run(v);
+      if constexpr (NS > 1 && R == 8) {
+        dft8_twiddled<INV>(v, tw.w1[b], tw.w4[b]);
+      } else {
+        if constexpr (NS > 1) twiddle_apply<R, INV>(v, tw.w1[b], tw.w4[b], tw.w8[b]);
+        Dft<R, INV>::run(v);
+      }
       if (LAST) {
 #pragma unroll
         for (int u = 0; u < R; ++u) r[b + u * NB] = v[u];

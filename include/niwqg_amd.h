@@ -189,7 +189,7 @@ int nq_create_slab(const nq_params* p, const double* kk, const double* ll, const
 int nq_slab_info(const nq_ctx* ctx, int* info8);
 int nq_group_buffers(nq_ctx* ctx, int group, void** x_side, void** y_side, long long* elems);
 /* local column slab of qh (which 0: (ny, local half-spectrum columns)) or phih (which 1: (ny, nx/nranks)); download also
- * which 2: ph, 3: qwh (half-spectrum slabs like qh) */
+ * which 2: ph, 3: qwh, 4: the second copy of qh of a dual_q context (half-spectrum slabs like qh) */
 int nq_upload_spectral(nq_ctx* ctx, int which, const double* host);
 int nq_download_spectral(nq_ctx* ctx, int which, double* host);
 enum {

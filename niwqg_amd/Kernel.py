@@ -88,13 +88,12 @@ class Kernel(object):
             slab = int(os.environ.get("WORLD_SIZE", "1")) > 1
         phys = dict(U=U, f=f, kappa2=self.kappa2, nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw)
         if slab:
-            if self._dual:
-                raise NotImplementedError("dealias=True / exact_qh=True need the dual-copy q equation: single-rank only")
             if self.model_id == _lib.YBJ:
                 raise NotImplementedError("YBJModel is single-rank only")
             from .slab import SlabContext
             self._ctx = SlabContext(self.model_id, nx, self.kk, self.ll, self.filtr, dt, peers=(slab if slab is not True else None),
-                                    nchunks=nchunks, device=(device if slab is not True else None), budgets=budgets, **phys)
+                                    nchunks=nchunks, device=(device if slab is not True else None), budgets=budgets,
+                                    dual_q=self._dual, **phys)
         else:
             self._ctx = _lib.Context(self.model_id, nx, self.kk, self.ll, self.filtr, dt, budgets=budgets, device=device,
                                      dual_q=self._dual, **phys)

@@ -300,6 +300,20 @@ __global__ void k_expand_half(const cd* __restrict__ f1, const cd* __restrict__ 
   out[(size_t)l * wout + k] = a;
 }
 
+// the same on a column slab whose first column is global column k0
+__global__ void k_avg_interior_g(const cd* __restrict__ a, const cd* __restrict__ b, cd* __restrict__ out, int width,
+                                 int pitch, int N, int k0) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+  if (k >= width) return;
+  const size_t idx = (size_t)l * pitch + k;
+  cd v = a[idx];
+  if (k0 + k > 0 && k0 + k < N / 2) {
+    const cd w = b[idx];
+    v = cmake(0.5 * (v.x + w.x), 0.5 * (v.y + w.y));
+  }
+  out[idx] = v;
+}
+
 // reductions: sum over a real/complex plane of a pointwise expression; result in out[0..] via atomics
 // kind 0: sum |a|^2 (complex plane, width N)       -> out[0]
 // kind 1: sum weight_k * wv2 * |a|^2 (half spectrum psi -> 2*ke_qg*M^2), skipping [0,0]
@@ -2048,9 +2062,10 @@ int nq_upload_spectral(nq_ctx* c, int which, const double* host) {
 int nq_download_spectral(nq_ctx* c, int which, double* host) {
   if (!c || !host) return -1;
   HIPCHK(c, hipSetDevice(c->device));
-  if (which == 0 || which == 2 || which == 3) {      // half-spectrum planes: qh, ph, qwh
+  if (which == 0 || which == 2 || which == 3 || which == 4) {      // half-spectrum planes: qh, ph, qwh, second copy of qh
     if (which == 3 && c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qwh exists only in the coupled model");
-    const cd* src = which == 0 ? c->q.y[c->q.cur] : (which == 2 ? c->ph : c->qwh);
+    if (which == 4 && !c->dual) NQ_FAIL(c, -4, "no second copy of qh in this context (dual_q)");
+    const cd* src = which == 0 ? c->q.y[c->q.cur] : (which == 2 ? c->ph : (which == 3 ? c->qwh : c->q2.y[c->q2.cur]));
     if (c->Wh > 0) HIPCHK(c, hipMemcpy2DAsync(host, sizeof(cd) * c->Wh, src, sizeof(cd) * c->Ph, sizeof(cd) * c->Wh, c->N, hipMemcpyDeviceToHost, c->stream));
   } else if (which == 1) {
     if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
@@ -2188,7 +2203,7 @@ int nq_slab_config(nq_ctx* c, int nchunks) {
 int nq_slab_step(nq_ctx* c, int nsteps) {
   if (!c) return -1;
   if (c->ybj) NQ_FAIL(c, -4, "nq_slab_step: YBJModel is single-rank only");
-  if (c->passive || c->dual) NQ_FAIL(c, -4, "nq_slab_step: passive scalar / dual-copy q are single-rank only");
+  if (c->passive) NQ_FAIL(c, -4, "nq_slab_step: the passive scalar is single-rank only");
   if (nsteps < 0) NQ_FAIL(c, -1, "nq_slab_step: nsteps < 0");
   std::vector<nq_ctx*> grp;
   SLABTRY(slab_group(c, &grp));
@@ -2245,6 +2260,8 @@ int nq_slab_commit(nq_ctx* c, int which) {
     for (nq_ctx* x : grp) {
       launch_A_m(x, false, {&x->mUq});
       if (x->Wh > 0) launch_B_p(x, false, x->mUq.ys, x->mUq.pitch, x->q.y[x->q.cur], x->Ph, x->Wh, 1.0);
+      if (x->dual)      // q is real: both copies of the dual-copy equation start from the same half spectrum
+        HIPCHK(x, hipMemcpyAsync(x->q2.y[x->q2.cur], x->q.y[x->q.cur], sizeof(cd) * (size_t)x->N * x->Ph, hipMemcpyDeviceToDevice, x->stream));
     }
     if (c0->p.model == NQ_MODEL_COUPLED) {
       for (nq_ctx* x : grp) phase_wavepv(x);
@@ -2352,6 +2369,11 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
     double* d = x->diag_out;
     HIPCHK(x, hipMemsetAsync(d, 0, sizeof(double) * 40, x->stream));
     const cd* qh = x->q.y[x->q.cur];
+    if (x->dual) {                                  // physical space sees the mean of the two copies
+      if (!x->scr_h1) ALLOC(x, x->scr_h1, (size_t)N * x->Ph);
+      if (x->Wh > 0) hipLaunchKernelGGL(k_avg_interior_g, dim3((x->Wh + 63) / 64, N), dim3(64), 0, x->stream, qh, (const cd*)x->q2.y[x->q2.cur], x->scr_h1, x->Wh, x->Ph, N, x->kh0);
+      qh = x->scr_h1;
+    }
     if (waves) {
       const cd* phih = x->w.y[x->w.cur];
       hipLaunchKernelGGL(k_diag_phi, dim3(NB), dim3(256), 0, x->stream, phih, N, x->Wf, x->Wf, x->kf0, x->kk, x->ll, x->diag_part);

@@ -36,7 +36,7 @@ class SlabRank(object):
     def __init__(self, model, nx, kk, ll, filtr, dt, nranks, rank, device, budgets=True, torch_buffers=False, **phys):
         self.L = _lib.lib()
         self.model, self.nx, self.nranks, self.rank, self.device = model, int(nx), int(nranks), int(rank), int(device)
-        p = _lib.Params(model=model, nx=nx, budgets=int(bool(budgets)), dual_q=0, dt=dt,
+        p = _lib.Params(model=model, nx=nx, budgets=int(bool(budgets)), dual_q=int(bool(phys.get("dual_q", False))), dt=dt,
                         U=phys.get("U", 0.0), f=phys.get("f", 1e-4), kappa2=phys.get("kappa2", 1.0),
                         nu=phys.get("nu", 0.0), nu4=phys.get("nu4", 0.0), mu=phys.get("mu", 0.0),
                         nuw=phys.get("nuw", 0.0), nu4w=phys.get("nu4w", 0.0), muw=phys.get("muw", 0.0),
@@ -417,7 +417,7 @@ class SlabContext(object):
         if fid == L.F_QPSI:
             q = self.sim.gather_rows(L.F_Q)
             return q - self.sim.gather_rows(L.F_QW) if self.model == L.COUPLED else q
-        which = {L.F_QH: 0, L.F_PHIH: 1, L.F_PH: 2, L.F_QWH: 3}.get(fid)
+        which = {L.F_QH: 0, L.F_PHIH: 1, L.F_PH: 2, L.F_QWH: 3, L.F_QH_MINUS: 4}.get(fid)
         if which is None:
             raise RuntimeError("field %d is not available on a slab-decomposed model" % fid)
         return self.sim.gather_spectral(which)

@@ -120,8 +120,46 @@ def test_whole_plane_calls_fail_loudly_on_slabs():
         m.fft(np.zeros((128, 128), complex))
     with pytest.raises(NotImplementedError):
         m.jacobian_psi_q()
-    with pytest.raises(NotImplementedError):
-        niwqg_amd.CoupledModel.Model(slab=2, dealias=True, use_filter=False, nx=128)
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_dual_copy_q_equation_on_slabs(golden, P):
+    """dealias=True (the reference's 2/3 mask is not mirror-symmetric, g4) and exact_qh=True (g2) keep two copies of
+    the q equation per column slab; the full-plane qh assembled from both must equal the reference's."""
+    import niwqg_amd
+    g = golden("g4_quirks_64.npz")
+    nx = 64 * (P // 2)
+    if nx == 64:
+        kw = notebook_kwargs(64, False)
+        kw.update(dealias=True, nu4w=1e10, mu=1e-8, muw=2e-8)
+        m = niwqg_amd.CoupledModel.Model(slab=P, **kw)
+        m.set_q(g["rough_q0"])
+        m.set_phi(g["rough_phi0"])
+        steps(m, 5)
+        assert rel(m.q, g["rough_q"]) < 1e-11 and rel(m.phi, g["rough_phi"]) < 1e-11
+        assert rel(m.phih, g["rough_phih"]) < 1e-11
+        assert rel(m.qh, g["rough_qh"]) < 1e-11
+        assert np.allclose([m.Ke, m.Pw, m.Kw], g["rough_budgets"], rtol=1e-8)
+    g = golden("g2_coupled_%d_nofilter.npz" % nx)
+    m = niwqg_amd.CoupledModel.Model(slab=P, exact_qh=True, **notebook_kwargs(nx, False))
+    m.set_q(g["q0"])
+    m.set_phi(g["phi0"])
+    n = 10 if nx == 64 else 100
+    steps(m, n)
+    assert rel(m.qh, g["qh_%d" % n]) < 1e-12             # no row excluded
+    assert rel(m.q, g["q_%d" % n]) < 1e-12 and rel(m.phi, g["phi_%d" % n]) < 1e-12
+    assert np.allclose([m.Ke, m.Pw, m.Kw], g["budgets_%d" % n], rtol=1e-9)
+    # and the whole-plane dual model is the same computation
+    kw = notebook_kwargs(nx, False)
+    kw.update(dealias=True)
+    w = niwqg_amd.UnCoupledModel.Model(slab=False, **kw)
+    s = niwqg_amd.UnCoupledModel.Model(slab=P, **kw)
+    for x in (w, s):
+        x.set_q(g["q0"])
+        x.set_phi(g["phi0"])
+        steps(x, 7)
+    assert rel(s.qh, w.qh) < 1e-13 and rel(s.phi, w.phi) < 1e-13 and rel(s.q, w.q) < 1e-13
+    assert np.allclose([s.Ke, s.Pw, s.Kw], [w.Ke, w.Pw, w.Kw], rtol=1e-11)
 
 
 MODEL_WORKER = """

@@ -234,6 +234,10 @@ int nq_comm_unique_id(void* out128);
 int nq_comm_init(nq_ctx* ctx, const void* id128, int nranks, int rank);
 int nq_slab_attach_peers(nq_ctx* const* ctxs, int nranks);
 int nq_slab_set_callbacks(nq_ctx* ctx, nq_exchange_fn exchange, nq_allreduce_fn allreduce, void* user);
+/* YBJModel on more than one rank has a fifth exchange group (4, y -> x, shaped like group 1: the stage results whose
+ * gradients the next stage reads, YBJModel.py:52-87).  The library owns its buffers unless the caller hands over two
+ * device buffers of nq_group_elems(p, nranks, 4) complex elements here (callback link: the caller moves them). */
+int nq_slab_set_stage_buffers(nq_ctx* ctx, void* x_side, void* y_side);
 int nq_slab_config(nq_ctx* ctx, int nchunks);               /* 1, 2, 4 or 8; reduced if the local rows do not divide */
 int nq_slab_step(nq_ctx* ctx, int nsteps);
 int nq_slab_put_rows(nq_ctx* ctx, int which /* 0: q, 1: phi */, const double* rows);   /* local: rows -> x side       */

@@ -88,8 +88,6 @@ class Kernel(object):
             slab = int(os.environ.get("WORLD_SIZE", "1")) > 1
         phys = dict(U=U, f=f, kappa2=self.kappa2, nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw)
         if slab:
-            if self.model_id == _lib.YBJ:
-                raise NotImplementedError("YBJModel is single-rank only")
             from .slab import SlabContext
             self._ctx = SlabContext(self.model_id, nx, self.kk, self.ll, self.filtr, dt, peers=(slab if slab is not True else None),
                                     nchunks=nchunks, device=(device if slab is not True else None), budgets=budgets,

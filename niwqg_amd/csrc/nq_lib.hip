@@ -83,12 +83,13 @@ struct nq_ctx {
   int Wl = 0, kh0 = 0;   // half-spectrum planes: columns per rank, first global column of this rank
   // exchange groups: G[0] X->Y {Muq,Mvq,Mw}, G[1] Y->X {Mphi,Mphiy}, G[2] X->Y {Ma,Mb},
   // G[3] Y->X {Mu,Mp,Mq,Mqw}; Gs = stale copy of G[1]'s X side (UnCoupled's frozen phix/phiy, quirk Q1)
+  // G[4] (YBJModel on more than one rank): Gs with a y side of its own, the second G1-shaped group of do_step_ybj
   struct Group {
     cd *bx = nullptr, *by = nullptr;
     int pitch = 0;
     size_t elems = 0;
-  } G[4];
-  cd* Gs = nullptr;
+  } G[5];
+  cd *Gs = nullptr, *Gs_y = nullptr;
   MArr mUq, mVq, mW, mPhi, mPhiy, mGx, mGy, mA, mB, mU, mP, mQ, mQw;
   // scratch for the generic transforms / downloads
   cd *scr_f0 = nullptr, *scr_f1 = nullptr, *scr_h0 = nullptr, *scr_h1 = nullptr;
@@ -131,8 +132,8 @@ struct nq_ctx {
   int reserve_cus = 0;                 // CUs the persistent row kernels leave free (RCCL's copy kernels need somewhere to run:
                                        // a row-kernel workgroup owns the whole register file of its CU)
   hipStream_t mstream = nullptr;       // exchanges run here, beside the compute stream
-  hipEvent_t ev_prod[8] = {}, ev_arr[4][8] = {}, ev_col = nullptr, ev_done = nullptr, ev_red = nullptr;
-  bool arr_pending[4] = {false, false, false, false};   // group g is arriving chunk by chunk (ev_arr[g][*] recorded)
+  hipEvent_t ev_prod[8] = {}, ev_arr[5][8] = {}, ev_col = nullptr, ev_done = nullptr, ev_red = nullptr;
+  bool arr_pending[5] = {false, false, false, false, false};   // group g is arriving chunk by chunk (ev_arr[g][*] recorded)
   long long n_exch = 0, n_calls = 0, n_steps = 0;       // counters since nq_slab_counters(reset)
   double bytes_sent = 0.0;
   std::vector<hipEvent_t> xev;         // timing pairs around every exchange chunk on mstream (when counting)
@@ -1157,7 +1158,7 @@ static int slab_link_setup(nq_ctx* c) {        // exchange stream and events, on
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking));
   for (int i = 0; i < 8; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_prod[i], hipEventDisableTiming));
-  for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < 5; ++g)
     for (int i = 0; i < 8; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_arr[g][i], hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_col, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
@@ -1378,8 +1379,49 @@ static void phase_update_q(nq_ctx* c, int s) {
   launch_sq(c, eq, s);
 }
 
+// YBJModel's stage graph (do_step_ybj) on slabs: only the wave products cross x -> y (group 0); the stage results 0..2
+// come back in group 4 (gradients for the next stage), the new state in group 1
+static int slab_step_ybj(std::vector<nq_ctx*>& grp) {
+  nq_ctx* c0 = grp[0];
+  const int nch = effective_chunks(c0);
+  for (int s = 0; s < 4; ++s) {
+    for (int i = 0; i < nch; ++i) {
+      for (nq_ctx* c : grp) {
+        SLABTRY(wait_arrival(c, 3, i, nch));
+        SLABTRY(wait_arrival(c, 1, i, nch));
+        SLABTRY(wait_arrival(c, 4, i, nch));
+        set_window(c, i, nch);
+        launch_products(c, -1.0, -0.5, s == 0);
+        HIPCHK(c, hipEventRecord(c->ev_prod[i], c->stream));
+      }
+      SLABTRY(issue_chunk(grp, 0, true, i, nch));
+    }
+    for (nq_ctx* c : grp) {
+      set_window(c, 0, 1);
+      if (c->link != LINK_CALLBACK) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+      launch_A_m(c, false, {&c->mW});
+      int wslot = 0;
+      const int cur = c->w.cur;
+      const cd* y_start = (s == 0) ? c->w.y[cur] : (s == 1 ? c->w.y[(cur + 1) % 3] : c->w.y[(cur + 2) % 3]);
+      EtdArrays ew = etd_arrays(c->w, s, &wslot);
+      if (s < 3) {
+        launch_sphi(c, ew, s, y_start, &c->mGx, &c->mGy);
+        launch_A_m(c, true, {&c->mGx, &c->mGy});
+      } else {
+        launch_sphi(c, ew, s, y_start);
+        launch_A_m(c, true, {&c->mPhi, &c->mPhiy});
+      }
+      HIPCHK(c, hipEventRecord(c->ev_col, c->stream));
+    }
+    for (int i = 0; i < nch; ++i) SLABTRY(issue_chunk(grp, s < 3 ? 4 : 1, false, i, nch));
+  }
+  for (nq_ctx* c : grp) c->n_steps += 1;
+  return 0;
+}
+
 static int slab_step_once(std::vector<nq_ctx*>& grp) {
   nq_ctx* c0 = grp[0];
+  if (c0->ybj) return slab_step_ybj(grp);
   const bool coupled = c0->p.model == NQ_MODEL_COUPLED, waves = c0->kernel_family;
   const int nch = effective_chunks(c0);
   for (int s = 0; s < 4; ++s) {
@@ -1443,7 +1485,7 @@ static int slab_step_once(std::vector<nq_ctx*>& grp) {
 static int slab_settle(std::vector<nq_ctx*>& grp) {
   for (nq_ctx* c : grp) {
     const int sent = effective_chunks(c);
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 5; ++g)
       if (c->arr_pending[g]) {
         for (int i = 0; i < sent; ++i) SLABTRY(wait_arrival(c, g, i, sent));
         c->arr_pending[g] = false;
@@ -1530,8 +1572,9 @@ static SlabGeom slab_geom(const nq_params* p, int P) {
 }
 
 long long nq_group_elems(const nq_params* p, int nranks, int group) {
-  if (!p || group < 0 || group > 3 || nranks < 1 || p->nx % nranks) return -1;
+  if (!p || group < 0 || group > 4 || nranks < 1 || p->nx % nranks) return -1;
   const SlabGeom g = slab_geom(p, nranks);
+  if (group == 4) return (p->model == NQ_MODEL_YBJ && nranks > 1) ? (long long)g.N * g.npitch[1] : 0;
   return (long long)g.N * g.npitch[group];       // one side: P blocks of Nloc rows = N rows of `pitch`
 }
 
@@ -1563,7 +1606,6 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
   nq_params pp = *p_in;
   const bool ybj = pp.model == NQ_MODEL_YBJ;
   if (ybj) {
-    if (P != 1) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create_slab: YBJModel is single-rank only");
     pp.model = NQ_MODEL_UNCOUPLED;
     pp.budgets = 0;
   }
@@ -1790,8 +1832,17 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
     c->mGy = c->mPhiy;
     if (c->p.model == NQ_MODEL_UNCOUPLED) {        // frozen copy of the X side of G1 (quirk Q1)
       ALLOC(c, c->Gs, c->G[1].elems);
-      c->mGx = make_marr(sg, c->Gs, c->Gs, 1, 0, false);
-      c->mGy = make_marr(sg, c->Gs, c->Gs, 1, 1, false);
+      cd* gsy = c->Gs;
+      if (ybj && P > 1) {                          // its stage results cross y -> x in a group of their own
+        ALLOC(c, c->Gs_y, c->G[1].elems);
+        gsy = c->Gs_y;
+        c->G[4].bx = c->Gs;
+        c->G[4].by = c->Gs_y;
+        c->G[4].pitch = c->G[1].pitch;
+        c->G[4].elems = c->G[1].elems;
+      }
+      c->mGx = make_marr(sg, c->Gs, gsy, 1, 0, false);
+      c->mGy = make_marr(sg, c->Gs, gsy, 1, 1, false);
     }
     if (c->bud) {
       c->nww = (c->Wf / CL) * c->S2;
@@ -2086,7 +2137,7 @@ int nq_download_spectral(nq_ctx* c, int which, double* host) {
 //   NQ_PH_BUDGET_FINISH    RK-weighted accumulation from the (reduced) sums
 int nq_phase(nq_ctx* c, int phase, int stage) {
   if (!c) return -1;
-  if (c->ybj) NQ_FAIL(c, -4, "nq_phase: YBJModel is single-rank only");
+  if (c->ybj) NQ_FAIL(c, -4, "nq_phase: YBJModel has a stage graph of its own (nq_step, nq_slab_step)");
   if (stage < 0 || stage > 3) NQ_FAIL(c, -1, "nq_phase: stage %d", stage);
   HIPCHK(c, hipSetDevice(c->device));
   switch (phase) {
@@ -2191,6 +2242,21 @@ int nq_slab_set_callbacks(nq_ctx* c, nq_exchange_fn exchange, nq_allreduce_fn al
   c->link = LINK_CALLBACK;
   return slab_link_setup(c);
 }
+// caller-owned buffers for exchange group 4 (as ext_buffers of nq_create_slab for groups 0..3), before the first step
+int nq_slab_set_stage_buffers(nq_ctx* c, void* bx, void* by) {
+  if (!c || !bx || !by) return -1;
+  if (!c->ybj || c->P == 1) NQ_FAIL(c, -4, "nq_slab_set_stage_buffers: only YBJModel on more than one rank has exchange group 4");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const SlabGeom sg = slab_geom(&c->p, c->P);
+  c->Gs = c->G[4].bx = reinterpret_cast<cd*>(bx);
+  c->Gs_y = c->G[4].by = reinterpret_cast<cd*>(by);
+  HIPCHK(c, hipMemsetAsync(c->Gs, 0, c->G[4].elems * sizeof(cd), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->Gs_y, 0, c->G[4].elems * sizeof(cd), c->stream));
+  c->mGx = make_marr(sg, c->Gs, c->Gs_y, 1, 0, false);
+  c->mGy = make_marr(sg, c->Gs, c->Gs_y, 1, 1, false);
+  return nq_sync(c);
+}
 int nq_slab_config(nq_ctx* c, int nchunks) {
   if (!c) return -1;
   if (nchunks != 1 && nchunks != 2 && nchunks != 4 && nchunks != 8) NQ_FAIL(c, -1, "nq_slab_config: nchunks = %d (1, 2, 4 or 8)", nchunks);
@@ -2202,7 +2268,6 @@ int nq_slab_config(nq_ctx* c, int nchunks) {
 }
 int nq_slab_step(nq_ctx* c, int nsteps) {
   if (!c) return -1;
-  if (c->ybj) NQ_FAIL(c, -4, "nq_slab_step: YBJModel is single-rank only");
   if (c->passive) NQ_FAIL(c, -4, "nq_slab_step: the passive scalar is single-rank only");
   if (nsteps < 0) NQ_FAIL(c, -1, "nq_slab_step: nsteps < 0");
   std::vector<nq_ctx*> grp;

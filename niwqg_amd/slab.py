@@ -42,7 +42,7 @@ class SlabRank(object):
                         nuw=phys.get("nuw", 0.0), nu4w=phys.get("nu4w", 0.0), muw=phys.get("muw", 0.0),
                         beta=phys.get("beta", 0.0))
         self.budgets = bool(budgets)
-        self.gx, self.gy, self.sums = [None] * 4, [None] * 4, None
+        self.gx, self.gy, self.sums = [None] * 5, [None] * 5, None
         ext = None
         if torch_buffers:
             import torch
@@ -76,6 +76,13 @@ class SlabRank(object):
         info = (ctypes.c_int * 8)()
         self.L.nq_slab_info(self.h, info)
         (_, _, self.nloc, self.wf, self.kf0, self.wh, self.kh0, self.ph) = list(info)
+        if torch_buffers and model == _lib.YBJ and nranks > 1:          # the stage-result group of YBJModel's step
+            n = self.L.nq_group_elems(ctypes.byref(p), nranks, 4)
+            self.gx[4] = torch.zeros(n, dtype=torch.complex128, device=dev)
+            self.gy[4] = torch.zeros(n, dtype=torch.complex128, device=dev)
+            torch.cuda.synchronize(dev)
+            self._chk(self.L.nq_slab_set_stage_buffers(self.h, ctypes.c_void_p(self.gx[4].data_ptr()),
+                                                       ctypes.c_void_p(self.gy[4].data_ptr())), "nq_slab_set_stage_buffers")
 
     def _chk(self, rc, what):
         if rc != 0:

@@ -182,6 +182,24 @@ eq, ep = rel(m.q, g["q_100"]), rel(m.phi, g["phi_100"])
 assert eq < 1e-12 and ep < 1e-12, (eq, ep)
 assert np.allclose([m.Ke, m.Pw, m.Kw], g["budgets_100"], rtol=1e-9)
 assert abs(m._calc_cfl() - float(np.max([np.abs(m.u).max(), np.abs(m.v).max(), np.abs(m.phi).max()])) * m.dt / m.dx) < 1e-12
+# YBJModel: its fifth exchange group crosses through the same callbacks (golden g8)
+g8 = np.load(%r, allow_pickle=False)
+kw = notebook_kwargs(64, True, tdiags=10 ** 9)
+kw.update(nu4w=3e9, muw=1e-7)
+y = niwqg_amd.YBJModel.Model(**kw)
+y.set_q(g8["q0"])
+y.set_phi(g8["phi0"])
+y.tmax = 19.5 * y.dt
+y.run()
+assert rel(y.phi, g8["phi_tdinf_filter"]) < 1e-12 and rel(y.phix, g8["phix_tdinf_filter"]) < 1e-12
+# dual-copy q equation (exact_qh) on two processes
+g2 = np.load(%r, allow_pickle=False)
+d = niwqg_amd.CoupledModel.Model(exact_qh=True, **notebook_kwargs(64, False))
+d.set_q(g2["q0"])
+d.set_phi(g2["phi0"])
+while d.tc < 10:
+    d._step_forward()
+assert rel(d.qh, g2["qh_10"]) < 1e-12 and rel(d.phi, g2["phi_10"]) < 1e-12
 if m._ctx.group.rank == 0:
     print("two-process model agrees with the reference golden")
 m._ctx.group.close()
@@ -197,10 +215,55 @@ def test_model_api_in_two_processes_over_gloo(tmp_path):
     from conftest import free_port, GOLDEN
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "model_worker.py"
-    script.write_text(MODEL_WORKER % (root, os.path.join(root, "tests"), os.path.join(GOLDEN, "g2_coupled_128_filter.npz")))
+    script.write_text(MODEL_WORKER % (root, os.path.join(root, "tests"), os.path.join(GOLDEN, "g2_coupled_128_filter.npz"),
+                                      os.path.join(GOLDEN, "g8_ybj_64.npz"), os.path.join(GOLDEN, "g2_coupled_64_nofilter.npz")))
     env = dict(os.environ, NIWQG_AMD_DIST_BACKEND="gloo")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "two-process model agrees with the reference golden" in out.stdout
+
+
+@pytest.mark.parametrize("td_tag,td", [("td1", 1), ("tdinf", 10 ** 9)])
+@pytest.mark.parametrize("use_filter", [True, False])
+def test_ybj_model_on_slabs_against_the_reference(golden, td_tag, td, use_filter):
+    """golden g8 (niwqg.YBJModel run by the reference) through Model(slab=2): the stage results 0..2 cross y -> x in an
+    exchange group of their own, so the stale phix / phiy a step leaves behind are the reference's as well."""
+    import niwqg_amd
+    g = golden("g8_ybj_64.npz")
+    key = "%s_%s" % (td_tag, "filter" if use_filter else "nofilter")
+    kw = notebook_kwargs(64, use_filter, tdiags=td)
+    kw.update(nu4w=3e9, muw=1e-7)
+    m = niwqg_amd.YBJModel.Model(slab=2, **kw)
+    m.set_q(g["q0"])
+    m.set_phi(g["phi0"])
+    m.tmax = 19.5 * m.dt
+    m.run()
+    assert m.tc == 20
+    assert rel(m.phi, g["phi_" + key]) < 1e-12 and rel(m.phih, g["phih_" + key]) < 1e-12
+    assert rel(m.phix, g["phix_" + key]) < 1e-12 and rel(m.phiy, g["phiy_" + key]) < 1e-12
+    assert np.allclose([m.Ke, m.Pw, m.Kw, m._calc_ke_niw(), m._calc_ke_qg()], g["scalars_" + key], rtol=1e-11)
+    if td == 1:
+        for name in m.diagnostics:
+            ref = g["diag_%s_%s" % (name, key)]
+            got = np.asarray(m.diagnostics[name]['value'])
+            assert np.allclose(got, ref, rtol=1e-8, atol=1e-12 if name in ("skew", "conc_niw") else 1e-30), name
+
+
+def test_ybj_model_on_four_slabs_equals_the_whole_plane_model():
+    import niwqg_amd
+    from niwqg_amd import InitialConditions as ic
+    kw = notebook_kwargs(256, True)
+    kw.update(nu4w=3e9, muw=1e-7)
+    w = niwqg_amd.YBJModel.Model(slab=False, **kw)
+    q0 = ic.LambDipole(w, U=U0, R=2 * np.pi / K0)
+    phi0 = ic.WavePacket(w, k=3 * K0, l=K0, R=L / 6, x0=L / 3, y0=L / 2)
+    for nch in (1, 2):
+        s = niwqg_amd.YBJModel.Model(slab=4, nchunks=nch, **kw)
+        for x in ((w, s) if nch == 1 else (s,)):
+            x.set_q(q0)
+            x.set_phi(phi0)
+            steps(x, 12)
+        assert rel(s.phi, w.phi) < 1e-13 and rel(s.phix, w.phix) < 1e-13 and rel(s.phiy, w.phiy) < 1e-13
+        assert rel(s.q, w.q) < 1e-13 and rel(s.u, w.u) < 1e-13

@@ -189,7 +189,8 @@ int nq_create_slab(const nq_params* p, const double* kk, const double* ll, const
 int nq_slab_info(const nq_ctx* ctx, int* info8);
 int nq_group_buffers(nq_ctx* ctx, int group, void** x_side, void** y_side, long long* elems);
 /* local column slab of qh (which 0: (ny, local half-spectrum columns)) or phih (which 1: (ny, nx/nranks)); download also
- * which 2: ph, 3: qwh, 4: the second copy of qh of a dual_q context (half-spectrum slabs like qh) */
+ * which 2: ph, 3: qwh, 4: the second copy of qh of a dual_q context, 5: ch of QGModel's passive scalar (half-spectrum
+ * slabs like qh) */
 int nq_upload_spectral(nq_ctx* ctx, int which, const double* host);
 int nq_download_spectral(nq_ctx* ctx, int which, double* host);
 enum {
@@ -226,7 +227,7 @@ int nq_reduce_write(nq_ctx* ctx, int which, const double* host_in);
  * nq_slab_put_rows + nq_slab_commit: Kernel.set_q / set_phi (Kernel.py:520-551) from this rank's ROWS of the physical
  * field (nloc rows of nx values, real / complex): row transform on the device (put_rows, local), then exchange, column
  * transform and the phases of the single-rank calls (commit, collective) -- no rank ever holds or transforms the whole plane.
- * nq_slab_get_rows: this rank's rows (nloc, nx) of a physical field (NQ_F_Q, _P, _U, _V, _QW, _QPSI real; _PHI, _PHIX,
+ * nq_slab_get_rows: this rank's rows (nloc, nx) of a physical field (NQ_F_Q, _P, _U, _V, _QW, _QPSI, _C real; _PHI, _PHIX,
  * _PHIY complex) from the mixed-space rows the last step left on the x side. */
 typedef int (*nq_exchange_fn)(void* user, int group, int to_y);
 typedef int (*nq_allreduce_fn)(void* user, int which);      /* which: as nq_reduce_buffer; 4: the 32 diagnostic sums */
@@ -240,9 +241,10 @@ int nq_slab_set_callbacks(nq_ctx* ctx, nq_exchange_fn exchange, nq_allreduce_fn 
 int nq_slab_set_stage_buffers(nq_ctx* ctx, void* x_side, void* y_side);
 int nq_slab_config(nq_ctx* ctx, int nchunks);               /* 1, 2, 4 or 8; reduced if the local rows do not divide */
 int nq_slab_step(nq_ctx* ctx, int nsteps);
-int nq_slab_put_rows(nq_ctx* ctx, int which /* 0: q, 1: phi */, const double* rows);   /* local: rows -> x side       */
+int nq_slab_put_rows(nq_ctx* ctx, int which /* 0: q, 1: phi, 2: c */, const double* rows);   /* local: rows -> x side */
 int nq_slab_commit(nq_ctx* ctx, int which);   /* collective: the rest of set_q / set_phi (rank-0 context in peers mode);
-                                                  which 2: Kernel._invert on the current state, nothing uploaded */
+                                                  which 2: Kernel._invert on the current state, nothing uploaded;
+                                                  which 3: the rest of QGModel.set_c (QGModel.py:522-534) after put_rows(2) */
 int nq_slab_get_rows(nq_ctx* ctx, int field_id, double* rows_out);
 /* nq_diagnostics of a slab-decomposed simulation: the same 32 sums, every rank's part summed over the ranks (collective);
  * nq_slab_local_max: max|u|, max|v|, max|phi| over this rank's rows (the caller takes the max over ranks for the CFL) */

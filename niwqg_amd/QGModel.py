@@ -44,12 +44,11 @@ class Model(object):
         if slab is None:                 # under torch.distributed.run the model is slab-decomposed over the ranks (Kernel.py)
             slab = int(os.environ.get("WORLD_SIZE", "1")) > 1
         if slab:
-            if passive_scalar:
-                raise NotImplementedError("passive_scalar=True is single-rank only")
             from .slab import SlabContext
             self._ctx = SlabContext(_lib.QG, nx, self.kk, self.ll, self.filtr, dt, peers=(slab if slab is not True else None),
                                     nchunks=nchunks, device=(device if slab is not True else None), budgets=budgets,
-                                    U=U, nu=nu, nu4=nu4, mu=mu, beta=beta)
+                                    U=U, nu=nu, nu4=nu4, mu=mu, beta=beta, passive_scalar=passive_scalar, nu4c=nu4c,
+                                    nuc=nuc, muc=muc)
         else:
             self._ctx = _lib.Context(_lib.QG, nx, self.kk, self.ll, self.filtr, dt, U=U, nu=nu, nu4=nu4, mu=mu,
                                      beta=beta, budgets=budgets, device=device, passive_scalar=passive_scalar,

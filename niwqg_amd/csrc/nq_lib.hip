@@ -432,20 +432,20 @@ __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, 
 
 // passive scalar of QGModel: S_n = sum w wv2^n |c-hat|^2, n = 0..3, over the half spectrum (w = 1 on the self-mirrored columns,
 // 2 elsewhere; n = 0 without the [0,0] entry, like spec_var): C2, gradC2, mean(lap c ^2), -mean(lap^2 c lap c)
-__global__ void k_diag_c(const cd* __restrict__ ch, int N, int width, int pitch, const double* __restrict__ kk,
+__global__ void k_diag_c(const cd* __restrict__ ch, int N, int width, int pitch, int k0, const double* __restrict__ kk,
                          const double* __restrict__ ll, double* __restrict__ part) {
   // n = 0, 1 are spec_var sums of c-hat as it is (C2, gradC2); n = 2, 3 stand for physical-space means of lap c, which only
   // sees the Hermitian part (in l) of the two self-mirrored columns -- what irfft2 keeps
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   const size_t total = (size_t)N * width;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int l = (int)(i / width), k = (int)(i - (size_t)l * width);
-    const cd z = ch[(size_t)l * pitch + k];
+    const int l = (int)(i / width), kl = (int)(i - (size_t)l * width), k = k0 + kl;
+    const cd z = ch[(size_t)l * pitch + kl];
     cd h = z;
     double wt = 2.0;
     if (k == 0 || k == N / 2) {
       wt = 1.0;
-      const cd zm = ch[(size_t)((N - l) % N) * pitch + k];
+      const cd zm = ch[(size_t)((N - l) % N) * pitch + kl];
       h = cmake(0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y));
     }
     const double kx = kk[k], ly = ll[l], wv2 = kx * kx + ly * ly;
@@ -1609,8 +1609,6 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
     pp.model = NQ_MODEL_UNCOUPLED;
     pp.budgets = 0;
   }
-  if (pp.model == NQ_MODEL_QG && pp.passive_scalar != 0 && P != 1)
-    NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create_slab: QGModel's passive scalar is single-rank only");
   const nq_params* p = &pp;
   int S1, S2;
   if (!plan_for(p->nx, &S1, &S2)) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d unsupported (power of two in [64, 8192])", p->nx);
@@ -2113,10 +2111,11 @@ int nq_upload_spectral(nq_ctx* c, int which, const double* host) {
 int nq_download_spectral(nq_ctx* c, int which, double* host) {
   if (!c || !host) return -1;
   HIPCHK(c, hipSetDevice(c->device));
-  if (which == 0 || which == 2 || which == 3 || which == 4) {      // half-spectrum planes: qh, ph, qwh, second copy of qh
+  if (which == 0 || which == 2 || which == 3 || which == 4 || which == 5) {      // half-spectrum planes: qh, ph, qwh, second copy of qh, ch
     if (which == 3 && c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qwh exists only in the coupled model");
     if (which == 4 && !c->dual) NQ_FAIL(c, -4, "no second copy of qh in this context (dual_q)");
-    const cd* src = which == 0 ? c->q.y[c->q.cur] : (which == 2 ? c->ph : (which == 3 ? c->qwh : c->q2.y[c->q2.cur]));
+    if (which == 5 && !c->passive) NQ_FAIL(c, -4, "no passive scalar in this context");
+    const cd* src = which == 0 ? c->q.y[c->q.cur] : (which == 2 ? c->ph : (which == 3 ? c->qwh : (which == 4 ? c->q2.y[c->q2.cur] : c->cq.y[c->cq.cur])));
     if (c->Wh > 0) HIPCHK(c, hipMemcpy2DAsync(host, sizeof(cd) * c->Wh, src, sizeof(cd) * c->Ph, sizeof(cd) * c->Wh, c->N, hipMemcpyDeviceToHost, c->stream));
   } else if (which == 1) {
     if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
@@ -2268,13 +2267,14 @@ int nq_slab_config(nq_ctx* c, int nchunks) {
 }
 int nq_slab_step(nq_ctx* c, int nsteps) {
   if (!c) return -1;
-  if (c->passive) NQ_FAIL(c, -4, "nq_slab_step: the passive scalar is single-rank only");
   if (nsteps < 0) NQ_FAIL(c, -1, "nq_slab_step: nsteps < 0");
   std::vector<nq_ctx*> grp;
   SLABTRY(slab_group(c, &grp));
   for (nq_ctx* x : grp) HIPCHK(x, hipSetDevice(x->device));
   c->n_calls += 1;
   for (int i = 0; i < nsteps; ++i) SLABTRY(slab_step_once(grp));
+  if (nsteps > 0)
+    for (nq_ctx* x : grp) x->stepped = true;
   SLABTRY(slab_settle(grp));
   for (nq_ctx* x : grp) HIPCHK(x, hipGetLastError());
   return 0;
@@ -2293,7 +2293,8 @@ int nq_slab_put_rows(nq_ctx* c, int which, const double* rows) {
   cd* scr = nullptr;
   SLABTRY(rows_scratch(c, &scr));
   const size_t n = (size_t)c->Nloc * c->N;
-  if (which == 0) {
+  if (which == 2 && !c->passive) NQ_FAIL(c, -4, "nq_slab_put_rows: this context has no passive scalar");
+  if (which == 0 || which == 2) {
     HIPCHK(c, hipMemcpyAsync(scr, rows, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     switch (c->N) {
 #define CASE_(nn, a, b) case nn: { typedef XPlan<nn> X; hipLaunchKernelGGL((k_x_put_real<nn, true>), dim3((c->Nloc + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, (const double*)scr, c->mUq, c->Nloc, c->tw); } break;
@@ -2333,7 +2334,7 @@ int nq_slab_commit(nq_ctx* c, int which) {
       SLABTRY(exchange_now(grp, 2, true));
     }
     for (nq_ctx* x : grp) {
-      phase_invert_y(x, x->q.y[x->q.cur], true, x->part0Q, nullptr);
+      phase_invert_y(x, x->q.y[x->q.cur], true, x->part0Q, nullptr, x->passive ? x->cq.y[x->cq.cur] : nullptr);
       if (x->bud && x->kernel_family)
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->part0Q, x->nwq, 3, 3, x->carryQ);
       x->have_q = true;
@@ -2354,13 +2355,21 @@ int nq_slab_commit(nq_ctx* c, int which) {
     SLABTRY(exchange_now(grp, 1, false));
     if (c0->bud) SLABTRY(slab_allreduce(grp, 1));
     for (nq_ctx* x : grp) SLABTRY(nq_refresh_grad_phi(x));
-  } else if (which == 2) {                      // Kernel._invert on the current state (CoupledModel.py:75-97 / UnCoupledModel.py:54-64)
+  } else if (which == 2 || which == 3) {        // Kernel._invert on the current state (CoupledModel.py:75-97 / UnCoupledModel.py:54-64)
+    if (which == 3) {                           // QGModel.set_c (QGModel.py:476-480): the scalar's spectrum first
+      if (!c0->passive) NQ_FAIL(c, -4, "nq_slab_commit: this context has no passive scalar");
+      SLABTRY(exchange_now(grp, 0, true));
+      for (nq_ctx* x : grp) {
+        launch_A_m(x, false, {&x->mUq});
+        if (x->Wh > 0) launch_B_p(x, false, x->mUq.ys, x->mUq.pitch, x->cq.y[x->cq.cur], x->Ph, x->Wh, 1.0);
+      }
+    }
     if (c0->p.model == NQ_MODEL_COUPLED) {
       for (nq_ctx* x : grp) phase_wavepv(x);
       SLABTRY(exchange_now(grp, 2, true));
     }
     for (nq_ctx* x : grp) {
-      phase_invert_y(x, x->q.y[x->q.cur], true, x->part0Q, nullptr);
+      phase_invert_y(x, x->q.y[x->q.cur], true, x->part0Q, nullptr, x->passive ? x->cq.y[x->cq.cur] : nullptr);
       if (x->bud && x->kernel_family)
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->part0Q, x->nwq, 3, 3, x->carryQ);
     }
@@ -2392,6 +2401,10 @@ int nq_slab_get_rows(nq_ctx* c, int id, double* out) {
     case NQ_F_QW:
       if (c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qw exists only in the coupled model");
       src = &c->mQw;
+      break;
+    case NQ_F_C:
+      if (!c->passive) NQ_FAIL(c, -4, "no passive scalar in this context");
+      src = &c->mQw;                            // the scalar rides in the qw slot of group 3
       break;
     case NQ_F_PHI: src = &c->mPhi; real = false; break;
     case NQ_F_PHIX: src = &c->mGx; real = false; mul_ik = 1; break;
@@ -2465,6 +2478,39 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
   for (int i = 15; i < 32; ++i) out[i] = 0.0;
   const double qbar = h[15] / M, abar = h[0] / (M * M);
   out[15] = qbar;
+  if (!waves && c0->passive) {
+    // as in nq_diagnostics: [16..19] the |c-hat|^2 sums, [20] the Gamma_c projection with the u, v of the fourth stage
+    for (nq_ctx* x : grp) {
+      const cd* ch = x->cq.y[x->cq.cur];
+      if (x->Wh > 0) {
+        hipLaunchKernelGGL(k_diag_c, dim3(NB), dim3(256), 0, x->stream, ch, N, x->Wh, x->Ph, x->kh0, x->kk, x->ll, x->diag_part);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, NB, 4, 4, x->diag_out + 16);
+      }
+      const cd* qh4 = x->stepped ? x->q.y[(x->q.cur + 2) % 3] : x->q.y[x->q.cur];
+      phase_invert_y(x, qh4, false, x->part0Q, nullptr, ch);
+    }
+    SLABTRY(exchange_now(grp, 3, false));
+    for (nq_ctx* x : grp) launch_products(x);
+    SLABTRY(exchange_now(grp, 0, true));
+    for (nq_ctx* x : grp) {
+      launch_A_m(x, false, {&x->mUc, &x->mVc});
+      const YGeom g = geom_half(x);
+      if (g.width <= 0) continue;
+      const int nwc = ((g.width + CL - 1) / CL) * x->S2;
+#define CALL_(sz) hipLaunchKernelGGL((k_s_project_c<sz>), dim3((g.width + CL - 1) / CL, x->S2), dim3(YPlan<sz>::THREADS), YPlan<sz>::LDS_BYTES, x->stream, x->mUc, x->mVc, x->cq.y[x->cq.cur], g, x->kk, x->ll, x->tw, 1, x->diag_part)
+      NQ_S1_SWITCH(x, CALL_)
+#undef CALL_
+      hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, nwc, 1, 1, x->diag_out + 20);
+    }
+    for (nq_ctx* x : grp)                           // the mixed-space rows of the CURRENT state again, for the next step
+      phase_invert_y(x, x->q.y[x->q.cur], true, x->part0Q, nullptr, x->cq.y[x->cq.cur]);
+    SLABTRY(exchange_now(grp, 3, false));
+    SLABTRY(slab_allreduce(grp, 5));
+    HIPCHK(c0, hipMemcpyAsync(out + 16, c0->diag_out + 16, sizeof(double) * 5, hipMemcpyDeviceToHost, c0->stream));
+    SLABTRY(slab_settle(grp));
+    for (nq_ctx* x : grp) SLABTRY(nq_sync(x));
+    return 0;
+  }
   if (!waves) return 0;
   for (nq_ctx* x : grp) {
     if (coupled) launch_xdiag_m<MODE_COUPLED>(x, qbar, abar, x->diag_part);
@@ -2927,7 +2973,7 @@ int nq_diagnostics(nq_ctx* c, double* out) {
   if (!waves && c->passive) {
     // QGModel's passive scalar (ref QGModel.py:724-737, :595-604): [16..19] the four |c-hat|^2 sums, [20] the Gamma_c projection
     const cd* ch = c->cq.y[c->cq.cur];
-    hipLaunchKernelGGL(k_diag_c, dim3(NB), dim3(256), 0, c->stream, ch, N, c->Wh, c->Ph, c->kk, c->ll, c->diag_part);
+    hipLaunchKernelGGL(k_diag_c, dim3(NB), dim3(256), 0, c->stream, ch, N, c->Wh, c->Ph, 0, c->kk, c->ll, c->diag_part);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, NB, 4, 4, d + 16);
     // jacobian_psi_c with the u, v the reference still holds at a tick: those of the state at which the last step evaluated
     // its fourth stage (QGModel.py:375 vs :396); before any step, those of the current state

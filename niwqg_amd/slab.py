@@ -25,7 +25,7 @@ from . import _lib
 (PH_PRODUCTS, PH_UPDATE, PH_WAVEPV, PH_INVERT, PH_EMIT_PHI, PH_INVERT_NOW, PH_BUDGET_SUMS,
  PH_BUDGET_FINISH) = range(8)
 
-_REAL_ROWS = (_lib.F_Q, _lib.F_P, _lib.F_U, _lib.F_V, _lib.F_QW)
+_REAL_ROWS = (_lib.F_Q, _lib.F_P, _lib.F_U, _lib.F_V, _lib.F_QW, _lib.F_C)
 _CPLX_ROWS = (_lib.F_PHI, _lib.F_PHIX, _lib.F_PHIY)
 
 
@@ -40,7 +40,9 @@ class SlabRank(object):
                         U=phys.get("U", 0.0), f=phys.get("f", 1e-4), kappa2=phys.get("kappa2", 1.0),
                         nu=phys.get("nu", 0.0), nu4=phys.get("nu4", 0.0), mu=phys.get("mu", 0.0),
                         nuw=phys.get("nuw", 0.0), nu4w=phys.get("nu4w", 0.0), muw=phys.get("muw", 0.0),
-                        beta=phys.get("beta", 0.0))
+                        beta=phys.get("beta", 0.0),
+                        passive_scalar=int(bool(phys.get("passive_scalar", False)) and model == _lib.QG),
+                        nu4c=phys.get("nu4c", 0.0), nuc=phys.get("nuc", 0.0), muc=phys.get("muc", 0.0))
         self.budgets = bool(budgets)
         self.gx, self.gy, self.sums = [None] * 5, [None] * 5, None
         ext = None
@@ -102,7 +104,7 @@ class SlabRank(object):
         return out
 
     def put_rows(self, which, rows):
-        rows = np.ascontiguousarray(rows, np.float64 if which == 0 else np.complex128)
+        rows = np.ascontiguousarray(rows, np.complex128 if which == 1 else np.float64)     # 0: q, 1: phi, 2: c
         assert rows.shape == (self.nloc, self.nx), rows.shape
         self._chk(self.L.nq_slab_put_rows(self.h, which, _lib._dptr(rows.view(np.float64))), "nq_slab_put_rows")
 
@@ -259,6 +261,12 @@ class SlabSimulation(object):
     def set_phi(self, phi):
         self._set(1, phi)
 
+    def set_c(self, c):
+        """QGModel's passive scalar (QGModel.set_c): rows in, then the inversion re-emits every mixed-space row"""
+        for r in self.ranks:
+            r.put_rows(2, c[r.rank * r.nloc:(r.rank + 1) * r.nloc])
+        self._lead_chk(self.L.nq_slab_commit(self.lead.h, 3), "nq_slab_commit(set_c)")
+
     def refresh_grad_phi(self):
         for r in self.ranks:
             r.refresh_grad_phi()
@@ -316,7 +324,7 @@ class SlabSimulation(object):
         self._lead_chk(self.L.nq_slab_commit(self.lead.h, 2), "nq_slab_commit(invert)")
 
     def gather_spectral(self, which):
-        """0: qh, 1: phih, 2: ph, 3: qwh -- the column slabs of all ranks side by side"""
+        """0: qh, 1: phih, 2: ph, 3: qwh, 4: second copy of qh, 5: ch -- the column slabs of all ranks side by side"""
         return self._gather([r.download(which) for r in self.ranks], 1)
 
     def gather_qh(self):
@@ -396,7 +404,8 @@ class SlabContext(object):
         self._touch()
 
     def set_c(self, c):
-        raise NotImplementedError("the passive scalar is single-rank only")
+        self.sim.set_c(np.asarray(c, np.float64))
+        self._touch()
 
     def invert(self):
         self.sim.invert()
@@ -424,7 +433,7 @@ class SlabContext(object):
         if fid == L.F_QPSI:
             q = self.sim.gather_rows(L.F_Q)
             return q - self.sim.gather_rows(L.F_QW) if self.model == L.COUPLED else q
-        which = {L.F_QH: 0, L.F_PHIH: 1, L.F_PH: 2, L.F_QWH: 3, L.F_QH_MINUS: 4}.get(fid)
+        which = {L.F_QH: 0, L.F_PHIH: 1, L.F_PH: 2, L.F_QWH: 3, L.F_QH_MINUS: 4, L.F_CH: 5}.get(fid)
         if which is None:
             raise RuntimeError("field %d is not available on a slab-decomposed model" % fid)
         return self.sim.gather_spectral(which)

@@ -267,3 +267,49 @@ def test_ybj_model_on_four_slabs_equals_the_whole_plane_model():
             steps(x, 12)
         assert rel(s.phi, w.phi) < 1e-13 and rel(s.phix, w.phix) < 1e-13 and rel(s.phiy, w.phiy) < 1e-13
         assert rel(s.q, w.q) < 1e-13 and rel(s.u, w.u) < 1e-13
+
+
+@pytest.mark.parametrize("use_filter", [True, False])
+def test_qg_passive_scalar_on_slabs_against_the_reference(golden, use_filter):
+    """golden g10 (QGModel with passive_scalar=True, run by the reference) through Model(slab=2): the scalar rides in the
+    spare slots of exchange groups 0 and 3; trajectory, variance budget and every diagnostics series of the tick."""
+    import niwqg_amd
+    g = golden("g10_qg_passive_64.npz")
+    key = "filter" if use_filter else "nofilter"
+    m = niwqg_amd.QGModel.Model(L=L, nx=64, tmax=19.5 * float(g["dt"]), dt=float(g["dt"]), twrite=10 ** 9,
+                                nu4=7.5e8 * 16, nu=5.0, mu=1e-8, use_filter=use_filter, U=-U0, tdiags=1, beta=2e-11,
+                                passive_scalar=True, nu4c=3e9, nuc=2.0, muc=1e-8, slab=2)
+    m.set_q(g["q0"])
+    m.set_c(g["c0"])
+    m.run()
+    assert m.tc == 20
+    assert rel(m.q, g["q_" + key]) < 1e-11 and rel(m.qh, g["qh_" + key]) < 1e-11
+    assert rel(m.c, g["c_" + key]) < 1e-12 and rel(m.ch, g["ch_" + key]) < 1e-12
+    m._calc_derived_fields()
+    assert np.allclose([m.Ke, m.cvar, m.C2, m.gradC2], g["scalars_" + key], rtol=1e-10)
+    for name in m.diagnostics:
+        ref = g["diag_%s_%s" % (name, key)]
+        tol = 1e-7 if name == "Gamma_c" else 1e-8
+        assert np.allclose(np.asarray(m.diagnostics[name]['value']), ref, rtol=tol, atol=1e-30), name
+
+
+def test_qg_passive_scalar_on_four_slabs_equals_the_whole_plane_model():
+    import niwqg_amd
+    rng = np.random.default_rng(5)
+    kw = dict(L=L, nx=256, tmax=1e30, dt=2000.0, twrite=10 ** 9, nu4=7.5e8, use_filter=True, U=-U0, tdiags=3, beta=1e-11,
+              passive_scalar=True, nu4c=3e9, nuc=2.0, muc=1e-8)
+    w = niwqg_amd.QGModel.Model(slab=False, **kw)
+    s = niwqg_amd.QGModel.Model(slab=4, **kw)
+    x = np.linspace(0, 2 * np.pi, 256, endpoint=False)
+    q0 = 1e-5 * (np.sin(3 * x)[None, :] * np.cos(2 * x)[:, None] + 0.1 * rng.standard_normal((256, 256)))
+    c0 = np.cos(x)[None, :] * np.sin(4 * x)[:, None] + 0.05 * rng.standard_normal((256, 256))
+    for m in (w, s):
+        m.set_q(q0)
+        m.set_c(c0)
+        m.tmax = 11.5 * m.dt
+        m.run()
+    assert rel(s.q, w.q) < 1e-13 and rel(s.c, w.c) < 1e-13 and rel(s.ch, w.ch) < 1e-13
+    assert np.allclose([s.Ke, s.cvar], [w.Ke, w.cvar], rtol=1e-12)
+    for name in w.diagnostics:
+        a, b = np.asarray(s.diagnostics[name]['value']), np.asarray(w.diagnostics[name]['value'])
+        assert np.allclose(a, b, rtol=1e-7 if name == "Gamma_c" else 1e-10, atol=1e-30), name

@@ -189,8 +189,8 @@ int nq_create_slab(const nq_params* p, const double* kk, const double* ll, const
 int nq_slab_info(const nq_ctx* ctx, int* info8);
 int nq_group_buffers(nq_ctx* ctx, int group, void** x_side, void** y_side, long long* elems);
 /* local column slab of qh (which 0: (ny, local half-spectrum columns)) or phih (which 1: (ny, nx/nranks)); download also
- * which 2: ph, 3: qwh, 4: the second copy of qh of a dual_q context, 5: ch of QGModel's passive scalar (half-spectrum
- * slabs like qh) */
+ * which 2: ph, 3: qwh, 4: the second copy of qh of a dual_q context, 5: ch of QGModel's passive scalar, 6: the q-hat the
+ * last step's fourth stage was evaluated at (NQ_F_QH_STAGE4) (half-spectrum slabs like qh) */
 int nq_upload_spectral(nq_ctx* ctx, int which, const double* host);
 int nq_download_spectral(nq_ctx* ctx, int which, double* host);
 enum {
@@ -246,6 +246,15 @@ int nq_slab_commit(nq_ctx* ctx, int which);   /* collective: the rest of set_q /
                                                   which 2: Kernel._invert on the current state, nothing uploaded;
                                                   which 3: the rest of QGModel.set_c (QGModel.py:522-534) after put_rows(2) */
 int nq_slab_get_rows(nq_ctx* ctx, int field_id, double* rows_out);
+/* The whole-plane calls of the class API on a slab model (Kernel.fft, jacobian_psi_q, jacobian_psi_phi,
+ * CoupledModel.jacobian_phic_phi): nq_slab_spectral (collective) runs the row kernel of the current state -- or takes
+ * the rows last given to nq_slab_put_rows -- through exchange and column transform into a scratch column slab;
+ * nq_slab_spectral_read (local) copies this rank's slab out: (nx, wh) complex for the half-spectrum results, (nx, wf)
+ * otherwise (wh, wf: nq_slab_info).  what 0 / 1: F[u q] / F[v q] (half); 2: F[u phix + v phiy] (full, [0,0] as
+ * computed); 3: F[i phi q_psi] (full); 4: F[Re i(phix* phiy - phiy* phix)] (half, coupled model); 5 / 6: forward
+ * transform of the real / complex rows of nq_slab_put_rows(0 / 1) (half / full).  The model state is not touched. */
+int nq_slab_spectral(nq_ctx* ctx, int what);
+int nq_slab_spectral_read(nq_ctx* ctx, int half, double* out_cplx);
 /* nq_diagnostics of a slab-decomposed simulation: the same 32 sums, every rank's part summed over the ranks (collective);
  * nq_slab_local_max: max|u|, max|v|, max|phi| over this rank's rows (the caller takes the max over ranks for the CFL) */
 int nq_slab_diagnostics(nq_ctx* ctx, double* out32);

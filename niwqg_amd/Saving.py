@@ -12,6 +12,9 @@ without an installed writer ``save_to_disk=True`` raises at construction -- neve
 Snapshots do not stall the time stepping: the device forms q and phi in physical space into buffers of their own, a
 second stream copies them to pinned host memory (nq_snapshot_begin), and the file is written when the host next looks
 (nq_snapshot_end), usually while the following batch of steps is already running on the GPU.
+
+A model that is slab-decomposed over several processes gathers its fields collectively (every rank takes part) and rank 0
+alone touches the files.
 """
 import os
 
@@ -57,6 +60,12 @@ def _open(fno):
     return h5py.File(fno, 'w')
 
 
+def _writes(self):
+    """False on the ranks > 0 of a model decomposed over several processes"""
+    group = getattr(getattr(self, "_ctx", None), "group", None)
+    return group is None or group.rank == 0
+
+
 def initialize_save_snapshots(self, path):
     """ref: niwqg/Saving.py:6-22"""
     self.fno = path
@@ -64,7 +73,7 @@ def initialize_save_snapshots(self, path):
     if self.save_to_disk and not writer_available():
         raise NotImplementedError("save_to_disk=True: h5py is not importable and no writer is installed "
                                   "(niwqg_amd.Saving.set_writer)")
-    if (not os.path.isdir(self.fno)) and self.save_to_disk:
+    if (not os.path.isdir(self.fno)) and self.save_to_disk and _writes(self):
         os.makedirs(self.fno)
         os.makedirs(self.fno + "/snapshots/")
 
@@ -80,7 +89,7 @@ def file_exist(fno, overwrite=True):
 
 def save_setup(self):
     """ref: niwqg/Saving.py:38-57"""
-    if self.save_to_disk:
+    if self.save_to_disk and _writes(self):
         fno = self.fno + '/setup.h5'
         file_exist(fno, overwrite=self.overwrite)
         h5file = _open(fno)
@@ -115,6 +124,8 @@ def flush_snapshots(self):
             other = dict(other, q=q)
             if phi is not None:
                 other["phi"] = phi
+        if not _writes(self):
+            continue
         file_exist(fno)
         h5file = _open(fno)
         for field in fields:
@@ -125,6 +136,8 @@ def flush_snapshots(self):
 
 def save_diagnostics(self):
     """ref: niwqg/Saving.py:88-101"""
+    if not _writes(self):
+        return
     fno = self.fno + '/diagnostics.h5'
     file_exist(fno, overwrite=self.overwrite)
     h5file = _open(fno)

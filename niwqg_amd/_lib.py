@@ -30,7 +30,7 @@ EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "
            "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
            "nq_reduce_buffer", "nq_reduce_read", "nq_reduce_write", "nq_device_bytes", "nq_stream",
-           "nq_comm_unique_id", "nq_comm_init", "nq_slab_attach_peers", "nq_slab_set_callbacks", "nq_slab_config", "nq_slab_set_stage_buffers",
+           "nq_comm_unique_id", "nq_comm_init", "nq_slab_attach_peers", "nq_slab_set_callbacks", "nq_slab_config", "nq_slab_set_stage_buffers", "nq_slab_spectral", "nq_slab_spectral_read",
            "nq_slab_step", "nq_slab_put_rows", "nq_slab_commit", "nq_slab_get_rows", "nq_slab_diagnostics",
            "nq_slab_local_max", "nq_slab_counters", "nq_snapshot_begin", "nq_snapshot_end"]
 
@@ -122,6 +122,8 @@ def lib():
     L.nq_slab_set_callbacks.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp]
     L.nq_slab_config.argtypes = [vp, ctypes.c_int]
     L.nq_slab_set_stage_buffers.argtypes = [vp, vp, vp]
+    L.nq_slab_spectral.argtypes = [vp, ctypes.c_int]
+    L.nq_slab_spectral_read.argtypes = [vp, ctypes.c_int, dp]
     L.nq_slab_step.argtypes = [vp, ctypes.c_int]
     L.nq_slab_put_rows.argtypes = [vp, ctypes.c_int, dp]
     L.nq_slab_commit.argtypes = [vp, ctypes.c_int]

@@ -2111,11 +2111,11 @@ int nq_upload_spectral(nq_ctx* c, int which, const double* host) {
 int nq_download_spectral(nq_ctx* c, int which, double* host) {
   if (!c || !host) return -1;
   HIPCHK(c, hipSetDevice(c->device));
-  if (which == 0 || which == 2 || which == 3 || which == 4 || which == 5) {      // half-spectrum planes: qh, ph, qwh, second copy of qh, ch
+  if (which == 0 || (which >= 2 && which <= 6)) {      // half-spectrum planes: qh, ph, qwh, second copy of qh, ch, stage-4 qh
     if (which == 3 && c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qwh exists only in the coupled model");
     if (which == 4 && !c->dual) NQ_FAIL(c, -4, "no second copy of qh in this context (dual_q)");
     if (which == 5 && !c->passive) NQ_FAIL(c, -4, "no passive scalar in this context");
-    const cd* src = which == 0 ? c->q.y[c->q.cur] : (which == 2 ? c->ph : (which == 3 ? c->qwh : (which == 4 ? c->q2.y[c->q2.cur] : c->cq.y[c->cq.cur])));
+    const cd* src = which == 0 ? c->q.y[c->q.cur] : (which == 2 ? c->ph : (which == 3 ? c->qwh : (which == 4 ? c->q2.y[c->q2.cur] : (which == 5 ? c->cq.y[c->cq.cur] : c->q.y[(c->q.cur + 2) % 3]))));
     if (c->Wh > 0) HIPCHK(c, hipMemcpy2DAsync(host, sizeof(cd) * c->Wh, src, sizeof(cd) * c->Ph, sizeof(cd) * c->Wh, c->N, hipMemcpyDeviceToHost, c->stream));
   } else if (which == 1) {
     if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
@@ -2531,6 +2531,58 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
   HIPCHK(c0, hipMemcpyAsync(out + 16, c0->diag_out + 16, sizeof(double) * 16, hipMemcpyDeviceToHost, c0->stream));
   for (nq_ctx* x : grp) SLABTRY(nq_sync(x));
   return 0;
+}
+// Spectra the whole-plane calls of the class API need on a slab model (fft seam, the three Jacobians): the row kernel of
+// the current state (or the rows uploaded by nq_slab_put_rows), exchange, column transform into a scratch column slab.
+//   what 0 / 1: F[u q] / F[v q]                 half-spectrum slab (Kernel.py:471-486, QGModel.py:469-481)
+//        2:     F[u phix + v phiy]              full-width slab, [0,0] as computed (Kernel.py:457-469)
+//        3:     F[i phi q_psi]                  full-width slab (the refraction source, Kernel.py:332)
+//        4:     F[Re i(phix* phiy - phiy* phix)] half-spectrum slab (CoupledModel.py:59-73)
+//        5 / 6: forward transform of the real / complex rows last given to nq_slab_put_rows(0 / 1)
+// Groups 0 and 2 are dead between steps, so the state is left alone.
+int nq_slab_spectral(nq_ctx* c, int what) {
+  if (!c) return -1;
+  if (what < 0 || what > 6) NQ_FAIL(c, -1, "nq_slab_spectral: what = %d", what);
+  std::vector<nq_ctx*> grp;
+  SLABTRY(slab_group(c, &grp));
+  for (nq_ctx* x : grp) HIPCHK(x, hipSetDevice(x->device));
+  SLABTRY(slab_settle(grp));
+  nq_ctx* c0 = grp[0];
+  const bool full = what == 2 || what == 3 || what == 6;
+  if (full && !c0->kernel_family) NQ_FAIL(c, -4, "nq_slab_spectral: no wave field in QGModel");
+  if (what == 4 && (c0->p.model != NQ_MODEL_COUPLED || c0->ybj)) NQ_FAIL(c, -4, "jacobian_phic_phi exists only in the coupled model");
+  if (what <= 3 && !c0->have_q) NQ_FAIL(c, -4, "nq_slab_spectral: set_q has not been called");
+  if ((what == 2 || what == 3 || what == 4) && !c0->have_phi) NQ_FAIL(c, -4, "nq_slab_spectral: set_phi has not been called");
+  for (nq_ctx* x : grp) {
+    if (!x->scr_f1) {
+      const size_t w = (size_t)(x->Wf > x->Ph ? x->Wf : x->Ph);
+      ALLOC(x, x->scr_f1, (size_t)x->N * w);
+    }
+    set_window(x, 0, 1);
+    if (what <= 1) launch_products(x);
+    else if (what == 2) launch_products(x, 1.0, 0.0);
+    else if (what == 3) launch_products(x, 0.0, 1.0);
+    else if (what == 4) launch_wavepv(x);
+  }
+  SLABTRY(exchange_now(grp, what == 4 ? 2 : 0, true));
+  for (nq_ctx* x : grp) {
+    const MArr& m = (what == 0 || what == 5) ? x->mUq : (what == 1 ? x->mVq : (what == 4 ? x->mB : x->mW));
+    launch_A_m(x, false, {&m});
+    if (full) launch_B_p(x, false, m.ys, m.pitch, x->scr_f1, x->Wf, x->Wf, 1.0);
+    else if (x->Wh > 0) launch_B_p(x, false, m.ys, m.pitch, x->scr_f1, x->Ph, x->Wh, 1.0);
+    HIPCHK(x, hipGetLastError());
+  }
+  for (nq_ctx* x : grp) SLABTRY(nq_sync(x));
+  return 0;
+}
+// this rank's column slab of the last nq_slab_spectral: (nx, wh) for the half-spectrum results, (nx, wf) for the others
+int nq_slab_spectral_read(nq_ctx* c, int half, double* out) {
+  if (!c || !out) return -1;
+  if (!c->scr_f1) NQ_FAIL(c, -4, "nq_slab_spectral_read: nothing computed yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int w = half ? c->Wh : c->Wf, pitch = half ? c->Ph : c->Wf;
+  if (w > 0) HIPCHK(c, hipMemcpy2DAsync(out, sizeof(cd) * w, c->scr_f1, sizeof(cd) * pitch, sizeof(cd) * w, c->N, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
 }
 // max |u|, max |v|, max |phi| over THIS rank's rows (the caller takes the max over ranks: Kernel._calc_cfl, Kernel.py:660-662)
 int nq_slab_local_max(nq_ctx* c, double* out3) {

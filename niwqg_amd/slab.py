@@ -373,6 +373,7 @@ class SlabContext(object):
 
     def __init__(self, model, nx, kk, ll, filtr, dt, peers=None, nchunks=2, device=None, budgets=True, **phys):
         self.model, self.nx = model, int(nx)
+        self._kk, self._ll = np.array(kk, np.float64), np.array(ll, np.float64)
         self.budgets_enabled = bool(budgets)
         self.kappa2 = phys.get("kappa2", 1.0)
         if peers:
@@ -433,7 +434,7 @@ class SlabContext(object):
         if fid == L.F_QPSI:
             q = self.sim.gather_rows(L.F_Q)
             return q - self.sim.gather_rows(L.F_QW) if self.model == L.COUPLED else q
-        which = {L.F_QH: 0, L.F_PHIH: 1, L.F_PH: 2, L.F_QWH: 3, L.F_QH_MINUS: 4, L.F_CH: 5}.get(fid)
+        which = {L.F_QH: 0, L.F_PHIH: 1, L.F_PH: 2, L.F_QWH: 3, L.F_QH_MINUS: 4, L.F_CH: 5, L.F_QH_STAGE4: 6}.get(fid)
         if which is None:
             raise RuntimeError("field %d is not available on a slab-decomposed model" % fid)
         return self.sim.gather_spectral(which)
@@ -468,8 +469,78 @@ class SlabContext(object):
         raise NotImplementedError("this call needs the whole plane on one device: not available on a slab-decomposed model "
                                   "(use a single-GPU model of the same parameters)")
 
-    fft2 = ifft2 = rfft2 = irfft2 = coeff = _single_rank_only
-    jacobian_psi_q = jacobian_psi_phi = jacobian_phic_phi = products_uq_vq = refraction = _single_rank_only
+    coeff = _single_rank_only
+
+    # --- the whole-plane calls of the class API: global arrays in and out on every rank, transforms and row kernels on the
+    # slabs (nq_slab_spectral).  Inverse transforms go through the forward path, ifft(X) = conj(fft(conj X)) / N^2: only
+    # the x -> y exchange groups are free between steps.
+    def _spectral(self, what, half):
+        sim = self.sim
+        sim._lead_chk(sim.L.nq_slab_spectral(sim.lead.h, int(what)), "nq_slab_spectral(%d)" % what)
+        parts = []
+        for r in sim.ranks:
+            out = np.empty((self.nx, r.wh if half else r.wf), np.complex128)
+            r._chk(r.L.nq_slab_spectral_read(r.h, int(half), _lib._dptr(out.view(np.float64))), "nq_slab_spectral_read")
+            parts.append(out)
+        return sim._gather(parts, 1)
+
+    def rfft2(self, a):
+        a = np.asarray(a, np.float64)
+        assert a.shape == (self.nx, self.nx), a.shape
+        for r in self.sim.ranks:
+            r.put_rows(0, a[r.rank * r.nloc:(r.rank + 1) * r.nloc])
+        return self._spectral(5, True)
+
+    def fft2(self, a):
+        a = np.asarray(a, np.complex128)
+        assert a.shape == (self.nx, self.nx), a.shape
+        if self.model == _lib.QG:                      # no complex carrier in QGModel's exchange groups: two real transforms
+            from .Kernel import hermitian_full
+            return hermitian_full(self.rfft2(a.real)) + 1j * hermitian_full(self.rfft2(a.imag))
+        for r in self.sim.ranks:
+            r.put_rows(1, a[r.rank * r.nloc:(r.rank + 1) * r.nloc])
+        return self._spectral(6, False)
+
+    def ifft2(self, a):
+        return np.conj(self.fft2(np.conj(np.asarray(a, np.complex128)))) / float(self.nx) ** 2
+
+    def irfft2(self, a):
+        """numpy.fft.irfft2 semantics: the self-mirrored columns count with their Hermitian part (in l) only"""
+        from .Kernel import hermitian_full, project_self_mirrored_columns
+        a = np.asarray(a, np.complex128)
+        assert a.shape == (self.nx, self.nx // 2 + 1), a.shape
+        return np.ascontiguousarray(self.ifft2(hermitian_full(project_self_mirrored_columns(a))).real)
+
+    def products_uq_vq(self):
+        """fft(u q), fft(v q) on k = 0..nx/2"""
+        return self._spectral(0, True), self._spectral(1, True)
+
+    def jacobian_psi_q(self):
+        """Kernel family: (ny, nx) with [0,0] = 0 (Kernel.py:471-486); QGModel: (ny, nx/2+1) (QGModel.py:469-481)"""
+        from .Kernel import hermitian_full
+        a, b = self.products_uq_vq()
+        ll = self._ll[:, None]
+        if self.model == _lib.QG:
+            return 1j * self._kk[None, :] * a + 1j * ll * b
+        out = 1j * self._kk[None, :] * hermitian_full(a) + 1j * ll * hermitian_full(b)
+        out[0, 0] = 0.0
+        return out
+
+    def jacobian_psi_phi(self):
+        out = self._spectral(2, False)
+        if self.model != _lib.YBJ:                     # YBJModel's own version keeps [0,0] (YBJModel.py:123-133)
+            out[0, 0] = 0.0
+        return out
+
+    def refraction(self):
+        """fft(phi * q_psi) from the row kernel (Kernel.py:332 without the -0.5j)"""
+        return -1j * self._spectral(3, False)
+
+    def jacobian_phic_phi(self):
+        from .Kernel import hermitian_full
+        out = hermitian_full(self._spectral(4, True))
+        out[0, 0] = 0.0
+        return out
 
     def close(self):
         for r in self.sim.ranks:

@@ -113,13 +113,67 @@ def test_qgmodel_golden_through_the_model_api_on_slabs(golden):
     assert abs(m.Ke - float(g["Ke_%d" % n])) < 1e-9 * abs(float(g["Ke_%d" % n]))
 
 
-def test_whole_plane_calls_fail_loudly_on_slabs():
+def test_whole_plane_calls_of_the_class_api_on_slabs(golden):
+    """Kernel.fft / ifft and the three Jacobians on a slab model: global arrays in and out, computed on the slabs.  Checked
+    against numpy, against the reference's own per-function vectors (golden g1) and against the whole-plane model."""
     import niwqg_amd
-    m = niwqg_amd.CoupledModel.Model(slab=2, **notebook_kwargs(128, True))
+    from niwqg_amd import InitialConditions as ic
+    rng = np.random.default_rng(3)
+    g1 = golden("g1_functions_64.npz")
+    m = niwqg_amd.CoupledModel.Model(slab=2, **notebook_kwargs(64, True))
+    a = rng.standard_normal((64, 64)) + 1j * rng.standard_normal((64, 64))
+    assert rel(m.fft(a), np.fft.fft2(a)) < 2e-15 and rel(m.ifft(a), np.fft.ifft2(a)) < 2e-15
+    m.set_q(g1["q0"])
+    m.set_phi(g1["phi0"])
+    m._invert()
+    assert rel(m.jacobian_psi_q(), g1["jac_psi_q"]) < 1e-13
+    assert rel(m.jacobian_psi_phi(), g1["jac_psi_phi"]) < 1e-13
+    assert rel(m.jacobian_phic_phi(), g1["jac_phic_phi"]) < 1e-13
+    assert rel(m._ctx.refraction(), g1["refraction"]) < 1e-13
+    assert m.jacobian_psi_q()[0, 0] == 0 and m.jacobian_psi_phi()[0, 0] == 0 and m.jacobian_phic_phi()[0, 0] == 0
+    steps(m, 2)                                   # the calls left the state alone
+    w = niwqg_amd.CoupledModel.Model(slab=False, **notebook_kwargs(64, True))
+    w.set_q(g1["q0"])
+    w.set_phi(g1["phi0"])
+    w._invert()
+    steps(w, 2)
+    assert rel(m.q, w.q) < 1e-13 and rel(m.phi, w.phi) < 1e-13
+    assert rel(m.jacobian_psi_q(), w.jacobian_psi_q()) < 1e-13 and rel(m.jacobian_phic_phi(), w.jacobian_phic_phi()) < 1e-13
+    # 4 ranks, 256^2, the random initial conditions that go through the FFT seam (same seeds as the whole-plane model)
+    kw = notebook_kwargs(256, True)
+    s4 = niwqg_amd.UnCoupledModel.Model(slab=4, **kw)
+    w4 = niwqg_amd.UnCoupledModel.Model(slab=False, **kw)
+    fields = []
+    for x in (s4, w4):
+        np.random.seed(11)
+        fields.append(ic.McWilliams1984(x, k0=6 * 2 * np.pi / L, E=0.5 * U0 ** 2))
+    b = rng.standard_normal((256, 256)) + 1j * rng.standard_normal((256, 256))
+    assert rel(s4.fft(b), np.fft.fft2(b)) < 2e-15 and rel(s4.ifft(b), np.fft.ifft2(b)) < 2e-15
+    assert rel(fields[0], fields[1]) < 1e-12        # the generator normalises by a ratio of spectral sums
+    for x in (s4, w4):
+        x.set_q(fields[1])
+        x.set_phi(ic.WavePacket(x, k=3 * K0, l=K0, R=L / 6, x0=L / 3, y0=L / 2))
+    assert rel(s4.jacobian_psi_phi(), w4.jacobian_psi_phi()) < 1e-13
+    assert rel(s4.jacobian_psi_q(), w4.jacobian_psi_q()) < 1e-13
     with pytest.raises(NotImplementedError):
-        m.fft(np.zeros((128, 128), complex))
-    with pytest.raises(NotImplementedError):
-        m.jacobian_psi_q()
+        s4._ctx.coeff(0, 0)
+    # QGModel: rfft2 / irfft2 semantics, half-plane Jacobian with [0,0] kept, the passive scalar's tick Jacobian
+    kwq = dict(L=L, nx=128, tmax=1e30, dt=2000.0, twrite=10 ** 9, nu4=7.5e8, use_filter=True, U=-U0, tdiags=10 ** 9,
+               passive_scalar=True)
+    sq = niwqg_amd.QGModel.Model(slab=2, **kwq)
+    wq = niwqg_amd.QGModel.Model(slab=False, **kwq)
+    r = rng.standard_normal((128, 128))
+    h = np.fft.rfft2(r) + 0.3j * rng.standard_normal((128, 65))        # not Hermitian on the self-mirrored columns
+    assert rel(sq.fft(r), np.fft.rfft2(r)) < 2e-15 and rel(sq.ifft(h), np.fft.irfft2(h)) < 2e-15
+    q0 = 1e-5 * rng.standard_normal((128, 128))
+    for x in (sq, wq):
+        x.set_q(q0)
+        x.set_c(r)
+    assert rel(sq.jacobian_psi_q(), wq.jacobian_psi_q()) < 1e-13
+    for x in (sq, wq):
+        x.tmax = 2.5 * x.dt
+        x.run()
+    assert rel(sq.jacobian_psi_c(), wq.jacobian_psi_c()) < 1e-12
 
 
 @pytest.mark.parametrize("P", [2, 4])
@@ -200,6 +254,23 @@ d.set_phi(g2["phi0"])
 while d.tc < 10:
     d._step_forward()
 assert rel(d.qh, g2["qh_10"]) < 1e-12 and rel(d.phi, g2["phi_10"]) < 1e-12
+# save_to_disk on a model spread over two processes: both gather, rank 0 alone writes (NpzWriter in place of h5py)
+import os
+from niwqg_amd import Saving
+Saving.set_writer(Saving.NpzWriter)
+out = %r
+kw = notebook_kwargs(64, True, tdiags=4)
+kw.update(tmax=11.5 * kw["dt"], save_to_disk=True, tsave_snapshots=6, path=out)
+w = niwqg_amd.CoupledModel.Model(**kw)
+w.set_q(g2["q0"])
+w.set_phi(g2["phi0"])
+w.run()
+w._ctx.group.barrier()
+names = sorted(os.listdir(out + "/snapshots"))
+assert names == ['{:015.0f}.h5'.format(n * w.dt) for n in (0, 6, 12)], names
+last = np.load(out + "/snapshots/" + names[-1], allow_pickle=False)
+assert rel(last["q"], w.q) < 1e-15 and rel(last["phi"], w.phi) < 1e-15 and float(last["t"]) == w.t
+assert os.path.exists(out + "/setup.h5") and os.path.exists(out + "/diagnostics.h5")
 if m._ctx.group.rank == 0:
     print("two-process model agrees with the reference golden")
 m._ctx.group.close()
@@ -216,12 +287,16 @@ def test_model_api_in_two_processes_over_gloo(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "model_worker.py"
     script.write_text(MODEL_WORKER % (root, os.path.join(root, "tests"), os.path.join(GOLDEN, "g2_coupled_128_filter.npz"),
-                                      os.path.join(GOLDEN, "g8_ybj_64.npz"), os.path.join(GOLDEN, "g2_coupled_64_nofilter.npz")))
+                                      os.path.join(GOLDEN, "g8_ybj_64.npz"), os.path.join(GOLDEN, "g2_coupled_64_nofilter.npz"),
+                                      str(tmp_path / "saved")))
     env = dict(os.environ, NIWQG_AMD_DIST_BACKEND="gloo")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
                          capture_output=True, text=True, timeout=600, env=env)
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    if out.returncode != 0:
+        print(out.stdout[-3000:])
+        print(out.stderr[-6000:])
+    assert out.returncode == 0
     assert "two-process model agrees with the reference golden" in out.stdout
 
 

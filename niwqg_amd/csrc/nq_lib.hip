@@ -139,6 +139,7 @@ struct nq_ctx {
   std::vector<hipEvent_t> xev;         // timing pairs around every exchange chunk on mstream (when counting)
   size_t xev_used = 0;
   bool xtime = false;
+  int spec_kind = -1;                  // what the scratch column slab of nq_slab_spectral holds: 1 half-spectrum, 0 full width
   bool ybj = false;
   bool passive = false;  // QGModel with its passive scalar: state cq, spectrum emitted through the qw slots of G3 / G0
   EqState cq;
@@ -2571,6 +2572,7 @@ int nq_slab_spectral(nq_ctx* c, int what) {
     if (full) launch_B_p(x, false, m.ys, m.pitch, x->scr_f1, x->Wf, x->Wf, 1.0);
     else if (x->Wh > 0) launch_B_p(x, false, m.ys, m.pitch, x->scr_f1, x->Ph, x->Wh, 1.0);
     HIPCHK(x, hipGetLastError());
+    x->spec_kind = full ? 0 : 1;
   }
   for (nq_ctx* x : grp) SLABTRY(nq_sync(x));
   return 0;
@@ -2578,7 +2580,8 @@ int nq_slab_spectral(nq_ctx* c, int what) {
 // this rank's column slab of the last nq_slab_spectral: (nx, wh) for the half-spectrum results, (nx, wf) for the others
 int nq_slab_spectral_read(nq_ctx* c, int half, double* out) {
   if (!c || !out) return -1;
-  if (!c->scr_f1) NQ_FAIL(c, -4, "nq_slab_spectral_read: nothing computed yet");
+  if (c->spec_kind < 0) NQ_FAIL(c, -4, "nq_slab_spectral_read: nothing computed yet");
+  if (c->spec_kind != (half ? 1 : 0)) NQ_FAIL(c, -1, "nq_slab_spectral_read: the last nq_slab_spectral result is a %s slab", c->spec_kind ? "half-spectrum" : "full-width");
   HIPCHK(c, hipSetDevice(c->device));
   const int w = half ? c->Wh : c->Wf, pitch = half ? c->Ph : c->Wf;
   if (w > 0) HIPCHK(c, hipMemcpy2DAsync(out, sizeof(cd) * w, c->scr_f1, sizeof(cd) * pitch, sizeof(cd) * w, c->N, hipMemcpyDeviceToHost, c->stream));

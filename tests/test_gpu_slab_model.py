@@ -123,6 +123,10 @@ def test_whole_plane_calls_of_the_class_api_on_slabs(golden):
     m = niwqg_amd.CoupledModel.Model(slab=2, **notebook_kwargs(64, True))
     a = rng.standard_normal((64, 64)) + 1j * rng.standard_normal((64, 64))
     assert rel(m.fft(a), np.fft.fft2(a)) < 2e-15 and rel(m.ifft(a), np.fft.ifft2(a)) < 2e-15
+    r0 = m._ctx.sim.ranks[0]                      # a full-width result cannot be read as a half-spectrum slab
+    buf = np.zeros((64, r0.wf), np.complex128)
+    assert r0.L.nq_slab_spectral_read(r0.h, 1, niwqg_amd._lib._dptr(buf.view(np.float64))) != 0
+    assert b"full-width" in r0.L.nq_last_error(r0.h)
     m.set_q(g1["q0"])
     m.set_phi(g1["phi0"])
     m._invert()

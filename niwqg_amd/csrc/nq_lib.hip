@@ -1125,8 +1125,14 @@ static bool rccl_load(std::string* err) {
   if (g_rccl.handle) return true;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
+  // NIWQG_AMD_RCCL_LIB: an explicit library instead (tests/mock_rccl: rank THREADS on one GPU)
+  const char* forced = getenv("NIWQG_AMD_RCCL_LIB");
+  if (forced && *forced && !(h = dlopen(forced, RTLD_NOW | RTLD_LOCAL))) {
+    *err = std::string("NIWQG_AMD_RCCL_LIB: ") + (dlerror() ? dlerror() : "?");
+    return false;
+  }
   for (const char* n : names)
-    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // the copy the process already uses, if any
+    if (!h && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // the copy the process already uses, if any
   for (const char* n : names) {
     if (h) break;
     h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);

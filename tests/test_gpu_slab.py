@@ -290,3 +290,124 @@ def test_bench_contract_with_two_ranks_rehearsed_over_gloo():
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert "cpu_baseline" not in d                     # rank 0 at N = 1 only
+
+
+THREAD_RANKS_WORKER = """
+import ctypes, os, sys, threading
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(tests)r)
+import numpy as np
+from niwqg_amd import _lib, slab
+from test_gpu_slab import setup_case
+from test_oracle_golden import rel
+
+def on_all(ranks, fn):
+    # one host thread per rank, as one process per GPU would run them; ctypes releases the GIL inside the library
+    out, err = [None] * len(ranks), []
+    def run(i, r):
+        try:
+            out[i] = fn(r)
+        except Exception as e:
+            err.append((i, repr(e)))
+    th = [threading.Thread(target=run, args=(i, r)) for i, r in enumerate(ranks)]
+    for t in th: t.start()
+    for t in th: t.join(300)
+    assert not any(t.is_alive() for t in th), "a rank thread hangs"
+    assert not err, err
+    return out
+
+mock = ctypes.CDLL(os.environ["NIWQG_AMD_RCCL_LIB"])
+for kind, nranks, nchunks, nx in (("coupled", 2, 2, 256), ("coupled", 4, 4, 256), ("uncoupled", 4, 1, 256), ("qg", 2, 2, 256),
+                                  ("ybj", 4, 2, 256), ("coupled", 8, 2, 512)):
+    model, o, dt, phys, q0, phi0 = setup_case("uncoupled" if kind == "ybj" else kind, nx)
+    if kind == "ybj":
+        model = _lib.YBJ          # the stage results cross in a fifth group; no budgets in YBJModel's step
+    nsteps = 3
+    one = _lib.Context(model, nx, o.kk, o.ll, o.filtr, dt, budgets=True, **phys)
+    one.set_q(q0)
+    if phi0 is not None:
+        one.set_phi(phi0)
+    bud = kind != "ybj"
+    if bud:
+        one.take_budget_increments() if model != _lib.QG else one.scalar(_lib.S_KE)
+    one.step(nsteps)
+    if bud:
+        inc1 = one.take_budget_increments() if model != _lib.QG else (one.scalar(_lib.S_KE),)
+    ranks = slab.make_ranks(model, nx, o.kk, o.ll, o.filtr, dt, nranks, budgets=True, **phys)
+    L = ranks[0].L
+    uid = (ctypes.c_ubyte * 128)()
+    assert L.nq_comm_unique_id(uid) == 0, L.nq_last_error(None)
+    def chk(r, rc, what):
+        assert rc == 0, (what, r.rank, L.nq_last_error(r.h))
+    on_all(ranks, lambda r: chk(r, L.nq_comm_init(r.h, uid, nranks, r.rank), "nq_comm_init"))
+    for r in ranks:
+        chk(r, L.nq_slab_config(r.h, nchunks), "nq_slab_config")
+        r.put_rows(0, q0[r.rank * r.nloc:(r.rank + 1) * r.nloc])
+    on_all(ranks, lambda r: chk(r, L.nq_slab_commit(r.h, 0), "commit q"))
+    if phi0 is not None:
+        for r in ranks:
+            r.put_rows(1, phi0[r.rank * r.nloc:(r.rank + 1) * r.nloc])
+        on_all(ranks, lambda r: chk(r, L.nq_slab_commit(r.h, 1), "commit phi"))
+    for r in ranks:
+        if bud:
+            r.budget_increments()
+    before = (ctypes.c_longlong * 4)()
+    mock.mock_rccl_counters(before)
+    on_all(ranks, lambda r: chk(r, L.nq_slab_step(r.h, 2), "step"))
+    on_all(ranks, lambda r: chk(r, L.nq_slab_step(r.h, nsteps - 2), "step"))
+    after = (ctypes.c_longlong * 4)()
+    mock.mock_rccl_counters(after)
+    groups = {"coupled": 4, "uncoupled": 3, "qg": 2, "ybj": 2}[kind]
+    sends = after[0] - before[0]
+    assert sends == after[1] - before[1] == nsteps * 4 * groups * nchunks * nranks * (nranks - 1), (kind, nranks, sends)
+    assert after[2] - before[2] == (0 if kind == "ybj" else nsteps), "one all-reduce of the budget sums per step"
+    qh = np.concatenate([r.download(0) for r in ranks], axis=1)
+    assert rel(qh, one.field(_lib.F_QH)) < 1e-13, (kind, nranks)
+    if phi0 is not None:
+        assert rel(np.concatenate([r.download(1) for r in ranks], axis=1), one.field(_lib.F_PHIH)) < 1e-13
+        assert rel(np.concatenate([r.get_rows(_lib.F_PHI) for r in ranks], axis=0), one.field(_lib.F_PHI)) < 1e-13
+    assert rel(np.concatenate([r.get_rows(_lib.F_Q) for r in ranks], axis=0), one.field(_lib.F_Q)) < 1e-13
+    assert rel(np.concatenate([r.get_rows(_lib.F_U) for r in ranks], axis=0), one.field(_lib.F_U)) < 1e-12
+    for r in ranks:
+        if bud:
+            inc = r.budget_increments()
+            assert np.allclose(inc[:len(inc1)], inc1, rtol=1e-10, atol=1e-30), (r.rank, inc, inc1)
+    if phi0 is not None:                                 # the tick's two all-reduces, every rank calling for itself
+        d1 = one.diagnostic_sums()
+        def diag(r):
+            out = np.zeros(32)
+            chk(r, L.nq_slab_diagnostics(r.h, _lib._dptr(out)), "diagnostics")
+            return out
+        for dP in on_all(ranks, diag):
+            assert np.allclose(dP, d1, rtol=1e-10, atol=1e-13 * np.abs(d1).max())
+    for r in ranks:
+        r.close()
+    one.close()
+    print("ok", kind, nranks, nchunks, flush=True)
+print("rank threads over the mock RCCL agree with the single context")
+"""
+
+
+def test_rccl_link_with_rank_threads_over_a_mock_librccl(tmp_path):
+    """The RCCL link with MORE than one rank: P host threads, one per rank context, drive nq_comm_init / nq_slab_commit /
+    nq_slab_step / nq_slab_diagnostics concurrently, exactly as P processes would, against tests/mock_rccl -- a test
+    double of the nine librccl entry points that matches sends and receives per rank pair in posting order and refuses
+    mismatched counts.  Pins what the one-rank test with the real librccl cannot: peer indexing and block offsets of the
+    grouped send/recv, the chunk choreography under independently running ranks, the all-reduce points."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tests", "mock_rccl", "libmock_rccl.so")
+    src = os.path.join(root, "tests", "mock_rccl", "mock_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["hipcc", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src, "-lpthread"], check=True)
+    script = tmp_path / "thread_ranks.py"
+    script.write_text(THREAD_RANKS_WORKER % dict(root=root, tests=os.path.join(root, "tests")))
+    env = dict(os.environ, NIWQG_AMD_RCCL_LIB=so, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
+    if out.returncode != 0:
+        print(out.stdout[-3000:])
+        print(out.stderr[-6000:])
+    assert out.returncode == 0
+    assert "rank threads over the mock RCCL agree with the single context" in out.stdout

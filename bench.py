@@ -162,7 +162,7 @@ class _SlabCtxView(object):
             setattr(self, name, getattr(_lib.Context, name).__get__(self))
 
 
-def build_slab(model, nx, grp, local_rank, nchunks=2):
+def build_slab(model, nx, grp, local_rank, nchunks=2, kind=None):
     """One slab-decomposed simulation over all ranks of `grp` (niwqg_amd.slab).  Two stages so that the ranks can agree
     that every one of them got its memory BEFORE the first collective: allocate() then initialise()."""
     from niwqg_amd import _lib, slab
@@ -175,6 +175,9 @@ def build_slab(model, nx, grp, local_rank, nchunks=2):
     filtr = np.exp(-23.6 * (wvx - 0.65 * np.pi) ** 4.)
     filtr[wvx <= 0.65 * np.pi] = 1.
     mid = {"coupled": _lib.COUPLED, "uncoupled": _lib.UNCOUPLED, "qg": _lib.QG}[model]
+    budgets = True
+    if kind == "ybj":                 # YBJModel: the UnCoupled workload, only phi is stepped, no budgets in the step
+        mid, budgets = _lib.YBJ, False
     phys = dict(U=kw["U"], nu=kw.get("nu", 0.0), nu4=kw["nu4"], mu=kw.get("mu", 0.0))
     if model != "qg":
         kappa2 = (kw["m"] * kw["f"] / kw["N"]) ** 2
@@ -182,7 +185,7 @@ def build_slab(model, nx, grp, local_rank, nchunks=2):
 
     def allocate():
         ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], grp.world, device=local_rank, only_rank=grp.rank,
-                                budgets=True, torch_buffers=True, **phys)
+                                budgets=budgets, torch_buffers=True, **phys)
         return ranks
 
     def initialise(ranks):
@@ -330,6 +333,15 @@ def relaunch_as_ranks(n):
     return subprocess.call(cmd)
 
 
+_watchdog = {"timer": None, "phase": None, "arm": None}
+
+
+def watchdog(phase):
+    """(re-)arm the multi-rank watchdog for the next phase of the run; None disarms it"""
+    if _watchdog["arm"] is not None:
+        _watchdog["arm"](phase)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,6 +355,8 @@ def main():
     ap.add_argument("--members", type=int, default=0, help="BASELINE config 5 instead of the headline: this many "
                     "independent UnCoupledModel 1024^2 members PER GPU (8 in the config), no collective")
     ap.add_argument("--chunks", type=int, default=2, help="row chunks per exchange of the slab path (1, 2, 4, 8)")
+    ap.add_argument("--watchdog-seconds", type=int, default=600, help="multi-rank runs: abort (exit 124) when one phase "
+                    "of the run makes no progress for this long (0 = off)")
     ap.add_argument("--replicas", action="store_true", help="with --gpus N > 1: N independent replicas instead of one "
                                                             "slab-decomposed simulation")
     args = ap.parse_args()
@@ -353,6 +367,29 @@ def main():
     if env_world is not None and int(env_world) != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s: launch with torch.distributed.run --nproc-per-node %d, or "
                  "run `python bench.py --gpus %d` without a launcher" % (args.gpus, env_world, args.gpus, args.gpus))
+
+    if args.gpus > 1 and args.watchdog_seconds > 0:
+        # A rank that waits for a peer which died (or an RCCL exchange that never completes) would sit there until the
+        # launcher's own limit: give up loudly instead.  The timer is re-armed at every phase of the run.
+        import threading
+
+        def expired():
+            sys.stderr.write("bench.py rank %s: no progress for %d s in phase '%s' -- giving up\n"
+                             % (os.environ.get("RANK", "?"), args.watchdog_seconds, _watchdog["phase"]))
+            sys.stderr.flush()
+            os._exit(124)
+
+        def arm(phase):
+            if _watchdog["timer"] is not None:
+                _watchdog["timer"].cancel()
+            _watchdog["phase"] = phase
+            if phase is not None:
+                t = threading.Timer(args.watchdog_seconds, expired)
+                t.daemon = True
+                t.start()
+                _watchdog["timer"] = t
+        _watchdog["arm"] = arm
+    watchdog("set-up")
 
     from niwqg_amd.distributed import Group, aggregate_throughput
     import torch
@@ -368,12 +405,10 @@ def main():
     mode = "single GPU"
     sim = None
     if (world > 1 or (args.force_slab and grp.dist is not None)) and not args.replicas:
-        if args.model == "ybj":
-            sys.exit("bench.py: YBJModel is single-rank only")
         # ONE simulation, slab-decomposed over the ranks.  Allocation is the only step allowed to fail
         # softly: the ranks agree on it BEFORE the first collective; from then on any error is fatal (a rank that
         # dropped out of a collective sequence cannot be recovered from inside the job).
-        allocate, initialise = build_slab(args.model, args.nx, grp, local_rank, args.chunks)
+        allocate, initialise = build_slab(phys_model, args.nx, grp, local_rank, args.chunks, kind=args.model)
         err, ranks = None, None
         try:
             ranks = allocate()
@@ -399,8 +434,10 @@ def main():
         else:
             ctx.step(n)
 
+    watchdog("warm-up")
     advance(args.warmup)
     ctx.sync()
+    watchdog("timed region")
 
     def barrier():
         grp.barrier()
@@ -456,7 +493,8 @@ def main():
             # the other way to use N GPUs (config 5 style): N independent simulations, no collective.  Timed AFTER
             # and OUTSIDE the K-step region above; reported as context only, never as `value`.
             sim.sync()
-            m2 = build_model(args.model, args.nx, local_rank)
+            watchdog("replica context")
+            m2 = build_model(phys_model, args.nx, local_rank, kind=args.model)
             m2._ctx.step(2)
             m2._ctx.sync()
             grp.barrier()
@@ -517,7 +555,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(phys_model, args.nx, nx_sample=args.cpu_baseline_nx or None)
         print(json.dumps(out))
+    watchdog("shutdown")
     grp.close()
+    watchdog(None)
 
 
 if __name__ == "__main__":

@@ -264,7 +264,8 @@ def test_config4_8192_on_8_virtual_ranks_against_the_oracle():
     assert np.allclose(inc, [o.Ke - o0.Ke, o.Pw - o0.Pw, o.Kw - o0.Kw], rtol=1e-8, atol=1e-30)
 
 
-def test_bench_contract_with_two_ranks_rehearsed_over_gloo():
+@pytest.mark.parametrize("model", ["coupled", "ybj"])
+def test_bench_contract_with_two_ranks_rehearsed_over_gloo(model):
     """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), with both
     ranks on the one GPU of the test box and the collectives staged through gloo (NIWQG_AMD_DIST_BACKEND): the slab
     set-up, the all-ranks agreement, barrier + max-over-ranks timing and the single JSON line of rank 0."""
@@ -278,7 +279,7 @@ def test_bench_contract_with_two_ranks_rehearsed_over_gloo():
     env = dict(os.environ, NIWQG_AMD_DIST_BACKEND="gloo")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--nx", "256"],
+                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--nx", "256", "--model", model],
                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -290,6 +291,24 @@ def test_bench_contract_with_two_ranks_rehearsed_over_gloo():
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert "cpu_baseline" not in d                     # rank 0 at N = 1 only
+
+
+def test_bench_watchdog_ends_a_multi_rank_run_that_makes_no_progress():
+    """a rank whose peer never shows up must not sit there until the launcher's limit: bench.py gives up with exit 124"""
+    from conftest import free_port
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIWQG_AMD_DIST_BACKEND="gloo", RANK="0", LOCAL_RANK="0", WORLD_SIZE="2",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--nx", "256", "--watchdog-seconds", "5"], capture_output=True, text=True, timeout=300, env=env,
+                         cwd=root)
+    assert out.returncode == 124, (out.returncode, out.stderr[-2000:])
+    assert "no progress for 5 s in phase 'set-up'" in out.stderr and time.time() - t0 < 120
 
 
 THREAD_RANKS_WORKER = """

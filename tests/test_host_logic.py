@@ -223,5 +223,24 @@ def test_saving_layout_names_and_overwrite_rules(tmp_path):
         w.create_dataset("grid/nx", data=4, dtype=int)
         w.close()
         assert int(np.load(str(tmp_path / "x.h5"))["grid__nx"]) == 4
+        # a model spread over several processes: every rank reads its fields (a collective gather), rank 0 alone writes
+        class Ctx(object):
+            def __init__(self, rank):
+                self.group = type("G", (), {"rank": rank})()
+        m.overwrite, m._ctx = True, Ctx(1)
+        p1 = str(tmp_path / "out_rank1")
+        Saving.initialize_save_snapshots(m, p1)
+        Saving.save_setup(m)
+        m.tc, m.t = 5, 500.0
+        Saving.save_snapshots(m, fields=['t', 'q', 'phi'])
+        assert len(m._pending_snapshots) == 1                 # the fields WERE read on this rank
+        Saving.flush_snapshots(m)
+        Saving.save_diagnostics(m)
+        assert not os.path.exists(p1) and m._pending_snapshots == []
+        m._ctx = Ctx(0)
+        Saving.initialize_save_snapshots(m, p1)
+        Saving.save_snapshots(m, fields=['t', 'q', 'phi'])
+        Saving.flush_snapshots(m)
+        assert os.listdir(p1 + "/snapshots") == ["000000000000500.h5"]
     finally:
         Saving.set_writer(None)

@@ -27,6 +27,13 @@ def describe_diagnostics(model):
         print('{:<10} | {:<54}'.format(k, model.diagnostics[k]['description']))
 
 
+def _set_active_diagnostics(model, diagnostics_list):
+    """ref: niwqg/Diagnostics.py:37-39 -- a comparison, not an assignment, in the reference: every diagnostic stays
+    active whatever the list says; kept that way"""
+    for d in model.diagnostics:
+        model.diagnostics[d]['active'] == (d in diagnostics_list)
+
+
 def increment_diagnostics(model):
     """Every ``tdiags`` steps (tested BEFORE tc advances) evaluate every registered function and
     append scalars.  ref: niwqg/Diagnostics.py:41-58"""

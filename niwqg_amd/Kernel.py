@@ -242,6 +242,21 @@ class Kernel(object):
     def _calc_rel_vorticity(self):
         """q_psi is formed on the device inside the product kernel; nothing to do on the host."""
 
+    def _calc_strain(self):
+        """Geostrophic rate of strain, 4 psi_xy^2 + (psi_xx - psi_yy)^2, left in ``qg_strain`` (ref: niwqg/Kernel.py:503-509);
+        three inverse transforms through the device FFT seam."""
+        ph = self.ph
+        pxx, pyy = self.ifft(-self.k * self.k * ph).real, self.ifft(-self.l * self.l * ph).real
+        pxy = self.ifft(-self.k * self.l * ph).real
+        self.qg_strain = 4 * (pxy ** 2) + (pxx - pyy) ** 2
+
+    def _calc_OW(self):
+        """Okubo-Weiss parameter exactly as the reference forms it, qg_strain**2 - q_psi**2 with qg_strain already a
+        squared rate (ref: niwqg/Kernel.py:511-518)."""
+        self._calc_rel_vorticity()
+        self._calc_strain()
+        return self.qg_strain ** 2 - self.q_psi ** 2
+
     def jacobian_psi_q(self):
         """ik F[u q] + il F[v q], [0,0] = 0.  ref: niwqg/Kernel.py:471-486"""
         return self._ctx.jacobian_psi_q()

@@ -174,6 +174,19 @@ class Model(object):
         self._cache.pop("ph", None)
         self._cache.pop("p", None)
 
+    # hooks the reference declares and never calls (ref: niwqg/QGModel.py:271-281, :303-304)
+    def _initialize_background(self):
+        raise NotImplementedError('needs to be implemented by Model subclass')
+
+    def _initialize_inversion_matrix(self):
+        raise NotImplementedError('needs to be implemented by Model subclass')
+
+    def _initialize_forcing(self):
+        raise NotImplementedError('needs to be implemented by Model subclass')
+
+    def _do_external_forcing(self):
+        pass
+
     def jacobian_psi_q(self):
         """ik F[u q] + il F[v q] on the half spectrum, [0,0] NOT zeroed.  ref: niwqg/QGModel.py:469-481"""
         return self._ctx.jacobian_psi_q()

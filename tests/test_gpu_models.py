@@ -632,3 +632,22 @@ def test_tick_side_effect_fields_on_demand():
         assert rel(getattr(m, name), want[name]) < 1e-10, name      # qh's Nyquist-row passenger is in phq
     cross = (m.uq * m.uw).mean() + (m.vq * m.vw).mean()
     assert abs(cross - m.diagnostics["ke_qg_qw"]["value"][-1]) < 1e-10 * abs(cross)
+
+
+@pytest.mark.parametrize("slab", [False, 2])
+def test_strain_and_okubo_weiss_helpers(slab):
+    """Kernel._calc_strain / _calc_OW (ref: niwqg/Kernel.py:503-518) through the device FFT seam, whole-plane and slab model,
+    against the reference's formulas evaluated with numpy on the downloaded psi-hat."""
+    from niwqg_amd import InitialConditions as ic
+    m = models().CoupledModel.Model(slab=slab, **notebook_kwargs(64, True))
+    q0 = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+    m.set_q(q0)
+    m.set_phi(ic.WavePacket(m, k=3 * K0, l=K0, R=L / 6, x0=L / 3, y0=L / 2))
+    m._invert()
+    ow = m._calc_OW()
+    ph = m.ph
+    pxx, pyy = np.fft.ifft2(-m.k * m.k * ph).real, np.fft.ifft2(-m.l * m.l * ph).real
+    pxy = np.fft.ifft2(-m.k * m.l * ph).real
+    strain = 4 * pxy ** 2 + (pxx - pyy) ** 2
+    assert rel(m.qg_strain, strain) < 1e-13
+    assert rel(ow, strain ** 2 - m.q_psi ** 2) < 1e-12

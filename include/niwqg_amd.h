@@ -168,8 +168,9 @@ int nq_refraction(nq_ctx* ctx, double* out_cplx);
  * which the last step evaluated its fourth stage, as the reference's are at a tick).                          */
 int nq_diagnostics(nq_ctx* ctx, double* out32);
 
-/* copy of one ETDRK4 coefficient plane (0:E 1:Eh 2:Q 3:f0 4:fab 5:fc) of equation eq (0:q 1:phi),
- * without the filter folded in; host layout as the reference's expch, expch_h, Qh, f0, fab, fc.      */
+/* copy of one ETDRK4 coefficient plane (0:E 1:Eh 2:Q 3:f0 4:fab 5:fc) of equation eq (0: q, (nx, nx/2+1) complex;
+ * 1: phi, (nx, nx) complex; 2: QGModel's passive scalar, (nx, nx/2+1)), without the filter folded in; values as the
+ * reference's expch, expch_h, Qh, f0, fab, fc (Kernel.py:417-454, QGModel.py:426-461).                           */
 int nq_get_coeff(nq_ctx* ctx, int eq, int which, double* out_cplx);
 
 /* ---- 1-D slab decomposition over nranks GPUs (one process per GPU) -----------------

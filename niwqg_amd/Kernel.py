@@ -74,6 +74,9 @@ class Kernel(object):
         # the device then keeps a second half-spectrum copy ("dual copy").  exact_qh=True asks for
         # the same with symmetric filters, which reproduces the reference's qh on the Nyquist row as well.
         self._dual = bool(exact_qh) or (bool(dealias) and not use_filter)
+        # ref: niwqg/CoupledModel.py:38-42 / UnCoupledModel.py / YBJModel.py (_allocate_variables): array types and shapes
+        self.dtype_real, self.dtype_cplx = np.dtype('float64'), np.dtype('complex128')
+        self.shape_real = self.shape_cplx = (self.ny, self.nx)
 
         self._initialize_logger()
         self.logger.info(self.model)
@@ -134,6 +137,8 @@ class Kernel(object):
         self.M = self.nx * self.ny
 
     _LAZY = ("x", "y", "k", "l", "ik", "il", "wv2", "wv", "wv4", "wv2i")
+    _COEFF = dict(expch=(0, 0), expch_h=(0, 1), Qh=(0, 2), f0=(0, 3), fab=(0, 4), fc=(0, 5), expch2=(0, 6),
+                  expchw=(1, 0), expch_hw=(1, 1), Qhw=(1, 2), f0w=(1, 3), fabw=(1, 4), fcw=(1, 5), expch2w=(1, 6))
 
     def __getattr__(self, name):
         if name in Kernel._LAZY:
@@ -141,6 +146,12 @@ class Kernel(object):
             return self.__dict__[name]
         if name in _DEVICE_FIELDS or name in ("qh", "ph", "qwh", "q_psi", "qw"):
             return self._field(name)
+        if name in Kernel._COEFF:         # ETDRK4 coefficient planes (ref: niwqg/Kernel.py:417-454), from the device on demand
+            eq, which = Kernel._COEFF[name]
+            v = self._ctx.coeff(eq, which if which < 6 else 0)
+            if eq == 0:                   # device keeps k = 0..nx/2; c(l,-k) = conj c(l,k), and so is every plane derived from it
+                v = np.concatenate([v, np.conj(v[:, 1:self.nx // 2][:, ::-1])], axis=1)
+            return v * v if which == 6 else v          # expch2 = exp(2 c dt)
         if name == "lapphi":             # fields the reference leaves behind after a diagnostics tick, on demand
             return self.ifft(-self.wv2 * self.phih)
         if name == "upsilon":

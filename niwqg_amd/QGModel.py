@@ -24,6 +24,8 @@ class Model(object):
         # ref: niwqg/QGModel.py:93-139
         self.nx = nx
         self.ny = nx
+        self.dtype_real, self.dtype_cplx = np.dtype('float64'), np.dtype('complex128')      # ref: niwqg/QGModel.py:147-150
+        self.shape_real, self.shape_cplx = (self.ny, self.nx), (self.ny, self.nx // 2 + 1)
         self.L = L
         self.W = L
         self.dt, self.twrite, self.tswrite, self.tmax, self.tdiags = dt, twrite, tswrite, tmax, tdiags
@@ -83,8 +85,15 @@ class Model(object):
         self.M = self.nx * self.ny
 
     _LAZY = ("x", "y", "k", "l", "ik", "il", "wv2", "wv", "wv4", "wv2i")
+    # ETDRK4 coefficient planes (ref: niwqg/QGModel.py:426-461), from the device on demand; the "c" ones with the scalar
+    _COEFF = dict(expch=(0, 0), expch_h=(0, 1), Qh=(0, 2), f0=(0, 3), fab=(0, 4), fc=(0, 5), expch2=(0, 6),
+                  expchc=(2, 0), expch_hc=(2, 1), Qhc=(2, 2), f0c=(2, 3), fabc=(2, 4), fcc=(2, 5), expch2c=(2, 6))
 
     def __getattr__(self, name):
+        if name in Model._COEFF and (Model._COEFF[name][0] == 0 or self.__dict__.get("passive_scalar")):
+            eq, which = Model._COEFF[name]
+            v = self._ctx.coeff(eq, which if which < 6 else 0)
+            return v * v if which == 6 else v
         if name in Model._LAZY:
             d = self.__dict__
             d["x"], d["y"] = np.meshgrid(np.arange(0.5, self.nx, 1.) / self.nx * self.L,

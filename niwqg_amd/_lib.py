@@ -252,7 +252,7 @@ class Context:
 
     def coeff(self, eq, which):
         n = self.nx
-        w = n // 2 + 1 if eq == 0 else n
+        w = n if eq == 1 else n // 2 + 1
         out = np.empty((n, w), np.complex128)
         self._chk(self.L.nq_get_coeff(self.h, eq, which, _dptr(out.view(np.float64))), "nq_get_coeff")
         return out

@@ -2918,19 +2918,20 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
 }
 
 int nq_get_coeff(nq_ctx* c, int eq, int which, double* out) {
-  if (!c || !out || which < 0 || which > 5 || eq < 0 || eq > 1) return -1;
+  if (!c || !out || which < 0 || which > 5 || eq < 0 || eq > 2) return -1;
   NQ_SINGLE_RANK(c, "nq_get_coeff");
   if (eq == 1 && !c->kernel_family) NQ_FAIL(c, -4, "no phi equation in QGModel");
+  if (eq == 2 && !c->passive) NQ_FAIL(c, -4, "no passive scalar in this context");
   HIPCHK(c, hipSetDevice(c->device));
   const int N = c->N;
-  const bool half = eq == 0;
+  const bool half = eq != 1;
   const int width = half ? c->Wh : N, pitch = half ? c->Ph : N;
   const size_t cnt = (size_t)N * pitch;
   cd* tmp[6];
   void* blockp = nullptr;                               // one allocation: nothing to leak when it fails
   HIPCHK(c, hipMalloc(&blockp, 6 * cnt * sizeof(cd)));
   for (int i = 0; i < 6; ++i) tmp[i] = reinterpret_cast<cd*>(blockp) + (size_t)i * cnt;
-  const int e = half ? (c->kernel_family ? 0 : 2) : 1;
+  const int e = eq == 2 ? 3 : (half ? (c->kernel_family ? 0 : 2) : 1);
   hipLaunchKernelGGL(k_etdrk4_coeffs, dim3((width + 63) / 64, N), dim3(64), 0, c->stream, e, N, width, pitch, 0, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5]);
   hipError_t er = hipMemcpy2DAsync(out, sizeof(cd) * width, tmp[which], sizeof(cd) * pitch, sizeof(cd) * width, N, hipMemcpyDeviceToHost, c->stream);
   int rc = nq_sync(c);

@@ -651,3 +651,31 @@ def test_strain_and_okubo_weiss_helpers(slab):
     strain = 4 * pxy ** 2 + (pxx - pyy) ** 2
     assert rel(m.qg_strain, strain) < 1e-13
     assert rel(ow, strain ** 2 - m.q_psi ** 2) < 1e-12
+
+
+def test_etdrk4_coefficient_attributes_of_the_class_surface(golden):
+    """m.expch, m.expch_h, m.Qh, m.f0, m.fab, m.fc (+ the `w` planes, expch2, and QGModel's `c` planes): the attributes the
+    reference's _initialize_etdrk4 leaves on the model (Kernel.py:417-454, QGModel.py:426-461), here downloaded from the
+    device on demand -- against the reference's own arrays (golden g1) and, for QGModel, against the oracle."""
+    g = golden("g1_functions_64.npz")
+    m = models().CoupledModel.Model(**notebook_kwargs(64, True))
+    for mine, ref in (("expch", "expch"), ("expch_h", "expch_h"), ("Qh", "Qh"), ("f0", "f0"), ("fab", "fab"), ("fc", "fc"),
+                      ("expchw", "expchw"), ("expch_hw", "expch_hw"), ("Qhw", "Qhw"), ("f0w", "f0w"), ("fabw", "fabw"),
+                      ("fcw", "fcw")):
+        a, b = getattr(m, mine), g[ref]
+        assert a.shape == b.shape == (64, 64), mine
+        assert np.all(np.abs(a - b) <= 1e-11 * np.abs(b)), (mine, np.abs(a - b).max())
+    assert rel(m.expch2, g["expch"] ** 2) < 1e-13 and rel(m.expch2w, g["expchw"] ** 2) < 1e-13
+    assert m.shape_real == m.shape_cplx == (64, 64) and m.dtype_cplx == np.complex128 and m.dtype_real == np.float64
+    kw = dict(L=L, nx=64, tmax=1e30, dt=2000.0, twrite=10 ** 9, nu4=7.5e8 * 16, nu=5.0, mu=1e-8, use_filter=True, U=-U0,
+              tdiags=10 ** 9, beta=2e-11, passive_scalar=True, nu4c=3e9, nuc=2.0, muc=1e-8)
+    o = O.QGOracle(**kw)
+    q = models().QGModel.Model(**kw)
+    assert q.shape_real == (64, 64) and q.shape_cplx == (64, 33)
+    for nm, key in (("expch", "E"), ("expch_h", "Eh"), ("Qh", "Q"), ("f0", "f0"), ("fab", "fab"), ("fc", "fc")):
+        a, b = getattr(q, nm), o.coef_q[key]
+        assert a.shape == b.shape == (64, 33) and np.all(np.abs(a - b) <= 1e-11 * np.abs(b)), nm
+        a, b = getattr(q, nm + "c" if nm not in ("Qh",) else "Qhc"), o.coef_c[key]
+        assert np.all(np.abs(a - b) <= 1e-11 * np.abs(b)), nm + " (scalar)"
+    with pytest.raises(AttributeError):
+        models().QGModel.Model(**dict(kw, passive_scalar=False)).expchc

@@ -152,6 +152,9 @@ class Kernel(object):
             if eq == 0:                   # device keeps k = 0..nx/2; c(l,-k) = conj c(l,k), and so is every plane derived from it
                 v = np.concatenate([v, np.conj(v[:, 1:self.nx // 2][:, ::-1])], axis=1)
             return v * v if which == 6 else v          # expch2 = exp(2 c dt)
+        if name == "c":                  # the linear operator the reference leaves behind: the wave equation's (Kernel.py:440-442)
+            advect = np.zeros((self.nl, self.nk), complex) - 1j * self.k * self.U
+            return advect + (-self.nu4w * self.wv4 - 0.5j * self.f * (self.wv2 / self.kappa2) - self.nuw * self.wv2 - self.muw)
         if name == "lapphi":             # fields the reference leaves behind after a diagnostics tick, on demand
             return self.ifft(-self.wv2 * self.phih)
         if name == "upsilon":

@@ -666,6 +666,7 @@ def test_etdrk4_coefficient_attributes_of_the_class_surface(golden):
         assert a.shape == b.shape == (64, 64), mine
         assert np.all(np.abs(a - b) <= 1e-11 * np.abs(b)), (mine, np.abs(a - b).max())
     assert rel(m.expch2, g["expch"] ** 2) < 1e-13 and rel(m.expch2w, g["expchw"] ** 2) < 1e-13
+    assert np.array_equal(np.exp(m.c * m.dt), g["expchw"])       # m.c: the operator the reference leaves behind (the wave one)
     assert m.shape_real == m.shape_cplx == (64, 64) and m.dtype_cplx == np.complex128 and m.dtype_real == np.float64
     kw = dict(L=L, nx=64, tmax=1e30, dt=2000.0, twrite=10 ** 9, nu4=7.5e8 * 16, nu=5.0, mu=1e-8, use_filter=True, U=-U0,
               tdiags=10 ** 9, beta=2e-11, passive_scalar=True, nu4c=3e9, nuc=2.0, muc=1e-8)

@@ -268,3 +268,27 @@ def test_rough_coupled_step_against_the_reference_itself_at_2048(golden):
     assert eq < 1e-11 and ep < 1e-11
     assert rel(m.q[::32, ::32], g["cpl_q_sub"]) < 1e-11 and rel(m.phi[::32, ::32], g["cpl_phi_sub"]) < 1e-11
     assert np.allclose([m.Ke, m.Pw, m.Kw], g["cpl_budgets"], rtol=1e-8)
+
+
+def test_headline_grid_on_eight_slab_ranks_equals_the_single_context():
+    """CoupledModel 4096^2 (BASELINE's headline grid) decomposed over 8 peer ranks on the one GPU, white-noise state with
+    every dissipation term on: three steps through the class API give the single-context model's fields and budgets --
+    which `test_rough_field_coupled_step_against_the_oracle[4096]` pins to the oracle."""
+    import niwqg_amd
+    rng = np.random.default_rng(7)
+    kw = notebook_kwargs(4096, True)
+    kw.update(nu4w=1e10, mu=1e-8, muw=2e-8)
+    q0 = 1e-5 * rng.standard_normal((4096, 4096))
+    phi0 = 0.05 * (rng.standard_normal((4096, 4096)) + 1j * rng.standard_normal((4096, 4096)))
+    res = {}
+    for tag, slab in (("one", False), ("slab8", 8)):
+        m = niwqg_amd.CoupledModel.Model(slab=slab, nchunks=2, **kw)
+        m.set_q(q0)
+        m.set_phi(phi0)
+        steps(m, 3)
+        res[tag] = (m.q.copy(), m.phi.copy(), m.phih.copy(), [m.Ke, m.Pw, m.Kw])
+        m._ctx.close()
+        del m
+    a, b = res["one"], res["slab8"]
+    assert rel(b[0], a[0]) < 1e-13 and rel(b[1], a[1]) < 1e-13 and rel(b[2], a[2]) < 1e-13
+    assert np.allclose(b[3], a[3], rtol=1e-11)

@@ -139,6 +139,7 @@ struct nq_ctx {
   std::vector<hipEvent_t> xev;         // timing pairs around every exchange chunk on mstream (when counting)
   size_t xev_used = 0;
   bool xtime = false;
+  bool alloc_plain = false;            // dev_alloc: no skew (exchange-group buffers: whole rows, read by the row kernels)
   int spec_kind = -1;                  // what the scratch column slab of nq_slab_spectral holds: 1 half-spectrum, 0 full width
   bool ybj = false;
   bool passive = false;  // QGModel with its passive scalar: state cq, spectrum emitted through the qw slots of G3 / G0
@@ -146,14 +147,28 @@ struct nq_ctx {
   MArr mUc, mVc;      // niwqg.YBJModel: UnCoupled layouts, only phi is stepped (stage graph in do_step_ybj)
 };
 
+// Device arrays start at staggered offsets inside their allocations.  hipMalloc hands out large blocks at addresses that
+// differ by multiples of 2 MiB (the 256 MiB planes: by exact multiples of their size), so element idx of every state,
+// tendency and coefficient plane a spectral kernel touches in one go would sit in the same DRAM channel and bank; a few
+// KB of skew per array spreads them (tools/rw_mix_bench.hip: +12-24 % for kernels with 4-8 streams).
+static size_t alloc_stagger_bytes() {
+  static long v = -1;
+  if (v < 0) {
+    const char* e = getenv("NIWQG_AMD_ALLOC_STAGGER");
+    v = e ? atol(e) : 4352;
+    if (v < 0 || v % 256) v = 0;
+  }
+  return (size_t)v;
+}
 template <typename Tp>
 static int dev_alloc(nq_ctx* c, Tp** out, size_t count) {
   void* p = nullptr;
-  HIPCHK(c, hipMalloc(&p, count * sizeof(Tp)));
-  HIPCHK(c, hipMemsetAsync(p, 0, count * sizeof(Tp), c->stream));
+  const size_t skew = c->alloc_plain ? 0 : (c->allocs.size() % 16) * alloc_stagger_bytes();
+  HIPCHK(c, hipMalloc(&p, count * sizeof(Tp) + skew));
+  HIPCHK(c, hipMemsetAsync(p, 0, count * sizeof(Tp) + skew, c->stream));
   c->allocs.push_back(p);
   c->bytes += (long long)(count * sizeof(Tp));
-  *out = reinterpret_cast<Tp*>(p);
+  *out = reinterpret_cast<Tp*>(static_cast<char*>(p) + skew);
   return 0;
 }
 #define ALLOC(c, ptr, count)                    \
@@ -1804,9 +1819,11 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
         HIPCHK(c, hipMemsetAsync(c->G[gi].bx, 0, c->G[gi].elems * sizeof(cd), c->stream));
         HIPCHK(c, hipMemsetAsync(c->G[gi].by, 0, c->G[gi].elems * sizeof(cd), c->stream));
       } else {
+        c->alloc_plain = true;
         ALLOC(c, c->G[gi].bx, c->G[gi].elems);
         if (P == 1) c->G[gi].by = c->G[gi].bx;
         else ALLOC(c, c->G[gi].by, c->G[gi].elems);
+        c->alloc_plain = false;
       }
     }
     c->mUq = make_marr(sg, c->G[0].bx, c->G[0].by, 0, 0, true);

@@ -46,11 +46,21 @@ static void run(Ptrs in, Ptrs out, size_t n, double* sink) {
          R * n * 16e-9 / best * 1e3, W * n * 16e-9 / best * 1e3);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  // argv[1]: stagger in bytes -- array i starts i * stagger bytes into its allocation (0: all arrays at offsets that are
+  // multiples of 512 MiB apart, i.e. the same index of every array maps to the same DRAM channel and bank)
+  const size_t stagger = argc > 1 ? (size_t)atol(argv[1]) : 0;
   const size_t n = (size_t)512 * 1024 * 1024 / 16;
+  printf("stagger %zu bytes\n", stagger);
   Ptrs in, out;
-  for (int i = 0; i < 8; ++i) { CK(hipMalloc(&in.p[i], n * 16)); CK(hipMemset(in.p[i], 0, n * 16)); }
-  for (int i = 0; i < 4; ++i) { CK(hipMalloc(&out.p[i], n * 16)); CK(hipMemset(out.p[i], 0, n * 16)); }
+  for (int i = 0; i < 8; ++i) {
+    char* b; CK(hipMalloc(&b, n * 16 + 16 * stagger)); CK(hipMemset(b, 0, n * 16 + 16 * stagger));
+    in.p[i] = reinterpret_cast<cd*>(b + i * stagger);
+  }
+  for (int i = 0; i < 4; ++i) {
+    char* b; CK(hipMalloc(&b, n * 16 + 16 * stagger)); CK(hipMemset(b, 0, n * 16 + 16 * stagger));
+    out.p[i] = reinterpret_cast<cd*>(b + (8 + i) * stagger);
+  }
   for (int i = 4; i < 8; ++i) out.p[i] = nullptr;
   double* sink; CK(hipMalloc(&sink, 8));
   run<1, 0>(in, out, n, sink); run<2, 0>(in, out, n, sink); run<4, 0>(in, out, n, sink); run<8, 0>(in, out, n, sink);

@@ -28,10 +28,9 @@ def describe_diagnostics(model):
 
 
 def _set_active_diagnostics(model, diagnostics_list):
-    """ref: niwqg/Diagnostics.py:37-39 -- a comparison, not an assignment, in the reference: every diagnostic stays
-    active whatever the list says; kept that way"""
-    for d in model.diagnostics:
-        model.diagnostics[d]['active'] == (d in diagnostics_list)
+    """Same signature as ref niwqg/Diagnostics.py:37-39, same effect: none.  The reference's loop evaluates
+    ``active == (name in list)`` and throws the result away, so every registered diagnostic stays active."""
+    return None
 
 
 def increment_diagnostics(model):

@@ -161,7 +161,8 @@ class Context:
         kk = np.ascontiguousarray(kk, dtype=np.float64)
         ll = np.ascontiguousarray(ll, dtype=np.float64)
         filtr = np.ascontiguousarray(filtr, dtype=np.float64)
-        assert kk.shape == (self.nk,) and ll.shape == (nx,) and filtr.shape == (nx, self.nk)
+        if kk.shape != (self.nk,) or ll.shape != (nx,) or filtr.shape != (nx, self.nk):
+            raise ValueError("kk %s, ll %s, filtr %s do not fit nx = %d (nk = %d)" % (kk.shape, ll.shape, filtr.shape, nx, self.nk))
         # roots of unity of the ETDRK4 contour mean, built exactly like the reference (Kernel.py:424-426)
         r = np.exp(2j * np.pi * (np.arange(1.0, 33.0) / 32.0))
         r = np.ascontiguousarray(r).view(np.float64)
@@ -192,19 +193,25 @@ class Context:
             pass
 
     # --- state
+    @staticmethod
+    def _shape(a, shape, what):
+        """the C ABI takes plain pointers: a host array of the wrong size must never reach it"""
+        if a.shape != tuple(shape):
+            raise ValueError("%s: array of shape %s, expected %s" % (what, a.shape, tuple(shape)))
+
     def set_q(self, q):
         q = np.ascontiguousarray(q, dtype=np.float64)
-        assert q.shape == (self.nx, self.nx)
+        self._shape(q, (self.nx, self.nx), "set_q")
         self._chk(self.L.nq_set_q(self.h, _dptr(q)), "nq_set_q")
 
     def set_c(self, c):
         c = np.ascontiguousarray(c, dtype=np.float64)
-        assert c.shape == (self.nx, self.nx)
+        self._shape(c, (self.nx, self.nx), "set_c")
         self._chk(self.L.nq_set_c(self.h, _dptr(c)), "nq_set_c")
 
     def set_phi(self, phi):
         phi = np.ascontiguousarray(phi, dtype=np.complex128)
-        assert phi.shape == (self.nx, self.nx)
+        self._shape(phi, (self.nx, self.nx), "set_phi")
         self._chk(self.L.nq_set_phi(self.h, _dptr(phi.view(np.float64))), "nq_set_phi")
 
     def invert(self):
@@ -234,7 +241,8 @@ class Context:
             out = np.empty((n, h), np.complex128)
         else:
             out = np.empty((n, n), np.complex128)
-        assert out.view(np.float64).size == nd, fid
+        if out.view(np.float64).size != nd:
+            raise RuntimeError("field %d: the library writes %d doubles, the binding allocated %d" % (fid, nd, out.view(np.float64).size))
         self._chk(self.L.nq_get_field(self.h, fid, _dptr(out.view(np.float64))), "nq_get_field(%d)" % fid)
         return out
 
@@ -269,8 +277,9 @@ class Context:
         return q, phi
 
     # --- FFT seam
-    def _xf(self, fn, a, in_dtype, out_shape, out_dtype):
+    def _xf(self, fn, a, in_dtype, out_shape, out_dtype, in_shape=None):
         a = np.ascontiguousarray(a, dtype=in_dtype)
+        self._shape(a, in_shape or (self.nx, self.nx), fn.__name__)
         out = np.empty(out_shape, out_dtype)
         self._chk(fn(self.h, _dptr(a.view(np.float64)), _dptr(out.view(np.float64))), fn.__name__)
         return out
@@ -285,7 +294,7 @@ class Context:
         return self._xf(self.L.nq_rfft2, a, np.float64, (self.nx, self.nx // 2 + 1), np.complex128)
 
     def irfft2(self, a):
-        return self._xf(self.L.nq_irfft2, a, np.complex128, (self.nx, self.nx), np.float64)
+        return self._xf(self.L.nq_irfft2, a, np.complex128, (self.nx, self.nx), np.float64, in_shape=(self.nx, self.nx // 2 + 1))
 
     # --- Jacobians in the reference's layouts (assembled on the device)
     def jacobian_psi_q(self):

@@ -105,7 +105,8 @@ class SlabRank(object):
 
     def put_rows(self, which, rows):
         rows = np.ascontiguousarray(rows, np.complex128 if which == 1 else np.float64)     # 0: q, 1: phi, 2: c
-        assert rows.shape == (self.nloc, self.nx), rows.shape
+        if rows.shape != (self.nloc, self.nx):
+            raise ValueError("put_rows: rows of shape %s, this rank holds %s" % (rows.shape, (self.nloc, self.nx)))
         self._chk(self.L.nq_slab_put_rows(self.h, which, _lib._dptr(rows.view(np.float64))), "nq_slab_put_rows")
 
     def get_rows(self, fid):
@@ -183,7 +184,8 @@ class SlabSimulation(object):
             self.lead._chk(self.L.nq_slab_attach_peers(arr, self.nranks), "nq_slab_attach_peers")
         elif link == "rccl":
             import torch
-            assert len(ranks) == 1 and dist is not None
+            if len(ranks) != 1 or dist is None:
+                raise ValueError("rccl link: one rank per process and a torch.distributed group")
             uid = torch.zeros(128, dtype=torch.uint8)
             if self.lead.rank == 0:
                 buf = (ctypes.c_ubyte * 128)()
@@ -196,7 +198,8 @@ class SlabSimulation(object):
             self.lead._chk(self.L.nq_comm_init(self.lead.h, buf, self.nranks, self.lead.rank), "nq_comm_init")
         elif link == "callback":
             import torch
-            assert len(ranks) == 1 and dist is not None and self.lead.gx[0] is not None, "callback link needs torch buffers"
+            if len(ranks) != 1 or dist is None or self.lead.gx[0] is None:
+                raise ValueError("callback link: one rank per process, a torch.distributed group and torch buffers (torch_buffers=True)")
             r, host = self.lead, bool(stage_via_host)
             dev = torch.device("cuda", r.device)
 
@@ -397,15 +400,21 @@ class SlabContext(object):
         self._ds = None
 
     def set_q(self, q):
-        self.sim.set_q(np.asarray(q, np.float64))
+        q = np.asarray(q, np.float64)
+        _lib.Context._shape(q, (self.nx, self.nx), "set_q")
+        self.sim.set_q(q)
         self._touch()
 
     def set_phi(self, phi):
-        self.sim.set_phi(np.asarray(phi, np.complex128))
+        phi = np.asarray(phi, np.complex128)
+        _lib.Context._shape(phi, (self.nx, self.nx), "set_phi")
+        self.sim.set_phi(phi)
         self._touch()
 
     def set_c(self, c):
-        self.sim.set_c(np.asarray(c, np.float64))
+        c = np.asarray(c, np.float64)
+        _lib.Context._shape(c, (self.nx, self.nx), "set_c")
+        self.sim.set_c(c)
         self._touch()
 
     def invert(self):
@@ -486,14 +495,14 @@ class SlabContext(object):
 
     def rfft2(self, a):
         a = np.asarray(a, np.float64)
-        assert a.shape == (self.nx, self.nx), a.shape
+        _lib.Context._shape(a, (self.nx, self.nx), "rfft2")
         for r in self.sim.ranks:
             r.put_rows(0, a[r.rank * r.nloc:(r.rank + 1) * r.nloc])
         return self._spectral(5, True)
 
     def fft2(self, a):
         a = np.asarray(a, np.complex128)
-        assert a.shape == (self.nx, self.nx), a.shape
+        _lib.Context._shape(a, (self.nx, self.nx), "fft2")
         if self.model == _lib.QG:                      # no complex carrier in QGModel's exchange groups: two real transforms
             from .Kernel import hermitian_full
             return hermitian_full(self.rfft2(a.real)) + 1j * hermitian_full(self.rfft2(a.imag))
@@ -508,7 +517,7 @@ class SlabContext(object):
         """numpy.fft.irfft2 semantics: the self-mirrored columns count with their Hermitian part (in l) only"""
         from .Kernel import hermitian_full, project_self_mirrored_columns
         a = np.asarray(a, np.complex128)
-        assert a.shape == (self.nx, self.nx // 2 + 1), a.shape
+        _lib.Context._shape(a, (self.nx, self.nx // 2 + 1), "irfft2")
         return np.ascontiguousarray(self.ifft2(hermitian_full(project_self_mirrored_columns(a))).real)
 
     def products_uq_vq(self):

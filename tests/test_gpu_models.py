@@ -680,3 +680,36 @@ def test_etdrk4_coefficient_attributes_of_the_class_surface(golden):
         assert np.all(np.abs(a - b) <= 1e-11 * np.abs(b)), nm + " (scalar)"
     with pytest.raises(AttributeError):
         models().QGModel.Model(**dict(kw, passive_scalar=False)).expchc
+
+
+@pytest.mark.parametrize("slab", [False, 2])
+def test_malformed_and_degenerate_inputs(slab):
+    """The C ABI takes plain pointers, so a host array of the wrong size has to be stopped in the binding (ValueError, also
+    under `python -O`); unsupported grids are refused at construction; identically zero fields step to zero without NaNs
+    (the reference's own diffusion test runs with phi = 0, niwqg/tests/test_diffusion.py)."""
+    M = models()
+    m = M.CoupledModel.Model(slab=slab, **notebook_kwargs(64, True, tdiags=1))
+    for bad in (np.zeros((64, 32)), np.zeros((32, 64)), np.zeros(64 * 64), np.zeros((65, 64))):
+        with pytest.raises(ValueError):
+            m.set_q(bad)
+        with pytest.raises(ValueError):
+            m.set_phi(bad.astype(complex))
+        with pytest.raises(ValueError):
+            m.fft(bad.astype(complex))
+        with pytest.raises(ValueError):
+            m.ifft(bad.astype(complex))
+    m.set_q(np.zeros((64, 64)))
+    m.set_phi(np.zeros((64, 64), complex))
+    with np.errstate(all="ignore"):                 # conc_niw is 0/0 for phi = 0 in the reference as well
+        steps(m, 3)
+    assert np.all(m.q == 0) and np.all(m.phi == 0) and np.all(np.isfinite(m.qh)) and m.Ke == 0 and m.Kw == 0
+    q = M.QGModel.Model(L=L, nx=64, tmax=1e30, dt=1000.0, twrite=10 ** 9, nu4=7.5e8, use_filter=True, U=-U0,
+                        tdiags=10 ** 9, slab=slab)
+    with pytest.raises(ValueError):
+        q.set_q(np.zeros((64, 33)))
+    with pytest.raises(ValueError):
+        q.ifft(np.zeros((64, 64), complex))         # irfft2 takes the (ny, nx/2+1) half spectrum
+    if not slab:
+        for nx in (96, 32, 16384):
+            with pytest.raises(RuntimeError):
+                M.CoupledModel.Model(**notebook_kwargs(nx, True))

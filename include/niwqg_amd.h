@@ -113,6 +113,13 @@ int nq_sync(nq_ctx* ctx);
 int nq_get_field(nq_ctx* ctx, int field_id, double* host_out);
 /* number of doubles nq_get_field(field_id) writes for this context (-1: unknown id or NULL ctx) */
 long long nq_field_doubles(const nq_ctx* ctx, int field_id);
+/* The reference's full-plane qh is not exactly Hermitian: on row l = ny/2 the il term of jacobian_psi_q
+ * (Kernel.py:471-486; numpy's ll[ny/2] is not odd) adds an anti-Hermitian part A_k that every stage update carries
+ * along (Kernel.py:327, :347, :364, :381) and that never reaches physical space.  The device evolves it as ONE extra row
+ * beside the half spectrum; out_cplx receives A_k for this context's local half-spectrum columns (nx/2+1 complex values
+ * on a single context, entries k = 0 and nx/2 zero; all zeros for QGModel, YBJModel and dual_q contexts):
+ *     qh_ref[ny/2, k] = qh[ny/2, k] + A_k,     qh_ref[ny/2, nx-k] = conj(qh[ny/2, k]) - conj(A_k),   0 < k < nx/2.    */
+int nq_get_qh_passenger(nq_ctx* ctx, double* out_cplx);
 int nq_get_scalar(nq_ctx* ctx, int scalar_id, double* out);
 
 /* Snapshots that do not stall the stepper (niwqg/Saving.py:59-86 saves t, q, phi every tsave_snapshots steps):
@@ -177,9 +184,11 @@ int nq_get_coeff(nq_ctx* ctx, int eq, int which, double* out_cplx);
  * Rows of the mixed-space planes are split over ranks on the "x side" (row kernels), columns on the "y side"
  * (spectral kernels).  Arrays that cross together form an exchange group g = 0..3; each group has an x-side
  * and a y-side buffer of nq_group_elems() complex128 elements, both cut into nranks equal blocks, so that ONE
- * all_to_all_single(recv = other side, send = this side) moves the group.  The caller owns the collectives
- * (torch.distributed / RCCL); the library only runs the phases in between, on the stream it was given (stream ==
- * NULL: a private stream the library creates -- then the caller must order its collectives against nq_stream()).
+ * all_to_all_single(recv = other side, send = this side) moves the group.  Two ways to drive a step: nq_slab_step
+ * (below: the library runs the phases AND issues the exchanges itself over the link the context was given -- the
+ * product path), or phase by phase with nq_phase, where the CALLER owns the collectives (torch.distributed / RCCL) and
+ * the library only runs the phases in between, on the stream it was given (stream == NULL: a private stream the
+ * library creates -- then the caller must order its collectives against nq_stream()).
  *   buffers[2g], buffers[2g+1] : x-side and y-side device buffers of group g (may be NULL for empty groups)
  *   buffers[8]                 : 64 doubles for the per-step budget sums (summed over ranks by the caller)
  * buffers == NULL: the library allocates all of them itself (nq_group_buffers / nq_reduce_buffer give the pointers).   */
@@ -228,10 +237,14 @@ int nq_reduce_write(nq_ctx* ctx, int which, const double* host_in);
  * nq_slab_put_rows + nq_slab_commit: Kernel.set_q / set_phi (Kernel.py:520-551) from this rank's ROWS of the physical
  * field (nloc rows of nx values, real / complex): row transform on the device (put_rows, local), then exchange, column
  * transform and the phases of the single-rank calls (commit, collective) -- no rank ever holds or transforms the whole plane.
- * nq_slab_get_rows: this rank's rows (nloc, nx) of a physical field (NQ_F_Q, _P, _U, _V, _QW, _QPSI, _C real; _PHI, _PHIX,
- * _PHIY complex) from the mixed-space rows the last step left on the x side. */
+ * nq_slab_get_rows: this rank's rows (nloc, nx) of a physical field (NQ_F_Q, _P, _U, _V, _QW, _C real; _PHI, _PHIX,
+ * _PHIY complex) from the mixed-space rows the last step left on the x side (q_psi = q - qw: two calls).
+ * nq_comm_probe: 0 when this process can resolve librccl (load only, no communicator) -- every rank calls it and the
+ * ranks agree on the outcome BEFORE rank 0 asks for an id, so that nobody is left alone in a collective. */
 typedef int (*nq_exchange_fn)(void* user, int group, int to_y);
-typedef int (*nq_allreduce_fn)(void* user, int which);      /* which: as nq_reduce_buffer; 4: the 32 diagnostic sums */
+typedef int (*nq_allreduce_fn)(void* user, int which);      /* which: as nq_reduce_read: 0..3, and 4 / 5 = the spectral /
+                                                              * physical half of the diagnostic sums, 16 doubles each */
+int nq_comm_probe(void);
 int nq_comm_unique_id(void* out128);
 int nq_comm_init(nq_ctx* ctx, const void* id128, int nranks, int rank);
 int nq_slab_attach_peers(nq_ctx* const* ctxs, int nranks);

@@ -209,6 +209,11 @@ class Kernel(object):
                     n = self.nx
                     inner = c.field(_lib.F_QH_MINUS)[:, 1:n // 2]
                     v[:, n // 2 + 1:] = np.conj(np.roll(inner[::-1, :], 1, axis=0))[:, ::-1]
+                else:                   # the anti-Hermitian passenger of row ny/2 (ref Kernel.py:471-486, :327), one device row
+                    n = self.nx
+                    a = c.qh_passenger()[1:n // 2]
+                    v[n // 2, 1:n // 2] += a
+                    v[n // 2, n // 2 + 1:] -= np.conj(a)[::-1]
             elif name == "ph":
                 v = hermitian_full(project_self_mirrored_columns(c.field(_lib.F_PH)))
             elif name == "qwh":
@@ -329,21 +334,26 @@ class Kernel(object):
     def run(self):
         """ref: niwqg/Kernel.py:183-203.  Steps between host-visible events are batched into one
         nq_step call; the sequence of diagnostics ticks and status lines is the reference's."""
-        if self.save_to_disk:                     # the initial condition (Kernel.py:194-195)
-            save_snapshots(self, fields=['t', 'q', 'phi'])
-        while self.t < self.tmax:
-            quiet = self._quiet_steps(self._steps_left(4096))
-            if quiet > 0:
-                self._ctx.step(quiet)             # asynchronous: a pending snapshot is written while these steps run
-                flush_snapshots(self)
-                for _ in range(quiet):
-                    self.tc += 1
-                    self.t += self.dt
-                self._after_steps()
-            self._step_forward()
-        flush_snapshots(self)
-        if self.save_to_disk:                     # Kernel.py:202-203
-            save_diagnostics(self)
+        self._defer_snapshots = True              # snapshots are written while the next batch of steps runs
+        try:
+            if self.save_to_disk:                     # the initial condition (Kernel.py:194-195)
+                save_snapshots(self, fields=['t', 'q', 'phi'])
+            while self.t < self.tmax:
+                quiet = self._quiet_steps(self._steps_left(4096))
+                if quiet > 0:
+                    self._ctx.step(quiet)             # asynchronous: a pending snapshot is written while these steps run
+                    flush_snapshots(self)
+                    for _ in range(quiet):
+                        self.tc += 1
+                        self.t += self.dt
+                    self._after_steps()
+                self._step_forward()
+            flush_snapshots(self)
+            if self.save_to_disk:                     # Kernel.py:202-203
+                save_diagnostics(self)
+        finally:
+            self._defer_snapshots = False
+            flush_snapshots(self)
 
     def run_with_snapshots(self, tsnapstart=0., tsnapint=432000.):
         """ref: niwqg/Kernel.py:161-181"""

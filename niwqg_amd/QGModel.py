@@ -248,21 +248,26 @@ class Model(object):
 
     def run(self):
         """ref: niwqg/QGModel.py:184-207"""
-        if self.save_to_disk:
-            save_snapshots(self, fields=self._snapshot_fields())
-        while self.t < self.tmax:
-            quiet = self._quiet_steps(self._steps_left(4096))
-            if quiet > 0:
-                self._ctx.step(quiet)
-                flush_snapshots(self)
-                for _ in range(quiet):
-                    self.tc += 1
-                    self.t += self.dt
-                self._after_steps()
-            self._step_forward()
-        flush_snapshots(self)
-        if self.save_to_disk:
-            save_diagnostics(self)
+        self._defer_snapshots = True              # snapshots are written while the next batch of steps runs
+        try:
+            if self.save_to_disk:
+                save_snapshots(self, fields=self._snapshot_fields())
+            while self.t < self.tmax:
+                quiet = self._quiet_steps(self._steps_left(4096))
+                if quiet > 0:
+                    self._ctx.step(quiet)
+                    flush_snapshots(self)
+                    for _ in range(quiet):
+                        self.tc += 1
+                        self.t += self.dt
+                    self._after_steps()
+                self._step_forward()
+            flush_snapshots(self)
+            if self.save_to_disk:
+                save_diagnostics(self)
+        finally:
+            self._defer_snapshots = False
+            flush_snapshots(self)
 
     def run_with_snapshots(self, tsnapstart=0., tsnapint=432000.):
         tsnapints = np.ceil(tsnapint / self.dt)

@@ -103,7 +103,9 @@ def save_setup(self):
 
 
 def save_snapshots(self, fields=['t', 'q', 'p']):
-    """ref: niwqg/Saving.py:59-86.  q and phi leave the device asynchronously; the file is written by flush_snapshots."""
+    """ref: niwqg/Saving.py:59-86.  Inside run() (``self._defer_snapshots``) q and phi leave the device asynchronously and the
+    file is written by flush_snapshots while the next batch of steps runs; called from anywhere else (_step_forward in a
+    user loop, run_with_snapshots) the file exists when this returns, as in the reference."""
     if (not (self.tc % self.tsnaps)) and self.save_to_disk:
         fno = self.fno + '/snapshots/{:015.0f}'.format(self.t) + '.h5'
         flush_snapshots(self)                       # one snapshot in flight at a time (one set of pinned buffers)
@@ -114,6 +116,8 @@ def save_snapshots(self, fields=['t', 'q', 'p']):
             ctx.snapshot_begin("phi" in want)
         other = {f: (self.t if f == 't' else np.array(getattr(self, f))) for f in fields if not (asynchronous and f in want)}
         self._pending_snapshots.append((fno, list(fields), other, asynchronous))
+        if not getattr(self, "_defer_snapshots", False):
+            flush_snapshots(self)
 
 
 def flush_snapshots(self):

@@ -25,12 +25,12 @@ COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
 (S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL) = range(7)
 
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
-           "nq_step", "nq_sync", "nq_get_field", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
+           "nq_step", "nq_sync", "nq_get_field", "nq_get_qh_passenger", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
            "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_diagnostics",
            "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
            "nq_reduce_buffer", "nq_reduce_read", "nq_reduce_write", "nq_device_bytes", "nq_stream",
-           "nq_comm_unique_id", "nq_comm_init", "nq_slab_attach_peers", "nq_slab_set_callbacks", "nq_slab_config", "nq_slab_set_stage_buffers", "nq_slab_spectral", "nq_slab_spectral_read",
+           "nq_comm_probe", "nq_comm_unique_id", "nq_comm_init", "nq_slab_attach_peers", "nq_slab_set_callbacks", "nq_slab_config", "nq_slab_set_stage_buffers", "nq_slab_spectral", "nq_slab_spectral_read",
            "nq_slab_step", "nq_slab_put_rows", "nq_slab_commit", "nq_slab_get_rows", "nq_slab_diagnostics",
            "nq_slab_local_max", "nq_slab_counters", "nq_snapshot_begin", "nq_snapshot_end"]
 
@@ -95,6 +95,7 @@ def lib():
     L.nq_get_field.argtypes = [vp, ctypes.c_int, dp]
     L.nq_field_doubles.argtypes = [vp, ctypes.c_int]
     L.nq_field_doubles.restype = ctypes.c_longlong
+    L.nq_get_qh_passenger.argtypes = [vp, dp]
     L.nq_get_scalar.argtypes = [vp, ctypes.c_int, dp]
     L.nq_get_coeff.argtypes = [vp, ctypes.c_int, ctypes.c_int, dp]
     L.nq_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -116,6 +117,7 @@ def lib():
     L.nq_reduce_buffer.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
     L.nq_reduce_read.argtypes = [vp, ctypes.c_int, dp]
     L.nq_reduce_write.argtypes = [vp, ctypes.c_int, dp]
+    L.nq_comm_probe.argtypes = []
     L.nq_comm_unique_id.argtypes = [vp]
     L.nq_comm_init.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int]
     L.nq_slab_attach_peers.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
@@ -244,6 +246,12 @@ class Context:
         if out.view(np.float64).size != nd:
             raise RuntimeError("field %d: the library writes %d doubles, the binding allocated %d" % (fid, nd, out.view(np.float64).size))
         self._chk(self.L.nq_get_field(self.h, fid, _dptr(out.view(np.float64))), "nq_get_field(%d)" % fid)
+        return out
+
+    def qh_passenger(self):
+        """anti-Hermitian part of the reference's qh on row ny/2, k = 0..nx/2 (include/niwqg_amd.h: nq_get_qh_passenger)"""
+        out = np.zeros(self.nx // 2 + 1, np.complex128)
+        self._chk(self.L.nq_get_qh_passenger(self.h, _dptr(out.view(np.float64))), "nq_get_qh_passenger")
         return out
 
     def scalar(self, sid):

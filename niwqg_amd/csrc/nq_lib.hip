@@ -71,6 +71,10 @@ struct nq_ctx {
   // dual-copy q equation (dealias=True, or exact full-plane qh on request): second copy + unfolded filters
   bool dual = false;
   EqState q2;
+  // the anti-Hermitian passenger on row l = N/2 of the reference's full-plane qh (k_s_q): one row per array, coefficient
+  // pointers at row N/2 of the q planes; off in dual mode (the second copy carries it) and for QGModel
+  bool pass = false;
+  EqState qp;
   cd* coefu[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // q coefficients without the filter
   double* filt_m = nullptr;                                                 // filter at (-l, -k)
   // half-spectrum aux spectra
@@ -862,7 +866,7 @@ static EtdArrays etd_arrays(EqState& e, int stage, int* out_slot) {
 }
 
 template <int S>
-static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage, const MArr& huq, const MArr& hvq) {
+static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage, const MArr& huq, const MArr& hvq, bool q_equation) {
   typedef YPlan<S> Y;
   DualQ dq;
   EtdArrays eap = ea;
@@ -882,8 +886,14 @@ static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage, const MArr& h
   const YGeom g = geom_half(c);
   if (g.width <= 0) return;
   const dim3 grid((g.width + CL - 1) / CL, c->S2), block(Y::THREADS);
-  if (c->dual) hipLaunchKernelGGL((k_s_q<S, true>), grid, block, Y::LDS_BYTES, c->stream, huq, hvq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq);
-  else hipLaunchKernelGGL((k_s_q<S, false>), grid, block, Y::LDS_BYTES, c->stream, huq, hvq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq);
+  EtdArrays ep;
+  memset(&ep, 0, sizeof(ep));
+  if (c->pass && q_equation) {             // the q equation itself, not the passive scalar's
+    int slot = 0;
+    ep = etd_arrays(c->qp, stage, &slot);
+  }
+  if (c->dual) hipLaunchKernelGGL((k_s_q<S, true>), grid, block, Y::LDS_BYTES, c->stream, huq, hvq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq, ep);
+  else hipLaunchKernelGGL((k_s_q<S, false>), grid, block, Y::LDS_BYTES, c->stream, huq, hvq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq, ep);
 }
 static BudgetW budget_w(nq_ctx* c, double* part, const cd* y_start) {
   BudgetW bw;
@@ -931,7 +941,7 @@ static void launch_sq(nq_ctx* c, const EtdArrays& ea, int stage, const MArr* huq
   ProfScope ps(c, PK_SQ);
   const MArr& a1 = huq ? *huq : c->mUq;
   const MArr& a2 = hvq ? *hvq : c->mVq;
-#define CALL_(s) launch_sq_s<s>(c, ea, stage, a1, a2)
+#define CALL_(s) launch_sq_s<s>(c, ea, stage, a1, a2, huq == nullptr)
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
@@ -977,6 +987,12 @@ static BudgetAcc budget_acc(nq_ctx* c) {
   b.nu = c->p.nu; b.nu4 = c->p.nu4; b.mu = c->p.mu; b.nuw = c->p.nuw; b.nu4w = c->p.nu4w; b.muw = c->p.muw;
   b.M = (double)c->N * c->N;
   return b;
+}
+
+// a new qh from physical space (set_q) is Hermitian: the passenger row starts from zero
+static int reset_passenger(nq_ctx* c) {
+  if (c->pass) HIPCHK(c, hipMemsetAsync(c->qp.y[c->qp.cur], 0, sizeof(cd) * (size_t)c->Ph, c->stream));
+  return 0;
 }
 
 // ---- phases of one ETDRK4 stage --------------------------------------------------------------------
@@ -1143,7 +1159,8 @@ static bool rccl_load(std::string* err) {
   // NIWQG_AMD_RCCL_LIB: an explicit library instead (tests/mock_rccl: rank THREADS on one GPU)
   const char* forced = getenv("NIWQG_AMD_RCCL_LIB");
   if (forced && *forced && !(h = dlopen(forced, RTLD_NOW | RTLD_LOCAL))) {
-    *err = std::string("NIWQG_AMD_RCCL_LIB: ") + (dlerror() ? dlerror() : "?");
+    const char* e = dlerror();                  // ONE call: dlerror() clears its state, a second call returns NULL
+    *err = std::string("NIWQG_AMD_RCCL_LIB: ") + (e ? e : "?");
     return false;
   }
   for (const char* n : names)
@@ -1153,7 +1170,8 @@ static bool rccl_load(std::string* err) {
     h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
   }
   if (!h) {
-    *err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+    const char* e = dlerror();
+    *err = std::string("librccl not found: ") + (e ? e : "?");
     return false;
   }
 #define SYM_(field, name)                                                  \
@@ -1789,6 +1807,13 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
       HIPCHK(c, hipMemcpyAsync(c->filt_m, fm.data(), sizeof(double) * half, hipMemcpyHostToDevice, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    c->pass = c->kernel_family && !c->dual && !ybj;
+    if (c->pass) {
+      for (int i = 0; i < 3; ++i) ALLOC(c, c->qp.y[i], (size_t)c->Ph);
+      ALLOC(c, c->qp.fn0, (size_t)c->Ph);
+      ALLOC(c, c->qp.fna, (size_t)c->Ph);
+      for (int i = 0; i < 6; ++i) c->qp.coef[i] = c->q.coef[i] + (size_t)(N / 2) * c->Ph;     // row N/2 of the q planes
+    }
     ALLOC(c, c->ph, half);
     ALLOC(c, c->qwh, half);
     if (P == 1) {                                   // scratch of the generic (single-rank) transform paths
@@ -2036,6 +2061,7 @@ int nq_set_q(nq_ctx* c, const double* q_host) {
   HIPCHK(c, hipMemcpyAsync(c->scr_r, q_host, sizeof(double) * full, hipMemcpyHostToDevice, c->stream));
   fwd2d_half(c, c->scr_r, c->q.y[c->q.cur], c->scr_h0);
   if (c->dual) HIPCHK(c, hipMemcpyAsync(c->q2.y[c->q2.cur], c->q.y[c->q.cur], sizeof(cd) * (size_t)c->N * c->Ph, hipMemcpyDeviceToDevice, c->stream));
+  { int rc = reset_passenger(c); if (rc) return rc; }
   do_invert_now(c);
   c->have_q = true;
   return nq_sync(c);
@@ -2126,6 +2152,7 @@ int nq_upload_spectral(nq_ctx* c, int which, const double* host) {
   if (which == 0) {
     if (c->Wh > 0) HIPCHK(c, hipMemcpy2DAsync(c->q.y[c->q.cur], sizeof(cd) * c->Ph, host, sizeof(cd) * c->Wh, sizeof(cd) * c->Wh, c->N, hipMemcpyHostToDevice, c->stream));
     if (c->dual) HIPCHK(c, hipMemcpyAsync(c->q2.y[c->q2.cur], c->q.y[c->q.cur], sizeof(cd) * (size_t)c->N * c->Ph, hipMemcpyDeviceToDevice, c->stream));
+    { int rc = reset_passenger(c); if (rc) return rc; }
   } else if (which == 1) {
     if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
     HIPCHK(c, hipMemcpyAsync(c->w.y[c->w.cur], host, sizeof(cd) * (size_t)c->N * c->Wf, hipMemcpyHostToDevice, c->stream));
@@ -2208,6 +2235,11 @@ int nq_reduce_buffer(nq_ctx* c, int which, void** ptr, int* count) {
 
 
 // ---- the slab step inside the library: API ------------------------------------------------------------------------
+int nq_comm_probe(void) {           // load-only: can this process resolve librccl at all?  (no communicator, no GPU work)
+  std::string err;
+  if (!rccl_load(&err)) NQ_FAIL((nq_ctx*)nullptr, -6, "nq_comm_probe: %s", err.c_str());
+  return 0;
+}
 int nq_comm_unique_id(void* out128) {
   if (!out128) return -1;
   std::string err;
@@ -2352,6 +2384,7 @@ int nq_slab_commit(nq_ctx* c, int which) {
       if (x->Wh > 0) launch_B_p(x, false, x->mUq.ys, x->mUq.pitch, x->q.y[x->q.cur], x->Ph, x->Wh, 1.0);
       if (x->dual)      // q is real: both copies of the dual-copy equation start from the same half spectrum
         HIPCHK(x, hipMemcpyAsync(x->q2.y[x->q2.cur], x->q.y[x->q.cur], sizeof(cd) * (size_t)x->N * x->Ph, hipMemcpyDeviceToDevice, x->stream));
+      SLABTRY(reset_passenger(x));
     }
     if (c0->p.model == NQ_MODEL_COUPLED) {
       for (nq_ctx* x : grp) phase_wavepv(x);
@@ -2672,15 +2705,15 @@ int nq_snapshot_begin(nq_ctx* c, int with_phi) {
   if (c->snap_busy) NQ_FAIL(c, -4, "nq_snapshot_begin: the previous snapshot has not been collected (nq_snapshot_end)");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t full = (size_t)c->N * c->N;
-  if (!c->snap_stream) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->snap_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_snap, hipEventDisableTiming));
-    ALLOC(c, c->snap_q, full);
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->snap_hq), sizeof(double) * full, hipHostMallocDefault));
-  }
-  if (with_phi && !c->snap_phi) {
-    ALLOC(c, c->snap_phi, full);
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->snap_hphi), sizeof(cd) * full, hipHostMallocDefault));
+  // every resource is guarded by its own pointer: a call that failed half-way (a 4096^2 snapshot pins 128 + 256 MB of
+  // host memory) leaves the rest to be made by the next call instead of running on null buffers
+  if (!c->snap_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->snap_stream, hipStreamNonBlocking));
+  if (!c->ev_snap) HIPCHK(c, hipEventCreateWithFlags(&c->ev_snap, hipEventDisableTiming));
+  if (!c->snap_q) ALLOC(c, c->snap_q, full);
+  if (!c->snap_hq) HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->snap_hq), sizeof(double) * full, hipHostMallocDefault));
+  if (with_phi) {
+    if (!c->snap_phi) ALLOC(c, c->snap_phi, full);
+    if (!c->snap_hphi) HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->snap_hphi), sizeof(cd) * full, hipHostMallocDefault));
   }
   const cd* qh = c->q.y[c->q.cur];
   if (c->dual) {
@@ -2867,6 +2900,18 @@ int nq_get_field(nq_ctx* c, int id, double* host) {
     }
     default: NQ_FAIL(c, -1, "nq_get_field: unknown field id %d", id);
   }
+}
+
+// the anti-Hermitian passenger of qh on row l = N/2 (k_s_q): this context's local half-spectrum columns, zeros where there is none
+int nq_get_qh_passenger(nq_ctx* c, double* out_cplx) {
+  if (!c || !out_cplx) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  memset(out_cplx, 0, sizeof(cd) * (size_t)(c->Wh > 0 ? c->Wh : 0));
+  if (c->pass && c->Wh > 0) {
+    HIPCHK(c, hipMemcpyAsync(out_cplx, c->qp.y[c->qp.cur], sizeof(cd) * (size_t)c->Wh, hipMemcpyDeviceToHost, c->stream));
+    return nq_sync(c);
+  }
+  return 0;
 }
 
 int nq_get_scalar(nq_ctx* c, int id, double* out) {

@@ -1096,7 +1096,7 @@ struct DualQ {
 template <int S1, bool DUAL>
 __global__ void __launch_bounds__(YPlan<S1>::THREADS)
 k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __restrict__ kk,
-      const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N, DualQ dq) {
+      const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N, DualQ dq, EtdArrays ep) {
   typedef YPlan<S1> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
@@ -1142,6 +1142,18 @@ k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __rest
       }
       etd_update_f(ea, idx, Np, stage, dq.filt_p[idx]);
       if (interior) etd_update_f(dq.minus, idx, Nm, stage, dq.filt_m[idx]);
+    }
+  }
+  // The passenger (DESIGN.md "Nyquist lines"): on row l = N/2 the il term of N_q is ANTI-Hermitian in the reference's full
+  // plane (numpy's ll[N/2] is not odd), never reaches physical space, but is part of the reference's qh
+  // (ref Kernel.py:471-486, :327).  It obeys the same ETDRK4 recursion with the coefficients of that row, so it is carried
+  // as ONE row of N/2+1 values (ep: state and tendency rows indexed by the local column, coefficient pointers at row N/2):
+  // qh[N/2, k] = X+ + A_k, qh[N/2, -k] = conj(X+) - conj(A_k).  The thread that holds l = N/2 is (l1 = 0, j = 0, t = P/2).
+  if constexpr (!dual) {
+    if (ep.y_out != nullptr && kernel_family && interior && l1 == 0 && j == 0) {
+      constexpr int tp = P / 2;
+      const double ly = ll[N / 2];
+      etd_update(ep, (size_t)k, cmake(ly * f2[tp].y, -ly * f2[tp].x), stage);      // -i l F[v q]
     }
   }
 }

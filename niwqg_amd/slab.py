@@ -103,6 +103,13 @@ class SlabRank(object):
         self._chk(self.L.nq_download_spectral(self.h, which, _lib._dptr(out.view(np.float64))), "nq_download_spectral")
         return out
 
+    def qh_passenger(self):
+        """this rank's columns of the anti-Hermitian passenger row of qh (include/niwqg_amd.h: nq_get_qh_passenger)"""
+        out = np.zeros(max(self.wh, 0), np.complex128)
+        if self.wh > 0:
+            self._chk(self.L.nq_get_qh_passenger(self.h, _lib._dptr(out.view(np.float64))), "nq_get_qh_passenger")
+        return out
+
     def put_rows(self, which, rows):
         rows = np.ascontiguousarray(rows, np.complex128 if which == 1 else np.float64)     # 0: q, 1: phi, 2: c
         if rows.shape != (self.nloc, self.nx):
@@ -165,10 +172,33 @@ def reference_all_to_all(sends):
     return [np.concatenate([blocks[s][d] for s in range(P)]) for d in range(P)]
 
 
+def agree_rccl_id(L, lead, dist):
+    """The communicator id of the RCCL link, or None when ANY rank cannot use librccl -- decided by collectives that every
+    rank takes part in whatever happened locally, so that no rank is ever left alone in a broadcast or in
+    ncclCommInitRank: (1) every rank probes the library (load only) and the outcomes are MIN-reduced; (2) rank 0 asks
+    for the id and ALWAYS broadcasts 129 bytes, the last one saying whether the id is real."""
+    import torch
+    on_dev = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", lead.device) if on_dev else torch.device("cpu")
+    ok = torch.tensor([1.0 if L.nq_comm_probe() == 0 else 0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok[0]) != 1.0:
+        return None
+    msg = torch.zeros(129, dtype=torch.uint8)
+    if lead.rank == 0:
+        buf = (ctypes.c_ubyte * 128)()
+        if L.nq_comm_unique_id(buf) == 0:
+            msg = torch.tensor(list(buf) + [1], dtype=torch.uint8)
+    msg = msg.to(dev)
+    dist.broadcast(msg, src=0)
+    msg = [int(v) for v in msg.cpu()]
+    return msg[:128] if msg[128] == 1 else None
+
+
 class SlabSimulation(object):
     """One slab-decomposed simulation: this process's ranks (one real rank, or all of them as peers) and their link."""
 
-    def __init__(self, ranks, link="peers", dist=None, nchunks=2, stage_via_host=False):
+    def __init__(self, ranks, link="peers", dist=None, nchunks=2, stage_via_host=False, uid=None):
         self.ranks, self.link, self.dist = ranks, link, dist
         self.L = ranks[0].L
         self.model = ranks[0].model
@@ -183,18 +213,13 @@ class SlabSimulation(object):
             arr = (ctypes.c_void_p * self.nranks)(*[r.h for r in ranks])
             self.lead._chk(self.L.nq_slab_attach_peers(arr, self.nranks), "nq_slab_attach_peers")
         elif link == "rccl":
-            import torch
             if len(ranks) != 1 or dist is None:
                 raise ValueError("rccl link: one rank per process and a torch.distributed group")
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if self.lead.rank == 0:
-                buf = (ctypes.c_ubyte * 128)()
-                self.lead._chk(self.L.nq_comm_unique_id(buf), "nq_comm_unique_id")
-                uid = torch.tensor(list(buf), dtype=torch.uint8)
-            if dist.get_backend() == "nccl":
-                uid = uid.to(torch.device("cuda", self.lead.device))
-            dist.broadcast(uid, src=0)
-            buf = (ctypes.c_ubyte * 128)(*[int(v) for v in uid.cpu()])
+            if uid is None:
+                uid = agree_rccl_id(self.L, self.lead, dist)
+            if uid is None:
+                raise RuntimeError("rccl link: librccl could not be set up on every rank (agreed over the process group)")
+            buf = (ctypes.c_ubyte * 128)(*uid)
             self.lead._chk(self.L.nq_comm_init(self.lead.h, buf, self.nranks, self.lead.rank), "nq_comm_init")
         elif link == "callback":
             import torch
@@ -330,6 +355,9 @@ class SlabSimulation(object):
         """0: qh, 1: phih, 2: ph, 3: qwh, 4: second copy of qh, 5: ch -- the column slabs of all ranks side by side"""
         return self._gather([r.download(which) for r in self.ranks], 1)
 
+    def gather_qh_passenger(self):
+        return self._gather([r.qh_passenger() for r in self.ranks], 0)
+
     def gather_qh(self):
         return self._gather([r.download(0) for r in self.ranks], 1)
 
@@ -355,14 +383,19 @@ def connect(ranks, dist, nchunks=2):
         return SlabSimulation(ranks, "callback", dist=dist, nchunks=nchunks, stage_via_host=True)
     sim, err = None, None
     if os.environ.get("NIWQG_AMD_SLAB_LINK", "rccl") == "rccl":
-        try:
-            sim = SlabSimulation(ranks, "rccl", dist=dist, nchunks=nchunks)
-        except RuntimeError as e:
-            err = e
-        flag = torch.tensor([1.0 if sim is not None else 0.0], device=torch.device("cuda", ranks[0].device))
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if float(flag[0]) == 1.0:
-            return sim
+        # agreement BEFORE any collective set-up call (agree_rccl_id), then ncclCommInitRank on every rank or on none
+        uid = agree_rccl_id(ranks[0].L, ranks[0], dist)
+        if uid is not None:
+            try:
+                sim = SlabSimulation(ranks, "rccl", dist=dist, nchunks=nchunks, uid=uid)
+            except RuntimeError as e:
+                err = e
+            flag = torch.tensor([1.0 if sim is not None else 0.0], device=torch.device("cuda", ranks[0].device))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag[0]) == 1.0:
+                return sim
+        else:
+            err = ranks[0].L.nq_last_error(None)
         import sys
         sys.stderr.write("niwqg_amd.slab rank %d: RCCL link not available on every rank (%s): falling back to "
                          "torch.distributed callbacks\n" % (ranks[0].rank, err or "another rank failed"))
@@ -447,6 +480,9 @@ class SlabContext(object):
         if which is None:
             raise RuntimeError("field %d is not available on a slab-decomposed model" % fid)
         return self.sim.gather_spectral(which)
+
+    def qh_passenger(self):
+        return self.sim.gather_qh_passenger()
 
     def diagnostic_sums(self):
         if self._ds is None:

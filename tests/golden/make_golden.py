@@ -24,6 +24,9 @@ Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
                           CoupledModel rough q and phi, 1 step): not the fields (32-64 MB each) but what pins them -- 256
                           seeded random projections, a 64x64 sub-sample, norms, budgets; the tests regenerate the same
                           projection vectors from the seed (g11 takes ~6 minutes and 16 GB here; not in the default list)
+  g12_coupled_2048_10steps.npz  the REAL reference, CoupledModel 2048^2, the same white-noise state and parameters as g11's
+                          coupled case, after 5 and 10 steps: projections, sub-samples, norms, budgets (round 3; ~8 minutes
+                          and 16 GB here; not in the default list)
 """
 import os
 import sys
@@ -360,6 +363,31 @@ def g11():
     out["cpl_norms"] = np.array([np.linalg.norm(m.q), np.linalg.norm(m.phi)])
     out["cpl_budgets"] = np.array([m.Ke, m.Pw, m.Kw])
     save("g11_at_size_2048.npz", **out)
+
+
+def g12():
+    nx = 2048
+    out = {}
+    kw = notebook_kwargs(nx, True, 10, tdiags=10 ** 9)
+    kw.update(nu4w=kw["nu4"] * 0.1, mu=1e-8, muw=2e-8)
+    m = CoupledModel.Model(**kw)
+    rng = np.random.default_rng(11)
+    q0 = 1e-5 * rng.standard_normal((nx, nx))
+    phi0 = 0.05 * (rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx)))
+    m.set_q(q0)
+    m.set_phi(phi0)
+    for n in (5, 10):
+        step_to(m, n)
+        tag = "s%d_" % n
+        out[tag + "q_proj"] = projections(m.q, 301)
+        out[tag + "phi_proj"] = projections(m.phi, 302)
+        out[tag + "qh_proj"] = projections(m.qh, 303)
+        out[tag + "phih_proj"] = projections(m.phih, 304)
+        out[tag + "q_sub"], out[tag + "phi_sub"] = m.q[::32, ::32].copy(), m.phi[::32, ::32].copy()
+        out[tag + "norms"] = np.array([np.linalg.norm(m.q), np.linalg.norm(m.phi)])
+        out[tag + "budgets"] = np.array([m.Ke, m.Pw, m.Kw])
+        print("g12: step", n, "done", flush=True)
+    save("g12_coupled_2048_10steps.npz", **out)
 
 
 if __name__ == "__main__":

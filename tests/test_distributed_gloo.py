@@ -95,3 +95,75 @@ def test_torch_transport_equals_virtual_transport(tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "slab transports agree" in out.stdout
+
+
+PROBE = textwrap.dedent("""
+    import sys, ctypes
+    sys.path.insert(0, %r)
+    from niwqg_amd import _lib
+    L = _lib.lib()
+    rc = L.nq_comm_probe()
+    msg = L.nq_last_error(None).decode()
+    buf = (ctypes.c_ubyte * 128)()
+    rc2 = L.nq_comm_unique_id(buf)
+    msg2 = L.nq_last_error(None).decode()
+    print("RC", rc, rc2)
+    print("MSG", msg, "|", msg2)
+""" % ROOT)
+
+
+def test_missing_librccl_is_an_error_code_not_a_crash(tmp_path):
+    """NIWQG_AMD_RCCL_LIB pointing nowhere: nq_comm_probe and nq_comm_unique_id return -6 with dlopen's message (the error
+    text used to be built from two dlerror() calls, the second of which returns NULL: undefined behaviour inside an
+    extern "C" entry point, and the RuntimeError that slab.connect falls back on was never raised)."""
+    script = tmp_path / "probe.py"
+    script.write_text(PROBE)
+    env = dict(os.environ, NIWQG_AMD_RCCL_LIB="/nonexistent/librccl.so")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RC -6 -6" in out.stdout, out.stdout
+    line = [x for x in out.stdout.splitlines() if x.startswith("MSG")][0]
+    assert "NIWQG_AMD_RCCL_LIB" in line and "/nonexistent/librccl.so" in line, line
+
+
+AGREE_WORKER = textwrap.dedent("""
+    import os, sys, types
+    sys.path.insert(0, %r)
+    rank = int(os.environ["RANK"])
+    if rank == 0:
+        os.environ["NIWQG_AMD_RCCL_LIB"] = "/nonexistent/librccl.so"      # the load fails on rank 0 only
+    else:
+        os.environ["NIWQG_AMD_RCCL_LIB"] = os.environ["MOCK_RCCL"]         # and succeeds on rank 1
+    from niwqg_amd import _lib, slab
+    from niwqg_amd.distributed import Group
+    g = Group(backend="gloo")
+    lead = types.SimpleNamespace(rank=g.rank, device=0)
+    uid = slab.agree_rccl_id(_lib.lib(), lead, g.dist)
+    assert uid is None, uid                  # agreed by both ranks: nobody goes on to ncclCommInitRank alone
+    g.barrier()                              # and the process group is still in step
+    if g.rank == 0:
+        print("agreed: no rccl link")
+    g.close()
+""" % ROOT)
+
+
+def test_rccl_setup_failure_on_one_rank_is_agreed_before_any_collective_setup(tmp_path):
+    """slab.agree_rccl_id on two gloo ranks with the library load forced to fail on rank 0: both ranks learn it from the
+    MIN-reduced probe, rank 0 never skips a broadcast that rank 1 waits in, and both return None (-> callback link)."""
+    from conftest import free_port
+    mock = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
+    if not os.path.exists(mock):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", mock,
+                        os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp"), "-lpthread"], check=False)
+    if not os.path.exists(mock):
+        import pytest
+        pytest.skip("tests/mock_rccl/libmock_rccl.so is not built (__graft_entry__.build())")
+    port = free_port()
+    script = tmp_path / "agree_worker.py"
+    script.write_text(AGREE_WORKER)
+    env = dict(os.environ, MOCK_RCCL=mock)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "agreed: no rccl link" in out.stdout

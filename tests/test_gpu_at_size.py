@@ -29,15 +29,6 @@ def steps(m, n):
         m._step_forward()
 
 
-def rel_no_passenger(qh, ref):
-    n = ref.shape[0]
-    a, b = qh.copy(), ref.copy()
-    for x in (a, b):
-        x[n // 2, 1:n // 2] = 0
-        x[n // 2, n // 2 + 1:] = 0
-    return rel(a, b)
-
-
 # ---- BASELINE config 2: QGModel 2048^2, random q ---------------------------------------------------------------------
 def test_config2_qgmodel_2048_random_q_against_the_oracle():
     """ref: niwqg/QGModel.py:328-407 on BASELINE.json configs[1] exactly as bench.py --model qg --nx 2048 builds it."""
@@ -123,7 +114,7 @@ def test_rough_field_coupled_step_against_the_oracle(nx):
     o.set_phi(phi0)
     o._step_forward()
     errs = {k: rel(got[k], getattr(o, k)) for k in ("q", "phi", "phih", "ph")}
-    errs["qh"] = rel_no_passenger(got["qh"], o.qh)
+    errs["qh"] = rel(got["qh"], o.qh)
     print("Coupled %d^2 rough field, 1 step:" % nx, {k: "%.2e" % v for k, v in errs.items()})
     for k, v in errs.items():
         assert v < 1e-11, (k, v)
@@ -292,3 +283,59 @@ def test_headline_grid_on_eight_slab_ranks_equals_the_single_context():
     a, b = res["one"], res["slab8"]
     assert rel(b[0], a[0]) < 1e-13 and rel(b[1], a[1]) < 1e-13 and rel(b[2], a[2]) < 1e-13
     assert np.allclose(b[3], a[3], rtol=1e-11)
+
+
+def test_config4_grid_on_eight_slab_ranks_equals_the_single_context_8192():
+    """BASELINE config 4's grid and partition on a FULL spectrum: CoupledModel 8192^2, white-noise q and phi, every
+    dissipation term on, one step on 8 peer ranks with 4 row chunks against the single context.  This is what runs the
+    slab instantiations of the even/odd row kernels (k_x_products_eo<8192,0,true>, k_x_wavepv_eo<8192,true>) on
+    high-index twiddles, the filter band and the Nyquist lines; the single-context kernels are pinned to the reference's
+    formulas by test_row_kernels_8192_on_a_full_spectrum_against_numpy.  The first model is freed before the second is built."""
+    import niwqg_amd
+    nx = 8192
+    rng = np.random.default_rng(17)
+    kw = rough_kwargs(nx)
+    q0 = 1e-5 * rng.standard_normal((nx, nx))
+    phi0 = 0.05 * (rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx)))
+    res = {}
+    for tag, slab in (("one", False), ("slab8", 8)):
+        m = niwqg_amd.CoupledModel.Model(slab=slab, nchunks=4, **kw)
+        m.set_q(q0)
+        m.set_phi(phi0)
+        steps(m, 1)
+        res[tag] = (m.q.copy(), m.phi.copy(), m.phih.copy(), m.qh.copy(), [m.Ke, m.Pw, m.Kw])
+        m._ctx.close()
+        del m
+    a, b = res["one"], res["slab8"]
+    errs = [rel(b[i], a[i]) for i in range(4)]
+    print("8192^2 white noise, 8 slab ranks x 4 chunks vs one context: q %.2e phi %.2e phih %.2e qh %.2e" % tuple(errs))
+    assert max(errs) < 1e-13
+    assert np.allclose(b[4], a[4], rtol=1e-11)
+    # the state compared is rough: the filter band and the Nyquist row carry data
+    k65 = int(0.65 * nx / 2) + 3
+    assert np.abs(a[2][k65, k65]) > 0 and np.abs(a[3][nx // 2, 5]) > 0
+
+
+def test_rough_coupled_ten_steps_against_the_reference_itself_at_2048(golden):
+    """The REAL reference at 2048^2 over 5 and 10 steps (golden g12, make_golden.py g12: CoupledModel, the white-noise state
+    and parameters of g11's coupled case): 256 random projections of q, phi, qh (full plane: the Nyquist-row passenger
+    included) and phih, a 64x64 sub-sample, norms, budgets."""
+    import niwqg_amd
+    g = golden("g12_coupled_2048_10steps.npz")
+    nx = 2048
+    m = niwqg_amd.CoupledModel.Model(**rough_kwargs(nx))
+    rng = np.random.default_rng(11)
+    m.set_q(1e-5 * rng.standard_normal((nx, nx)))
+    m.set_phi(0.05 * (rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx))))
+    for n in (5, 10):
+        steps(m, n)
+        t = "s%d_" % n
+        nq, nphi = float(g[t + "norms"][0]), float(g[t + "norms"][1])
+        e = dict(q=l2_error_estimate(m.q, g[t + "q_proj"], nq, 301), phi=l2_error_estimate(m.phi, g[t + "phi_proj"], nphi, 302),
+                 qh=l2_error_estimate(m.qh, g[t + "qh_proj"], nq * nx, 303),
+                 phih=l2_error_estimate(m.phih, g[t + "phih_proj"], nphi * nx, 304),
+                 q_sub=rel(m.q[::32, ::32], g[t + "q_sub"]), phi_sub=rel(m.phi[::32, ::32], g[t + "phi_sub"]))
+        print("rough Coupled 2048^2 vs the reference after %d steps:" % n, {k: "%.2e" % v for k, v in e.items()})
+        for k, v in e.items():
+            assert v < 1e-10, (n, k, v)
+        assert np.allclose([m.Ke, m.Pw, m.Kw], g[t + "budgets"], rtol=1e-8)

@@ -27,17 +27,6 @@ def steps(m, n):
         m._step_forward()
 
 
-def rel_no_passenger(qh, ref):
-    """q-hat comparison without the Nyquist row of the interior columns: the reference carries an
-    anti-Hermitian passenger there that never reaches physical space (known gaps)."""
-    n = ref.shape[0]
-    a, b = qh.copy(), ref.copy()
-    for x in (a, b):
-        x[n // 2, 1:n // 2] = 0
-        x[n // 2, n // 2 + 1:] = 0
-    return rel(a, b)
-
-
 @pytest.mark.parametrize("use_filter", [False, True])
 def test_coupled_golden_trajectory_64(golden, use_filter):
     g = golden("g2_coupled_64_%s.npz" % ("filter" if use_filter else "nofilter"))
@@ -52,7 +41,7 @@ def test_coupled_golden_trajectory_64(golden, use_filter):
         assert rel(m.phi, g["phi_%d" % n]) < 1e-12
         assert rel(m.phih, g["phih_%d" % n]) < 1e-12
         assert rel(m.ph, g["ph_%d" % n]) < 1e-12
-        assert rel_no_passenger(m.qh, g["qh_%d" % n]) < 1e-12
+        assert rel(m.qh, g["qh_%d" % n]) < 1e-12
         assert np.allclose([m.Ke, m.Pw, m.Kw], g["budgets_%d" % n], rtol=1e-9)
 
 
@@ -386,13 +375,19 @@ def _low_modes(h, kk, ll, x0, y0, nx, M=12):
 
 @pytest.mark.parametrize("nx", [4096, 8192])
 def test_full_size_parity_through_resolution_independence(nx):
-    kw = notebook_kwargs(64, False)            # one dt / viscosity set for every resolution
+    """BASELINE.json's horizon AT SIZE: 100 steps of the size's own parameter set (dt and hyperviscosity scaled with nx as
+    in configs[2] / configs[3]) on a band-limited state, against the reference-pinned oracle run at 128^2 with the same
+    dt and viscosities.  The pseudo-spectral step is exact at any resolution that holds the band; on the CPU the oracle
+    at 128^2 and at 256^2 agree to 1e-15 over these 100 steps (nothing leaves the band: tail below 2e-16), so every mode
+    of the device run is pinned.  Tolerance: BASELINE's 1e-10 (relative to the largest mode); achieved figure printed."""
+    nsteps = 100
+    kw = notebook_kwargs(nx, False)            # the SIZE's dt / viscosities, used at both resolutions
     kw.update(nx=128)
     o = O.NIWQGOracle("coupled", **kw)
     q0, phi0 = _band_limited_state(o.grid)
     o.set_q(q0)
     o.set_phi(phi0)
-    for _ in range(3):
+    for _ in range(nsteps):
         o._step_forward()
     kw.update(nx=nx)
     m = models().CoupledModel.Model(**kw)
@@ -400,12 +395,17 @@ def test_full_size_parity_through_resolution_independence(nx):
     m.set_q(q1)
     m.set_phi(phi1)
     del q1, phi1
-    steps(m, 3)
+    steps(m, nsteps)
+    worst = {}
     for name in ("qh", "phih"):
         ref = _low_modes(getattr(o, name), o.kk, o.ll, o.grid.x.ravel()[0], o.grid.y.ravel()[0], 128)
         got = _low_modes(getattr(m, name), np.asarray(m.kk).ravel(), np.asarray(m.ll).ravel(), m.x.ravel()[0],
                          m.y.ravel()[0], nx)
-        assert np.abs(got - ref).max() < 1e-11 * np.abs(ref).max(), name
+        worst[name] = np.abs(got - ref).max() / np.abs(ref).max()
+    print("%d^2, %d steps against the oracle through resolution independence:" % (nx, nsteps),
+          {k: "%.2e" % v for k, v in worst.items()})
+    for name, v in worst.items():
+        assert v < 1e-10, (name, v)
     assert np.allclose([m.Ke, m.Pw, m.Kw], [o.Ke, o.Pw, o.Kw], rtol=1e-9)
     # nothing outside the band beyond rounding: what aliasing or a misplaced mode would show
     qh = np.abs(m.qh) / nx ** 2
@@ -559,7 +559,7 @@ def test_run_with_save_to_disk_writes_the_references_files(tmp_path):
             self.fno, self.data = fno, {}
 
         def create_dataset(self, name, data=None, dtype=None):
-            self.data[name] = np.array(data)
+            self.data[name] = np.array(data, dtype=dtype)          # what h5py stores: the array in the dtype asked for
 
         def close(self):
             open(self.fno, "w").write("stub")
@@ -581,20 +581,51 @@ def test_run_with_save_to_disk_writes_the_references_files(tmp_path):
         names = sorted(os.listdir(path + "/snapshots"))
         want = ['{:015.0f}.h5'.format(n * m.dt) for n in (0, 6, 12, 18, 24)]
         assert names == sorted(want), (names, want)
-        assert set(Rec.files[path + "/setup.h5"]) == {"grid/nx", "grid/x", "grid/y", "grid/wv", "grid/k", "grid/l"}
-        d = Rec.files[path + "/diagnostics.h5"]
+        # the on-disk schema, transcribed from the reference's writer: dataset name -> (dtype kind, shape)
+        n = 128
+        setup_schema = {                                   # ref niwqg/Saving.py:50-55
+            "grid/nx": ("i", ()),                          #   create_dataset("grid/nx", data=(self.nx), dtype=int)
+            "grid/x": ("f", (n, n)), "grid/y": ("f", (n, n)),     # self.x, self.y: meshgrid planes (Kernel.py:232-234)
+            "grid/wv": ("f", (n, n)),                      #   self.wv = sqrt(wv2) (Kernel.py:256)
+            "grid/k": ("f", (n,)), "grid/l": ("f", (n,)),  #   data=self.kk / self.ll: the 1-D wavenumbers (Kernel.py:242-244)
+        }
+        snap_schema = {"t": ("f", ()), "q": ("f", (n, n)), "phi": ("c", (n, n))}       # ref niwqg/Saving.py:72-82, Kernel.py:216
+        got = Rec.files[path + "/setup.h5"]
+        assert set(got) == set(setup_schema)
+        for name, (kind, shape) in setup_schema.items():
+            assert got[name].dtype.kind == kind and got[name].shape == shape, (name, got[name].dtype, got[name].shape)
+        assert int(got["grid/nx"]) == n and np.array_equal(got["grid/k"], m.kk) and np.array_equal(got["grid/x"], m.x)
+        d = Rec.files[path + "/diagnostics.h5"]            # ref niwqg/Saving.py:97-99: one dataset per registered diagnostic
         assert set(d) == set(m.diagnostics) and len(d["time"]) == len(m.diagnostics["time"]["value"])
-        # the same run without output, stopped at two of the snapshot steps
-        r = mk()
-        r.set_q(q0)
-        r.set_phi(phi0)
+        for key in d:
+            assert np.array_equal(d[key], np.array(m.diagnostics[key]["value"])), key
+        # contents: the ORACLE (pinned to the reference by the goldens) stepped to the snapshot steps
+        o = O.NIWQGOracle("coupled", **dict(kw, tmax=1e30))
+        o.set_q(q0)
+        o.set_phi(phi0)
         s0 = Rec.files[path + "/snapshots/" + want[0]]
         assert np.array_equal(s0["q"], q0) or rel(s0["q"], q0) < 1e-14
-        for n in (12, 24):
-            steps(r, n)
-            snap = Rec.files[path + "/snapshots/" + '{:015.0f}.h5'.format(n * m.dt)]
-            assert float(snap["t"]) == r.t
-            assert rel(snap["q"], r.q) < 1e-14 and rel(snap["phi"], r.phi) < 1e-14
+        assert rel(s0["phi"], phi0) < 1e-14 and float(s0["t"]) == 0.0
+        for nstep in (6, 12, 18, 24):
+            while o.tc < nstep:
+                o._step_forward()
+            snap = Rec.files[path + "/snapshots/" + '{:015.0f}.h5'.format(nstep * m.dt)]
+            assert set(snap) == set(snap_schema)
+            for name, (kind, shape) in snap_schema.items():
+                assert snap[name].dtype.kind == kind and snap[name].shape == shape, (name, snap[name].dtype)
+            assert float(snap["t"]) == o.t
+            assert rel(snap["q"], o.q) < 1e-12 and rel(snap["phi"], o.phi) < 1e-12, nstep
+        # run_with_snapshots / a user loop over _step_forward: every file exists when the step returns (Saving.py:59-86)
+        p2 = str(tmp_path / "out2")
+        m2 = mk(save_to_disk=True, tsave_snapshots=6, path=p2)
+        m2.set_q(q0)
+        m2.set_phi(phi0)
+        seen = []
+        for t in m2.run_with_snapshots(tsnapstart=0., tsnapint=6 * m2.dt):
+            seen.append(sorted(os.listdir(p2 + "/snapshots")))
+        assert [len(x) for x in seen] == [1, 2, 3, 4], seen          # steps 6, 12, 18, 24 (no initial-condition file here)
+        assert seen[-1] == sorted(want[1:])
+        assert rel(Rec.files[p2 + "/snapshots/" + want[4]]["q"], o.q) < 1e-12
         # QGModel: t and q (no c without the passive scalar)
         pq = str(tmp_path / "outqg")
         qg = models().QGModel.Model(L=L, nx=64, tmax=4.5 * 1000.0, dt=1000.0, twrite=10 ** 9, nu4=7.5e8, use_filter=False,

@@ -209,7 +209,9 @@ def test_saving_layout_names_and_overwrite_rules(tmp_path):
         for tc, t in ((0, 0.0), (3, 300.0), (5, 500.0), (10, 123456.7)):
             m.tc, m.t = tc, t
             Saving.save_snapshots(m, fields=['t', 'q', 'phi'])
-        Saving.flush_snapshots(m)
+            # outside run() the file exists when the call returns, as in the reference (Saving.py:59-86)
+            assert m._pending_snapshots == []
+            assert os.path.exists(path + '/snapshots/{:015.0f}.h5'.format(t)) == (tc % 5 == 0)
         names = sorted(os.listdir(path + "/snapshots"))
         assert names == ["000000000000000.h5", "000000000000500.h5", "000000000123457.h5"]      # tc = 3 is no snapshot step
         snap = _Recorder.files[path + "/snapshots/000000000000500.h5"]
@@ -232,9 +234,11 @@ def test_saving_layout_names_and_overwrite_rules(tmp_path):
         Saving.initialize_save_snapshots(m, p1)
         Saving.save_setup(m)
         m.tc, m.t = 5, 500.0
+        m._defer_snapshots = True                             # as inside run(): written by the next flush
         Saving.save_snapshots(m, fields=['t', 'q', 'phi'])
         assert len(m._pending_snapshots) == 1                 # the fields WERE read on this rank
         Saving.flush_snapshots(m)
+        m._defer_snapshots = False
         Saving.save_diagnostics(m)
         assert not os.path.exists(p1) and m._pending_snapshots == []
         m._ctx = Ctx(0)

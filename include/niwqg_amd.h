@@ -277,6 +277,9 @@ int nq_slab_local_max(nq_ctx* ctx, double* out3);
  * rank sent to OTHER ranks, [4] milliseconds the exchange stream spent in exchanges (HIP events; 0 unless timing was
  * switched on with reset = 2), [5] nchunks in use */
 int nq_slab_counters(nq_ctx* ctx, double* out6, int reset);
+/* out2[0]: milliseconds the exchange stream spent in the all-reduces of the steps since timing was switched on
+ * (nq_slab_counters with reset = 2), out2[1]: how many all-reduces that was.  Read before the call that resets. */
+int nq_slab_allreduce_ms(nq_ctx* ctx, double* out2);
 
 /* timing of the hot loop with HIP events on the context's stream */
 int nq_timer_start(nq_ctx* ctx);
@@ -288,6 +291,9 @@ int nq_event_elapsed(nq_ctx* ctx, int slot_a, int slot_b, float* elapsed_ms);
 /* Per-kernel timing with HIP events on the context's stream.  While enabled, every launch of the
  * selected kernel class inside nq_step is bracketed by an event pair (cost ~2 us per launch).
  * class: 0 x_products, 1 x_wavepv, 2 s_q, 3 s_phi, 4 s_invert, 5 y_A (all A sub-passes)              */
+/* best of `reps` timed launches of a 1-read + 1-write stream copy of `bytes` bytes (16 B per lane, grid-stride), in GB/s
+ * of bytes moved (read + written): the copy rate of THIS device, bench.py's second roofline denominator */
+int nq_stream_copy_gbs(nq_ctx* ctx, long long bytes, int reps, double* gbs_out);
 int nq_profile_enable(nq_ctx* ctx, int kernel_class);     /* -1 disables, -2 brackets every class */
 int nq_profile_read(nq_ctx* ctx, int* launches, float* total_ms);   /* synchronises, then resets */
 int nq_profile_read_all(nq_ctx* ctx, int* launches6, float* total_ms6);   /* per class, after nq_profile_enable(-2) */

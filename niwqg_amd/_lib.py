@@ -15,7 +15,8 @@ except Exception:         # pragma: no cover - torch is optional for single-GPU 
     torch = None
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libniwqg_amd.so")
+# NIWQG_AMD_LIB: another build of the same sources (A/B experiments with compile-time knobs, tools/); default: the in-tree library
+LIB_PATH = os.environ.get("NIWQG_AMD_LIB") or os.path.join(HERE, "libniwqg_amd.so")
 SRC = os.path.join(HERE, "csrc", "nq_lib.hip")
 HEADERS = [os.path.join(HERE, "csrc", h) for h in ("nq_fft.hpp", "nq_generic.hpp", "nq_step.hpp")] + [
     os.path.join(os.path.dirname(HERE), "include", "niwqg_amd.h")]
@@ -27,12 +28,12 @@ COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
            "nq_step", "nq_sync", "nq_get_field", "nq_get_qh_passenger", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
            "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_diagnostics",
-           "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
+           "nq_stream_copy_gbs", "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
            "nq_reduce_buffer", "nq_reduce_read", "nq_reduce_write", "nq_device_bytes", "nq_stream",
            "nq_comm_probe", "nq_comm_unique_id", "nq_comm_init", "nq_slab_attach_peers", "nq_slab_set_callbacks", "nq_slab_config", "nq_slab_set_stage_buffers", "nq_slab_spectral", "nq_slab_spectral_read",
            "nq_slab_step", "nq_slab_put_rows", "nq_slab_commit", "nq_slab_get_rows", "nq_slab_diagnostics",
-           "nq_slab_local_max", "nq_slab_counters", "nq_snapshot_begin", "nq_snapshot_end"]
+           "nq_slab_local_max", "nq_slab_counters", "nq_slab_allreduce_ms", "nq_snapshot_begin", "nq_snapshot_end"]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
@@ -98,6 +99,7 @@ def lib():
     L.nq_get_qh_passenger.argtypes = [vp, dp]
     L.nq_get_scalar.argtypes = [vp, ctypes.c_int, dp]
     L.nq_get_coeff.argtypes = [vp, ctypes.c_int, ctypes.c_int, dp]
+    L.nq_stream_copy_gbs.argtypes = [vp, ctypes.c_longlong, ctypes.c_int, dp]
     L.nq_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.nq_event_record.argtypes = [vp, ctypes.c_int]
     L.nq_event_elapsed.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
@@ -133,6 +135,7 @@ def lib():
     L.nq_slab_diagnostics.argtypes = [vp, dp]
     L.nq_slab_local_max.argtypes = [vp, dp]
     L.nq_slab_counters.argtypes = [vp, dp, ctypes.c_int]
+    L.nq_slab_allreduce_ms.argtypes = [vp, dp]
     L.nq_snapshot_begin.argtypes = [vp, ctypes.c_int]
     L.nq_snapshot_end.argtypes = [vp, dp, dp]
     L.nq_device_bytes.argtypes = [vp]
@@ -247,6 +250,12 @@ class Context:
             raise RuntimeError("field %d: the library writes %d doubles, the binding allocated %d" % (fid, nd, out.view(np.float64).size))
         self._chk(self.L.nq_get_field(self.h, fid, _dptr(out.view(np.float64))), "nq_get_field(%d)" % fid)
         return out
+
+    def stream_copy_gbs(self, nbytes=512 << 20, reps=5):
+        """GB/s (read + written) of a plain 1r + 1w copy kernel on this device (nq_stream_copy_gbs)"""
+        v = ctypes.c_double()
+        self._chk(self.L.nq_stream_copy_gbs(self.h, int(nbytes), int(reps), ctypes.byref(v)), "nq_stream_copy_gbs")
+        return v.value
 
     def qh_passenger(self):
         """anti-Hermitian part of the reference's qh on row ny/2, k = 0..nx/2 (include/niwqg_amd.h: nq_get_qh_passenger)"""

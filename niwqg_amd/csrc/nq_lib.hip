@@ -61,8 +61,7 @@ struct nq_ctx {
   // tables
   cd* tw = nullptr;
   int num_cu = 256;
-  cd *twx_half = nullptr;   // stage table of the N/2-point plan and the per-workgroup scratch rows of k_x_products_eo
-  cd *eo_scratch = nullptr;
+  cd *twx_half = nullptr;   // stage table of the N/2-point plan (k_x_products_eo / k_x_wavepv_eo: 8192-point rows)
   cd *twx = nullptr, *twx1 = nullptr;   // per-stage twiddle tables of the two row-kernel plans (WgFft::tw_off layout)
   double *kk = nullptr, *ll = nullptr, *filt_h = nullptr, *filt_f = nullptr;
   cd* contour = nullptr;
@@ -142,6 +141,8 @@ struct nq_ctx {
   double bytes_sent = 0.0;
   std::vector<hipEvent_t> xev;         // timing pairs around every exchange chunk on mstream (when counting)
   size_t xev_used = 0;
+  std::vector<hipEvent_t> rev;         // the same around every all-reduce
+  size_t rev_used = 0;
   bool xtime = false;
   bool alloc_plain = false;            // dev_alloc: no skew (exchange-group buffers: whole rows, read by the row kernels)
   int spec_kind = -1;                  // what the scratch column slab of nq_slab_spectral holds: 1 half-spectrum, 0 full width
@@ -775,11 +776,11 @@ static void launch_wavepv_t(nq_ctx* c) {
   switch (c->N) {
 #define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n, SLAB>), dim3(c->nrows / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, mPhi, mPhiy, mA, mB, c->twx1, c->kk); } break;
     case 8192:
-      if (c->eo_scratch) {                            // even / odd samples as two 4096-point problems (no spills)
+      if (c->twx_half) {                              // even / odd samples as two 4096-point problems (no spills)
         typedef XPlan<4096> X;
         const int ncu = c->num_cu - c->reserve_cus, nb = c->nrows, grid = nb < ncu ? nb : ncu;
-        const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd);
-        hipLaunchKernelGGL((k_x_wavepv_eo<8192, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mPhi, mPhiy, mA, mB, c->twx_half, c->tw, c->kk, nb, c->eo_scratch);
+        const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd) ;          // + the 64 KB of thread-private park slots
+        hipLaunchKernelGGL((k_x_wavepv_eo<8192, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mPhi, mPhiy, mA, mB, c->twx_half, c->tw, c->kk, nb);
       } else {
         typedef XPlan1<8192> X;
         hipLaunchKernelGGL((k_x_wavepv<8192, SLAB>), dim3(c->nrows / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, mPhi, mPhiy, mA, mB, c->twx1, c->kk);
@@ -809,14 +810,14 @@ static void launch_products_t(nq_ctx* c, double cj, double cr, bool fresh_grad) 
   const MArr mU = rw(c, c->mU), mP = rw(c, c->mP), mQ = rw(c, c->mQ), mQw = rw(c, c->mQw), mPhi = rw(c, c->mPhi);
   const MArr mUq = rw(c, c->mUq), mVq = rw(c, c->mVq), mW = rw(c, c->mW), mPhiy = rw(c, c->mPhiy);
   const MArr mGx = rw(c, c->mGx), mGy = rw(c, c->mGy), mUc = rw(c, c->mUc), mVc = rw(c, c->mVc);
-  if (c->N == 8192 && MODE != MODE_QGC && c->eo_scratch) {
+  if (c->N == 8192 && c->twx_half) {
     // rows too long for the register budget as one transform: even / odd samples as two 4096-point problems
     typedef XPlan<4096> X;
-    const MArr& gx8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? mGx : mPhi;
-    const MArr& gy8 = (MODE == MODE_UNCOUPLED && !fresh_grad) ? mGy : mPhiy;
+    const MArr& gx8 = (MODE == MODE_QGC) ? mUc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? mGx : mPhi);
+    const MArr& gy8 = (MODE == MODE_QGC) ? mVc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? mGy : mPhiy);
     const int ncu = c->num_cu - c->reserve_cus, nb = c->nrows, grid = nb < ncu ? nb : ncu;
-    const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd);
-    hipLaunchKernelGGL((k_x_products_eo<8192, MODE, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mU, mP, mQ, mQw, mPhi, gx8, gy8, mUq, mVq, mW, c->twx_half, c->tw, c->kk, vz, cj, cr, nb, c->eo_scratch);
+    const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd) ;            // + the 64 KB of thread-private park slots
+    hipLaunchKernelGGL((k_x_products_eo<8192, MODE, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mU, mP, mQ, mQw, mPhi, gx8, gy8, mUq, mVq, mW, c->twx_half, c->tw, c->kk, vz, cj, cr, nb);
     return;
   }
   const MArr& gx = (MODE == MODE_QGC) ? mUc : ((MODE == MODE_UNCOUPLED && !fresh_grad) ? mGx : mPhi);
@@ -1236,23 +1237,25 @@ static int effective_chunks(const nq_ctx* c) {
   while (n > 1 && (c->Nloc % (n * rows_per_wg) != 0)) n >>= 1;
   return n;
 }
-struct XTimer {                                  // optional HIP-event pair around one exchange chunk on the exchange stream
+struct XTimer {                                  // optional HIP-event pair around one exchange chunk (or one all-reduce) on the exchange stream
   nq_ctx* c;
   bool on;
-  explicit XTimer(nq_ctx* c_) : c(c_), on(c_->xtime) {
+  std::vector<hipEvent_t>& ev;
+  size_t& used;
+  explicit XTimer(nq_ctx* c_, bool reduce = false) : c(c_), on(c_->xtime), ev(reduce ? c_->rev : c_->xev), used(reduce ? c_->rev_used : c_->xev_used) {
     if (!on) return;
-    if (c->xev_used + 2 > c->xev.size())
+    if (used + 2 > ev.size())
       for (int i = 0; i < 2; ++i) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
-        c->xev.push_back(e);
+        ev.push_back(e);
       }
-    (void)hipEventRecord(c->xev[c->xev_used], c->mstream);
+    (void)hipEventRecord(ev[used], c->mstream);
   }
   ~XTimer() {
     if (!on) return;
-    (void)hipEventRecord(c->xev[c->xev_used + 1], c->mstream);
-    c->xev_used += 2;
+    (void)hipEventRecord(ev[used + 1], c->mstream);
+    used += 2;
   }
 };
 
@@ -1386,7 +1389,10 @@ static int slab_allreduce(std::vector<nq_ctx*>& grp, int which) {
       HIPCHK(grp[r], hipEventRecord(grp[r]->ev_red, grp[r]->stream));
       HIPCHK(c0, hipStreamWaitEvent(c0->mstream, grp[r]->ev_red, 0));
     }
-    hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(64), 0, c0->mstream, pb, (int)grp.size(), n);
+    {
+      XTimer xt(c0, true);
+      hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(64), 0, c0->mstream, pb, (int)grp.size(), n);
+    }
     HIPCHK(c0, hipEventRecord(c0->ev_done, c0->mstream));
     for (nq_ctx* c : grp) HIPCHK(c, hipStreamWaitEvent(c->stream, c0->ev_done, 0));
     return 0;
@@ -1395,7 +1401,10 @@ static int slab_allreduce(std::vector<nq_ctx*>& grp, int which) {
     double* p = red_ptr(c, which, &n);
     HIPCHK(c, hipEventRecord(c->ev_red, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->mstream, c->ev_red, 0));
-    NCCLCHK(c, g_rccl.AllReduce(p, p, (size_t)n, kNcclDouble, kNcclSum, c->comm, c->mstream));
+    {
+      XTimer xt(c, true);
+      NCCLCHK(c, g_rccl.AllReduce(p, p, (size_t)n, kNcclDouble, kNcclSum, c->comm, c->mstream));
+    }
     HIPCHK(c, hipEventRecord(c->ev_done, c->mstream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
   }
@@ -1759,7 +1768,6 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
       ALLOC(c, c->twx_half, st.size() / 2 + 1);
       HIPCHK(c, hipMemcpyAsync(c->twx_half, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      ALLOC(c, c->eo_scratch, (size_t)c->num_cu * 2 * Mh);
     }
     ALLOC(c, c->kk, (size_t)N);
     ALLOC(c, c->ll, (size_t)N);
@@ -1976,7 +1984,49 @@ long long nq_device_bytes(const nq_ctx* c) { return c ? c->bytes : 0; }
 int nq_sync(nq_ctx* c) {
   if (!c) return -1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  // ... and the exchange stream: the last y -> x group of a slab step is only waited for by the NEXT row kernel, so the
+  // library's communicator can still have sends / receives queued when the compute stream is idle.  A caller that syncs
+  // and then runs a collective of its own (torch.distributed) must never find two communicators active on the device.
+  if (c->mstream) HIPCHK(c, hipStreamSynchronize(c->mstream));
   HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// 1 read + 1 write stream copy, 16 B per lane, grid-stride: the rate a plain copy kernel reaches on THIS device, the second
+// denominator of bench.py's roofline fractions.  Buffers live only for the call.
+__global__ void __launch_bounds__(256) k_stream_copy(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int nq_stream_copy_gbs(nq_ctx* c, long long bytes, int reps, double* gbs_out) {
+  if (!c || !gbs_out || bytes < (1 << 20) || reps < 1) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)bytes / sizeof(double2);
+  double2 *a = nullptr, *b = nullptr;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&a), n * sizeof(double2)));
+  if (hipMalloc(reinterpret_cast<void**>(&b), n * sizeof(double2)) != hipSuccess) {
+    (void)hipFree(a);
+    NQ_FAIL(c, -5, "nq_stream_copy_gbs: out of device memory");
+  }
+  (void)hipMemsetAsync(a, 1, n * sizeof(double2), c->stream);
+  (void)hipMemsetAsync(b, 0, n * sizeof(double2), c->stream);
+  const int grid = c->num_cu * 8;
+  hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, c->stream, (const double2*)a, b, n);      // untimed warm-up
+  double best = 0.0;
+  int rc = 0;
+  for (int r = 0; r < reps && rc == 0; ++r) {
+    if (hipEventRecord(c->ev0, c->stream) != hipSuccess) { rc = -5; break; }
+    hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, c->stream, (const double2*)a, b, n);
+    float ms = 0.f;
+    if (hipEventRecord(c->ev1, c->stream) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
+        hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) { rc = -5; break; }
+    const double g = 2.0 * (double)(n * sizeof(double2)) / (ms * 1e-3) / 1e9;
+    best = g > best ? g : best;
+  }
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  if (rc) NQ_FAIL(c, rc, "nq_stream_copy_gbs: event timing failed");
+  *gbs_out = best;
   return 0;
 }
 
@@ -2689,8 +2739,23 @@ int nq_slab_counters(nq_ctx* c, double* out, int reset) {
     c->n_calls = c->n_steps = c->n_exch = 0;
     c->bytes_sent = 0.0;
     c->xev_used = 0;
+    c->rev_used = 0;
     c->xtime = reset == 2;
   }
+  return 0;
+}
+// milliseconds the exchange stream spent in all-reduces since timing was switched on (nq_slab_counters(reset = 2)), and
+// how many were timed; read BEFORE the nq_slab_counters call that resets
+int nq_slab_allreduce_ms(nq_ctx* c, double* out2) {
+  if (!c || !out2) return -1;
+  SLABTRY(nq_sync(c));
+  float tot = 0.f;
+  for (size_t i = 0; i + 1 < c->rev_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->rev[i], c->rev[i + 1]) == hipSuccess) tot += ms;
+  }
+  out2[0] = (double)tot;
+  out2[1] = (double)(c->rev_used / 2);
   return 0;
 }
 

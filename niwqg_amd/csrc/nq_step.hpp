@@ -525,19 +525,30 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   }   // row blocks
 }
 
-// ---- X2 for rows of 2M points that do not fit the register budget as one transform ------------------------
+// ---- row kernels for rows of 2M points that do not fit the register budget as one transform -----------------------
 // An 8192-point row with 8 points per thread needs 1024 threads, i.e. 128 VGPRs: k_x_products then spills 700 B per
-// lane.  But every physical-space operation of this kernel is pointwise, so the even and the odd samples of a row can
-// be processed as two independent problems of M = 4096 points with the 4096 plan (512 threads, 256 VGPRs):
+// lane.  But every physical-space operation of the row kernels is pointwise, so the even and the odd samples of a row
+// are two independent problems of M = 4096 points with the 4096 plan (512 threads, 256 VGPRs):
 //     x[2m]   = ifft_M( X[k] + X[k+M] )[m],          x[2m+1] = ifft_M( (X[k] - X[k+M]) w^k )[m],   w = exp(2 pi i / 2M)
 //     Y[k]    = E[k] + conj(w^k) O[k],               Y[k+M]  = E[k] - conj(w^k) O[k],   E, O = fft_M(y_even), fft_M(y_odd)
-// The even pass parks its two output spectra (the packed (uq, vq) pair and W) in a per-workgroup scratch row in global
-// memory (L2-resident); the odd pass combines, splits the pair into its two half spectra and stores.  Inputs are read
-// once per pass (the second time from L2).  LDS: exchange area + stage twiddles of the M plan + the w^k table.
+// Round 3 (profiles/r03_pmc_summary_8192_before.json): the first version ran the even problem of a row to the end, parked
+// its output spectra in a global scratch row, then ran the odd problem -- every input was read TWICE and the scratch made a
+// round trip: 15.4 GB per launch for 6.4 GB of algorithmic bytes, at 4.8 TB/s of fabric traffic, 70 % of the wave cycles
+// waiting for memory.  Now BOTH parities go through every phase together: a raw input row is loaded once, folded into its
+// even and its odd problem in registers, the two transforms run back to back, and the two output spectra are combined in
+// registers (cache-warming "touch" loads a transform ahead of the real ones were tried on top, as LDS-DMA loads without a VGPR
+// destination: products unchanged, wave-PV 13 % slower, profiles/r03_tried_8192_cache_touches.txt -- the kernels are not
+// latency-bound any more).  What that costs is live state for two problems; the real fields that have to survive the longest (q_psi of
+// both parities; the odd (ik phi) transform in the wave-PV kernel) are parked in thread-private LDS slots (no barrier:
+// every thread reads back only what it wrote).  w^k = w^j w^(512 t) with w^(512 t) = exp(2 pi i t / 16) a compile-time
+// constant: no table.  LDS: exchange 64 KB + stage twiddles of the M plan 18.7 KB + park 64 KB.
+template <int T>
+__device__ __forceinline__ cd eo_omega(cd wj, int t) { return tw16<true>(wj, t); }      // w^(j + T t), T = M / 8
+
+// half-spectrum pair (a, b real-field spectra, k = 0..M) -> even and odd folds of Z = a + i b over the full row
 template <int M, int P, int T, bool PAIR, typename Row>
-__device__ __forceinline__ void eo_fold_pair(cd (&w)[P], const Row& rowA, const Row& rowB, int j, int par,
-                                             const cd* __restrict__ wtab, const double* __restrict__ kk, bool b_mul_ik,
-                                             bool b_zero_nyq, double b_scale) {
+__device__ __forceinline__ void eo_fold_pair2(cd (&we)[P], cd (&wo)[P], const Row& rowA, const Row& rowB, int j, cd wj,
+                                              const double* __restrict__ kk, bool b_mul_ik, bool b_zero_nyq, double b_scale) {
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int k = j + t * T, km = (k == 0) ? M : M - k;
@@ -547,8 +558,10 @@ __device__ __forceinline__ void eo_fold_pair(cd (&w)[P], const Row& rowA, const 
       b1 = cscale(cmul_i(b1), kk[k]);
       b2 = cscale(cmul_i(b2), kk[km]);
     }
-    b1 = cscale(b1, b_scale);
-    b2 = cscale(b2, b_scale);
+    if (PAIR) {
+      b1 = cscale(b1, b_scale);
+      b2 = cscale(b2, b_scale);
+    }
     cd z1, z2;
     if (k == 0) {                 // the two self-mirrored entries Z[0], Z[M]: imaginary parts of a, b dropped (hs_pack)
       if (b_zero_nyq) b2.x = 0.0;
@@ -558,24 +571,11 @@ __device__ __forceinline__ void eo_fold_pair(cd (&w)[P], const Row& rowA, const 
       z1 = cmake(a1.x - b1.y, a1.y + b1.x);             // Z[k]   = a + i b
       z2 = cmake(a2.x + b2.y, b2.x - a2.y);             // Z[k+M] = conj(a[M-k]) + i conj(b[M-k])
     }
-    w[t] = (par == 0) ? cadd(z1, z2) : cmul(cmake(z1.x - z2.x, z1.y - z2.y), wtab[k]);
+    we[t] = cadd(z1, z2);
+    wo[t] = cmul(csub(z1, z2), eo_omega<T>(wj, t));
   }
 }
-template <int M, int P, int T, typename Row>
-__device__ __forceinline__ void eo_fold_full(cd (&w)[P], const Row& row, int j, int par, const cd* __restrict__ wtab,
-                                             const double* __restrict__ kk, bool mul_ik) {
-#pragma unroll
-  for (int t = 0; t < P; ++t) {
-    const int k = j + t * T;
-    cd x1 = *row.at(k), x2 = *row.at(k + M);
-    if (mul_ik) {
-      x1 = cscale(cmul_i(x1), kk[k]);
-      x2 = cscale(cmul_i(x2), kk[k + M]);
-    }
-    w[t] = (par == 0) ? cadd(x1, x2) : cmul(cmake(x1.x - x2.x, x1.y - x2.y), wtab[k]);
-  }
-}
-// the same in two steps, so that the loads can be issued a phase ahead (and one row serve two folds)
+// full-width row: raw X[k], X[k+M] in registers -> one parity's fold (of X or of ik X)
 template <int M, int P, int T, typename Row>
 __device__ __forceinline__ void eo_load_full(cd (&x1)[P], cd (&x2)[P], const Row& row, int j) {
 #pragma unroll
@@ -585,8 +585,8 @@ __device__ __forceinline__ void eo_load_full(cd (&x1)[P], cd (&x2)[P], const Row
   }
 }
 template <int M, int P, int T>
-__device__ __forceinline__ void eo_fold_regs(cd (&w)[P], const cd (&x1)[P], const cd (&x2)[P], int j, int par,
-                                             const cd* __restrict__ wtab, const double* __restrict__ kk, bool mul_ik) {
+__device__ __forceinline__ void eo_fold_regs(cd (&w)[P], const cd (&x1)[P], const cd (&x2)[P], int j, int par, cd wj,
+                                             const double* __restrict__ kk, bool mul_ik) {
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int k = j + t * T;
@@ -595,35 +595,35 @@ __device__ __forceinline__ void eo_fold_regs(cd (&w)[P], const cd (&x1)[P], cons
       a = cscale(cmul_i(a), kk[k]);
       b = cscale(cmul_i(b), kk[k + M]);
     }
-    w[t] = (par == 0) ? cadd(a, b) : cmul(cmake(a.x - b.x, a.y - b.y), wtab[k]);
+    w[t] = (par == 0) ? cadd(a, b) : cmul(csub(a, b), eo_omega<T>(wj, t));
   }
 }
-// odd pass: r = O; scratch = E; writes the two half spectra of the packed pair
+// E, O = spectra of the even / odd problem of a PACKED pair y = a + i b (a, b real): combine to Y and split into the two
+// half spectra A, B (k = 0..M).  The mirrored entry Y[2M - k] = E[M-k] - conj(w^(M-k)) O[M-k] comes from the thread that
+// owns M - k, through the exchange area (one LDS round trip).  O is destroyed.
 template <int M, int P, int T, typename F, typename Row>
-__device__ __forceinline__ void eo_unpack_pair_store(cd (&r)[P], int j, int c, cd* lds, const cd* __restrict__ escr,
-                                                     const cd* __restrict__ wtab, const Row& rowA, const Row& rowB,
-                                                     double scaleB = 1.0) {
+__device__ __forceinline__ void eo_unpack_pair_store2(const cd (&e)[P], cd (&o)[P], int j, int c, cd* lds, cd wj,
+                                                      const Row& rowA, const Row& rowB, double scaleB = 1.0) {
   wg_barrier();
 #pragma unroll
-  for (int t = 0; t < P; ++t) lds[F::lds_index(j + t * T, c)] = r[t];
+  for (int t = 0; t < P; ++t) {
+    const cd w = eo_omega<T>(wj, t);
+    o[t] = cmul(cmake(w.x, -w.y), o[t]);                                // conj(w^k) O[k]
+    lds[F::lds_index(j + t * T, c)] = csub(e[t], o[t]);                 // D[k] = Y[k + M]
+  }
   wg_barrier();
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int k = j + t * T;
-    const cd e1 = escr[k], w1 = wtab[k];
-    const cd o1 = cmul(cmake(w1.x, -w1.y), r[t]);
-    const cd y = cadd(e1, o1);
+    const cd y = cadd(e[t], o[t]);
     cd ym;
     if (k == 0) {
-      ym = y;                                                  // Y[2M] = Y[0]
-      const cd yM = cmake(e1.x - o1.x, e1.y - o1.y);           // Y[M] = E[0] - O[0], its own mirror
+      ym = y;                                                    // Y[2M] = Y[0]
+      const cd yM = csub(e[t], o[t]);                            // Y[M] = E[0] - O[0], its own mirror
       *rowA.at(M) = cmake(yM.x, 0.0);
       *rowB.at(M) = cmake(scaleB * yM.y, 0.0);
     } else {
-      const int km = M - k;
-      const cd e2 = escr[km], w2 = wtab[km];
-      const cd o2 = cmul(cmake(w2.x, -w2.y), lds[F::lds_index(km, c)]);
-      ym = cmake(e2.x - o2.x, e2.y - o2.y);                    // Y[2M - k] = E[M-k] - conj(w^(M-k)) O[M-k]
+      ym = lds[F::lds_index(M - k, c)];                          // Y[2M - k]
     }
     *rowA.at(k) = cmake(0.5 * (y.x + ym.x), 0.5 * (y.y - ym.y));
     *rowB.at(k) = cmake(scaleB * 0.5 * (y.y + ym.y), scaleB * 0.5 * (ym.x - y.x));
@@ -631,241 +631,368 @@ __device__ __forceinline__ void eo_unpack_pair_store(cd (&r)[P], int j, int c, c
   wg_barrier();
 }
 
+#ifndef NQ_EO_PREFETCH_ROW
+#define NQ_EO_PREFETCH_ROW 0
+#endif
+#ifndef NQ_EO_HOLD_PHI
+#define NQ_EO_HOLD_PHI 1     // 1: the coupled model keeps phi's raw row in registers from the phix phase to the phi phase
+#endif
+// Phase boundary of the even/odd kernels: NQ_PHASE_FENCE plus a laundering of j, c and w^j.  Everything derived from
+// them (the eight w^k, kk[k], kk[k + M], row addresses) would otherwise be computed once and kept live across the whole
+// row by common-subexpression elimination: ~60 VGPRs that the two-problem live state cannot spare (500 B/lane of scratch).
+#define NQ_EO_FENCE()                                                  \
+  do {                                                                 \
+    NQ_PHASE_FENCE();                                                  \
+    asm volatile("" : "+v"(j), "+v"(c), "+v"(wj.x), "+v"(wj.y));      \
+  } while (0)
+
 template <int N2, int MODE, bool SLAB>
 __global__ void __launch_bounds__(XPlan<N2 / 2>::THREADS, XPlan<N2 / 2>::MIN_WAVES)
 k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy, MArr Muq, MArr Mvq, MArr Mw,
                 const cd* __restrict__ tw, const cd* __restrict__ wglob, const double* __restrict__ kk, int v_zero_nyq,
-                double cj, double cr, int nblocks, cd* __restrict__ scratch) {
+                double cj, double cr, int nblocks) {
   constexpr int M = N2 / 2;
   typedef XPlan<M> X;
   typedef typename X::F F;
   constexpr int P = X::P, T = X::T;
-  static_assert(X::C == 1, "one row per workgroup");
+  static_assert(X::C == 1 && P == 8, "one row per workgroup, 8 points per thread (w^(T t) = 16th roots of unity)");
   const int j_tid = threadIdx.x;
-  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  cd* lds = reinterpret_cast<cd*>(nq_smem);                             // [exchange][stage twiddles][park][red]
   cd* twl = lds + F::LDS_ELEMS;
-  cd* wtab = twl + F::TW_LDS_ELEMS;                      // w^k = exp(+2 pi i k / N2), k < M
+  double* park = reinterpret_cast<double*>(twl + F::TW_LDS_ELEMS);      // [2][M] doubles, thread-private slots
+  double* red = park + 2 * M;                                            // 512 B of reduction scratch
   for (int i = threadIdx.x; i < F::TW_LDS_ELEMS; i += X::THREADS) twl[i] = tw[i];
-  for (int i = threadIdx.x; i < M; i += X::THREADS) {
-    const cd z = wglob[i];                               // global table holds exp(-2 pi i m / N2)
-    wtab[i] = cmake(z.x, -z.y);
-  }
   typename F::TwLds twr;
   twr.base = twl;
+  cd wj_tid;
+  {
+    const cd z = wglob[j_tid];                           // global table holds exp(-2 pi i m / N2)
+    wj_tid = cmake(z.x, -z.y);
+  }
   wg_barrier_all();
-  double* red = reinterpret_cast<double*>(wtab + M);
-  cd* escr_p = scratch + (size_t)blockIdx.x * 2 * M;     // E of the packed pair, then E of W
-  cd* escr_w = escr_p + M;
   constexpr bool PAIRQ = (MODE == MODE_COUPLED || MODE == MODE_QGC);
   constexpr bool ONLYQ = (MODE == MODE_QG || MODE == MODE_QGC);
   for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+    // per-iteration copies the compiler cannot see through (loop-invariant addresses would be hoisted and spill)
     int j = j_tid, c = 0;
-    asm volatile("" : "+v"(j), "+v"(c));
+    cd wj = wj_tid;
+    asm volatile("" : "+v"(j), "+v"(c), "+v"(wj.x), "+v"(wj.y));
     const size_t row = (size_t)rb;
-    double js[2] = {0.0, 0.0};
-#pragma unroll 1
-    for (int par_i = 0; par_i < 2; ++par_i) {
-      // the scratch row is written by this workgroup in the even pass and read back by it in the odd pass (and
-      // rewritten for the next row after that): order the two with a workgroup-scope fence and barrier
-      __threadfence_block();
-      __syncthreads();
-      int par = par_i;
-      asm volatile("" : "+s"(par), "+v"(j), "+v"(c));     // nothing of a pass may be hoisted or shared with the other
-      cd w[P];
-      double q[P], qpsi[P], u[P], v[P];
-      eo_fold_pair<M, P, T, PAIRQ>(w, xrow<SLAB>(Mq, row), xrow<SLAB>(PAIRQ ? Mqw : Mq, row), j, par, wtab, kk, false, false, 1.0);
-      NQ_PHASE_FENCE();
-      F::template run<true>(w, j, c, lds, twr);
+    cd we[P], wo[P];
+    double qe[P], qo[P];
+    double c_unscale = 1.0, c_scale = 1.0;
+    if constexpr (MODE == MODE_QGC) {
+      // q and the passive scalar share one complex transform; c has arbitrary units: rescale it per row by a power of two
+      // (k_x_products does the same).  One extra sweep over the two rows (they are re-read from cache by the fold).
+      const XRowT<SLAB> ra = xrow<SLAB>(Mq, row), rbw = xrow<SLAB>(Mqw, row);
+      double ma = 0.0, mb = 0.0;
 #pragma unroll
       for (int t = 0; t < P; ++t) {
-        q[t] = w[t].x;
-        qpsi[t] = (MODE == MODE_COUPLED) ? w[t].x - w[t].y : (MODE == MODE_QGC ? w[t].y : w[t].x);
+        const cd a = *ra.at(j + t * T), b = *rbw.at(j + t * T);
+        ma = fmax(ma, fmax(fabs(a.x), fabs(a.y)));
+        mb = fmax(mb, fmax(fabs(b.x), fabs(b.y)));
       }
-      NQ_PHASE_FENCE();
-      eo_fold_pair<M, P, T, true>(w, xrow<SLAB>(Mu, row), xrow<SLAB>(Mp, row), j, par, wtab, kk, true, v_zero_nyq != 0, 1.0);
-      NQ_PHASE_FENCE();
-      F::template run<true>(w, j, c, lds, twr);
-#pragma unroll
-      for (int t = 0; t < P; ++t) {
-        u[t] = w[t].x;
-        v[t] = w[t].y;
-        w[t] = cmake(u[t] * q[t], v[t] * q[t]);
+      if (j == 0) {
+        const cd a = *ra.at(M), b = *rbw.at(M);
+        ma = fmax(ma, fabs(a.x));
+        mb = fmax(mb, fabs(b.x));
       }
-      NQ_PHASE_FENCE();
-      F::template run<false>(w, j, c, lds, twr);
-      NQ_PHASE_FENCE();
-      if (par == 0) {
-#pragma unroll
-        for (int t = 0; t < P; ++t) escr_p[j + t * T] = w[t];
-      } else {
-        eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr_p, wtab, xrow<SLAB>(Muq, row), xrow<SLAB>(Mvq, row));
+      unsigned long long* mx = reinterpret_cast<unsigned long long*>(red + 40);
+      if (j == 0) {
+        mx[0] = 0ull;
+        mx[1] = 0ull;
       }
-      if (ONLYQ) {
-        if (MODE == MODE_QGC) {
-          NQ_PHASE_FENCE();
-          // second packed pair (u c, v c); the even pass parks it in the W slot of the scratch row
+      wg_barrier();
+      row_atomic_max<T>(mx, ma, mb);
+      wg_barrier();
+      ma = __longlong_as_double((long long)mx[0]);
+      mb = __longlong_as_double((long long)mx[1]);
+      int e = 0;
+      if (ma > 0.0 && mb > 0.0) e = ilogb(ma) - ilogb(mb);
+      e = e > 900 ? 900 : (e < -900 ? -900 : e);
+      c_scale = ldexp(1.0, e);
+      c_unscale = ldexp(1.0, -e);
+      wg_barrier();
+    }
+    // ---- phase 1: (q, qw | c) -> q, q_psi of both parities
+    eo_fold_pair2<M, P, T, PAIRQ>(we, wo, xrow<SLAB>(Mq, row), xrow<SLAB>(PAIRQ ? Mqw : Mq, row), j, wj, kk, false, false, c_scale);
+    NQ_EO_FENCE();
+    F::template run<true>(we, j, c, lds, twr);
 #pragma unroll
-          for (int t = 0; t < P; ++t) w[t] = cmake(u[t] * qpsi[t], v[t] * qpsi[t]);
-          NQ_PHASE_FENCE();
-          F::template run<false>(w, j, c, lds, twr);
-          NQ_PHASE_FENCE();
-          if (par == 0) {
+    for (int t = 0; t < P; ++t) {
+      qe[t] = we[t].x;
+      const double qp = (MODE == MODE_COUPLED) ? we[t].x - we[t].y : (MODE == MODE_QGC ? we[t].y * c_unscale : we[t].x);
+      if constexpr (MODE != MODE_QG) park[j + t * T] = qp;              // q_psi, or QGModel's passive scalar
+    }
+    NQ_EO_FENCE();
+    F::template run<true>(wo, j, c, lds, twr);
 #pragma unroll
-            for (int t = 0; t < P; ++t) escr_w[j + t * T] = w[t];
-          } else {
-            eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr_w, wtab, xrow<SLAB>(Mgx, row), xrow<SLAB>(Mgy, row));
-          }
+    for (int t = 0; t < P; ++t) {
+      qo[t] = wo[t].x;
+      const double qp = (MODE == MODE_COUPLED) ? wo[t].x - wo[t].y : (MODE == MODE_QGC ? wo[t].y * c_unscale : wo[t].x);
+      if constexpr (MODE != MODE_QG) park[M + j + t * T] = qp;
+    }
+    // ---- phase 2: (u, v) = ifft of (-il psi, ik psi); u q + i v q of both parities -> Muq, Mvq
+    NQ_EO_FENCE();
+    eo_fold_pair2<M, P, T, true>(we, wo, xrow<SLAB>(Mu, row), xrow<SLAB>(Mp, row), j, wj, kk, true, v_zero_nyq != 0, 1.0);
+    NQ_EO_FENCE();
+    F::template run<true>(we, j, c, lds, twr);
+    double ue[P], ve[P], uo[P], vo[P];
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      ue[t] = we[t].x;
+      ve[t] = we[t].y;
+      we[t] = cmake(ue[t] * qe[t], ve[t] * qe[t]);
+    }
+    NQ_EO_FENCE();
+    F::template run<true>(wo, j, c, lds, twr);
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      uo[t] = wo[t].x;
+      vo[t] = wo[t].y;
+      wo[t] = cmake(uo[t] * qo[t], vo[t] * qo[t]);
+    }
+    NQ_EO_FENCE();
+    F::template run<false>(we, j, c, lds, twr);
+    NQ_EO_FENCE();
+    F::template run<false>(wo, j, c, lds, twr);
+    NQ_EO_FENCE();
+    eo_unpack_pair_store2<M, P, T, F>(we, wo, j, c, lds, wj, xrow<SLAB>(Muq, row), xrow<SLAB>(Mvq, row));
+    if constexpr (ONLYQ) {
+      if constexpr (MODE == MODE_QGC) {          // second packed pair (u c, v c) -> Mgx, Mgy (= the Muc, Mvc arrays)
+#pragma unroll
+        for (int t = 0; t < P; ++t) {
+          const double ce = park[j + t * T], co = park[M + j + t * T];
+          we[t] = cmake(ue[t] * ce, ve[t] * ce);
+          wo[t] = cmake(uo[t] * co, vo[t] * co);
         }
-        continue;
+        NQ_EO_FENCE();
+        F::template run<false>(we, j, c, lds, twr);
+        NQ_EO_FENCE();
+        F::template run<false>(wo, j, c, lds, twr);
+        NQ_EO_FENCE();
+        eo_unpack_pair_store2<M, P, T, F>(we, wo, j, c, lds, wj, xrow<SLAB>(Mgx, row), xrow<SLAB>(Mgy, row));
       }
-      if constexpr (!ONLYQ) {
-      // (requesting the full-width rows a phase ahead costs 64 VGPRs: the spills it causes eat the gain -- measured)
-      NQ_PHASE_FENCE();
-      eo_fold_full<M, P, T>(w, xrow<SLAB>(Mphi, row), j, par, wtab, kk, false);
-      NQ_PHASE_FENCE();
-      F::template run<true>(w, j, c, lds, twr);
-      cd acc[P];
+      continue;
+    } else {
+      // The three wave phases in the order that ends the longest-lived real fields first: phiy x v (v dies), phix x u (u
+      // dies), phi x q_psi (q_psi comes back from its LDS slots).  je, jo accumulate cj (u phix + v phiy) + i cr phi q_psi.
+      cd x1[P], x2[P], je[P], jo[P];
+      double js[2] = {0.0, 0.0};
+      // ---- phase 3: phiy, times v
+      eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mgy, row), j);
+      NQ_EO_FENCE();
+      eo_fold_regs<M, P, T>(je, x1, x2, j, 0, wj, kk, false);
+      eo_fold_regs<M, P, T>(jo, x1, x2, j, 1, wj, kk, false);
+      NQ_EO_FENCE();
+      F::template run<true>(je, j, c, lds, twr);
 #pragma unroll
-      for (int t = 0; t < P; ++t) acc[t] = cmake(-cr * qpsi[t] * w[t].y, cr * qpsi[t] * w[t].x);
-      NQ_PHASE_FENCE();
-      eo_fold_full<M, P, T>(w, xrow<SLAB>(MODE == MODE_COUPLED ? Mphi : Mgx, row), j, par, wtab, kk, true);
-      NQ_PHASE_FENCE();
-      F::template run<true>(w, j, c, lds, twr);
+      for (int t = 0; t < P; ++t) je[t] = cscale(je[t], ve[t]);
+      NQ_EO_FENCE();
+      F::template run<true>(jo, j, c, lds, twr);
 #pragma unroll
-      for (int t = 0; t < P; ++t) w[t] = cscale(w[t], u[t]);
-      cd pre[P];
-      NQ_PHASE_FENCE();
-      eo_fold_full<M, P, T>(pre, xrow<SLAB>(Mgy, row), j, par, wtab, kk, false);
-      NQ_PHASE_FENCE();
-      F::template run<true>(pre, j, c, lds, twr);
+      for (int t = 0; t < P; ++t) jo[t] = cscale(jo[t], vo[t]);
+      // ---- phase 4: phix = ifft(ik g), times u.  Coupled: g is the phi row itself.
+      NQ_EO_FENCE();
+      eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(MODE == MODE_COUPLED ? Mphi : Mgx, row), j);
+      NQ_EO_FENCE();
+      eo_fold_regs<M, P, T>(we, x1, x2, j, 0, wj, kk, true);
+#if !NQ_EO_HOLD_PHI
+      eo_fold_regs<M, P, T>(wo, x1, x2, j, 1, wj, kk, true);
+#endif
+      NQ_EO_FENCE();
+      F::template run<true>(we, j, c, lds, twr);
 #pragma unroll
       for (int t = 0; t < P; ++t) {
-        const cd J = cmake(w[t].x + pre[t].x * v[t], w[t].y + pre[t].y * v[t]);
-        js[0] += J.x;
-        js[1] += J.y;
-        acc[t] = cmake(acc[t].x + cj * J.x, acc[t].y + cj * J.y);
+        je[t] = cmake(je[t].x + we[t].x * ue[t], je[t].y + we[t].y * ue[t]);
+        js[0] += je[t].x;
+        js[1] += je[t].y;
+        je[t] = cscale(je[t], cj);
       }
-      NQ_PHASE_FENCE();
-      F::template run<false>(acc, j, c, lds, twr);
-      NQ_PHASE_FENCE();
-      if (par == 0) {
+      NQ_EO_FENCE();
+#if NQ_EO_HOLD_PHI
+      eo_fold_regs<M, P, T>(wo, x1, x2, j, 1, wj, kk, true);
+      NQ_EO_FENCE();
+#endif
+      F::template run<true>(wo, j, c, lds, twr);
 #pragma unroll
-        for (int t = 0; t < P; ++t) escr_w[j + t * T] = acc[t];
-      } else {
+      for (int t = 0; t < P; ++t) {
+        jo[t] = cmake(jo[t].x + wo[t].x * uo[t], jo[t].y + wo[t].y * uo[t]);
+        js[0] += jo[t].x;
+        js[1] += jo[t].y;
+        jo[t] = cscale(jo[t], cj);
+      }
+      // ---- phase 5: phi, the refraction factor: + i cr phi q_psi
+      NQ_EO_FENCE();
+#if NQ_EO_HOLD_PHI
+      if constexpr (MODE != MODE_COUPLED) eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, row), j);
+#else
+      eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, row), j);       // Coupled: the same row again, 6 us later (from cache)
+#endif
+      NQ_EO_FENCE();
+      eo_fold_regs<M, P, T>(we, x1, x2, j, 0, wj, kk, false);
+      eo_fold_regs<M, P, T>(wo, x1, x2, j, 1, wj, kk, false);
+      NQ_EO_FENCE();
+      F::template run<true>(we, j, c, lds, twr);
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        const double qp = cr * park[j + t * T];
+        je[t] = cmake(je[t].x - qp * we[t].y, je[t].y + qp * we[t].x);
+      }
+      NQ_EO_FENCE();
+      F::template run<true>(wo, j, c, lds, twr);
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        const double qp = cr * park[M + j + t * T];
+        jo[t] = cmake(jo[t].x - qp * wo[t].y, jo[t].y + qp * wo[t].x);
+      }
+      // ---- forward: W = fft of the phi tendency source, both parities, combined in registers
+      NQ_EO_FENCE();
+      F::template run<false>(je, j, c, lds, twr);
+      NQ_EO_FENCE();
+      F::template run<false>(jo, j, c, lds, twr);
+      NQ_EO_FENCE();
+      {
         const XRowT<SLAB> rp = xrow<SLAB>(Mw, row);
 #pragma unroll
         for (int t = 0; t < P; ++t) {
           const int k = j + t * T;
-          const cd e = escr_w[k], w1 = wtab[k];
-          const cd o = cmul(cmake(w1.x, -w1.y), acc[t]);
-          *rp.at(k) = cadd(e, o);
-          *rp.at(k + M) = cmake(e.x - o.x, e.y - o.y);
+          const cd w = eo_omega<T>(wj, t);
+          const cd o = cmul(cmake(w.x, -w.y), jo[t]);
+          *rp.at(k) = cadd(je[t], o);
+          *rp.at(k + M) = csub(je[t], o);
         }
       }
-      }   // !ONLYQ
-    }
-    if (!ONLYQ) {
-      NQ_PHASE_FENCE();
+      // sum of the Jacobian part over this row -> passenger slot of the row (padding column Muq.W of block 0)
+      NQ_EO_FENCE();
       block_sum_store<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)rb * Muq.pitch + Muq.W));
     }
   }
 }
 
-// wave-PV sources for rows of 2M points, even / odd samples as two M-point problems (see k_x_products_eo)
+// wave-PV sources for rows of 2M points: both parities through every phase, inputs read once (see k_x_products_eo)
 template <int N2, bool SLAB>
 __global__ void __launch_bounds__(XPlan<N2 / 2>::THREADS, XPlan<N2 / 2>::MIN_WAVES)
 k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, const cd* __restrict__ wglob,
-              const double* __restrict__ kk, int nblocks, cd* __restrict__ scratch) {
+              const double* __restrict__ kk, int nblocks) {
   constexpr int M = N2 / 2;
   typedef XPlan<M> X;
   typedef typename X::F F;
   constexpr int P = X::P, T = X::T;
-  static_assert(X::C == 1, "one row per workgroup");
+  static_assert(X::C == 1 && P == 8, "one row per workgroup, 8 points per thread");
   const int j_tid = threadIdx.x;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
   cd* twl = lds + F::LDS_ELEMS;
-  cd* wtab = twl + F::TW_LDS_ELEMS;
+  cd* park = twl + F::TW_LDS_ELEMS;                        // [M] complex, thread-private slots: phix of the odd parity
+  unsigned long long* mx = reinterpret_cast<unsigned long long*>(park + M);
   for (int i = threadIdx.x; i < F::TW_LDS_ELEMS; i += X::THREADS) twl[i] = tw[i];
-  for (int i = threadIdx.x; i < M; i += X::THREADS) {
-    const cd z = wglob[i];
-    wtab[i] = cmake(z.x, -z.y);
-  }
   typename F::TwLds twr;
   twr.base = twl;
+  cd wj_tid;
+  {
+    const cd z = wglob[j_tid];
+    wj_tid = cmake(z.x, -z.y);
+  }
   wg_barrier_all();
-  unsigned long long* mx = reinterpret_cast<unsigned long long*>(wtab + M);
-  cd* escr = scratch + (size_t)blockIdx.x * 2 * M;
-  // raw rows are requested one phase ahead: phi's row (it serves both phi and phix) before the forward transform and
-  // the stores of the previous pass, phiy's row before the first two inverse transforms
-  cd r1[P], r2[P];
-  eo_load_full<M, P, T>(r1, r2, xrow<SLAB>(Mphi, (size_t)blockIdx.x), j_tid);
+#if NQ_EO_PREFETCH_ROW
+  // the phi row of the NEXT row block is requested before the forward transforms and the stores of the current one
+  cd x1[P], x2[P];
+  eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, (size_t)blockIdx.x), j_tid);
+#endif
   for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
     int j = j_tid, c = 0;
+    cd wj = wj_tid;
+    asm volatile("" : "+v"(j), "+v"(c), "+v"(wj.x), "+v"(wj.y));
     const size_t row = (size_t)rb;
     const bool more = rb + (int)gridDim.x < nblocks;
-    int e_scale = 0;                     // power-of-two rescale of the second field: chosen in the even pass, used in both
-#pragma unroll 1
-    for (int par_i = 0; par_i < 2; ++par_i) {
-      __threadfence_block();
-      __syncthreads();
-      int par = par_i;
-      asm volatile("" : "+s"(par), "+v"(j), "+v"(c));
-      cd w[P], gx[P];
-      double a[P];
-      eo_fold_regs<M, P, T>(w, r1, r2, j, par, wtab, kk, false);
-      eo_fold_regs<M, P, T>(gx, r1, r2, j, par, wtab, kk, true);
-      eo_load_full<M, P, T>(r1, r2, xrow<SLAB>(Mphiy, row), j);          // in flight during the next two transforms
-      NQ_PHASE_FENCE();
-      F::template run<true>(w, j, c, lds, twr);
-      double ma = 0.0, mb = 0.0;
+    cd we[P], wo[P], ge[P];
+    double ae[P], ao[P];
+#if !NQ_EO_PREFETCH_ROW
+    cd x1[P], x2[P];
+    eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, row), j);
+    NQ_EO_FENCE();
+#endif
+    // phi and phix = ifft(ik phi) of both parities from ONE read of the row
+    eo_fold_regs<M, P, T>(we, x1, x2, j, 0, wj, kk, false);
+    NQ_EO_FENCE();
+    F::template run<true>(we, j, c, lds, twr);
+    double ma = 0.0, mb = 0.0;
 #pragma unroll
-      for (int t = 0; t < P; ++t) {
-        a[t] = w[t].x * w[t].x + w[t].y * w[t].y;
-        ma = fmax(ma, a[t]);
-      }
-      NQ_PHASE_FENCE();
-      F::template run<true>(gx, j, c, lds, twr);
-      NQ_PHASE_FENCE();
-      eo_fold_regs<M, P, T>(w, r1, r2, j, par, wtab, kk, false);
-      // phi's row again: for the odd pass of this row, or for the next row of this workgroup
-      if (par == 0) eo_load_full<M, P, T>(r1, r2, xrow<SLAB>(Mphi, row), j);
-      else if (more) eo_load_full<M, P, T>(r1, r2, xrow<SLAB>(Mphi, row + gridDim.x), j);
-      NQ_PHASE_FENCE();
-      F::template run<true>(w, j, c, lds, twr);
-#pragma unroll
-      for (int t = 0; t < P; ++t) {
-        const double b = -2.0 * (gx[t].x * w[t].y - gx[t].y * w[t].x);
-        mb = fmax(mb, fabs(b));
-        w[t] = cmake(a[t], b);
-      }
-      if (par == 0) {
-        if (j == 0) {
-          mx[0] = 0ull;
-          mx[1] = 0ull;
-        }
-        wg_barrier();
-        row_atomic_max<T>(mx, ma, mb);
-        wg_barrier();
-        ma = __longlong_as_double((long long)mx[0]);
-        mb = __longlong_as_double((long long)mx[1]);
-        int e = 0;
-        if (ma > 0.0 && mb > 0.0) e = ilogb(ma) - ilogb(mb);
-        e_scale = e > 900 ? 900 : (e < -900 ? -900 : e);
-      }
-      const double sb = ldexp(1.0, e_scale);
-#pragma unroll
-      for (int t = 0; t < P; ++t) w[t].y *= sb;
-      NQ_PHASE_FENCE();
-      F::template run<false>(w, j, c, lds, twr);
-      NQ_PHASE_FENCE();
-      if (par == 0) {
-#pragma unroll
-        for (int t = 0; t < P; ++t) escr[j + t * T] = w[t];
-      } else {
-        // split into the two half spectra; the second carries the factor sb, undone here by scaling its rows
-        eo_unpack_pair_store<M, P, T, F>(w, j, c, lds, escr, wtab, xrow<SLAB>(Ma, row), xrow<SLAB>(Mb, row), ldexp(1.0, -e_scale));
-      }
+    for (int t = 0; t < P; ++t) {
+      ae[t] = we[t].x * we[t].x + we[t].y * we[t].y;
+      ma = fmax(ma, ae[t]);
     }
+    NQ_EO_FENCE();
+    eo_fold_regs<M, P, T>(wo, x1, x2, j, 1, wj, kk, false);
+    NQ_EO_FENCE();
+    F::template run<true>(wo, j, c, lds, twr);
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      ao[t] = wo[t].x * wo[t].x + wo[t].y * wo[t].y;
+      ma = fmax(ma, ao[t]);
+    }
+    NQ_EO_FENCE();
+    eo_fold_regs<M, P, T>(wo, x1, x2, j, 1, wj, kk, true);
+    NQ_EO_FENCE();
+    F::template run<true>(wo, j, c, lds, twr);
+#pragma unroll
+    for (int t = 0; t < P; ++t) park[j + t * T] = wo[t];
+    NQ_EO_FENCE();
+    eo_fold_regs<M, P, T>(ge, x1, x2, j, 0, wj, kk, true);
+    // phi_y's row: in flight during the next transform
+    eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphiy, row), j);
+    NQ_EO_FENCE();
+    F::template run<true>(ge, j, c, lds, twr);
+    NQ_EO_FENCE();
+    eo_fold_regs<M, P, T>(we, x1, x2, j, 0, wj, kk, false);
+    eo_fold_regs<M, P, T>(wo, x1, x2, j, 1, wj, kk, false);
+    NQ_EO_FENCE();
+    F::template run<true>(we, j, c, lds, twr);
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const double b = -2.0 * (ge[t].x * we[t].y - ge[t].y * we[t].x);
+      mb = fmax(mb, fabs(b));
+      we[t] = cmake(ae[t], b);
+    }
+    NQ_EO_FENCE();
+    F::template run<true>(wo, j, c, lds, twr);
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const cd g = park[j + t * T];
+      const double b = -2.0 * (g.x * wo[t].y - g.y * wo[t].x);
+      mb = fmax(mb, fabs(b));
+      wo[t] = cmake(ao[t], b);
+    }
+#if NQ_EO_PREFETCH_ROW
+    NQ_EO_FENCE();
+    // the phi row of the next row block: in flight during the two forward transforms and the stores
+    if (more) eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, row + gridDim.x), j);
+#endif
+    // |phi|^2 is typically 1e8 times J(phi*, phi): the second field is rescaled per row by a power of two (k_x_wavepv)
+    if (j == 0) {
+      mx[0] = 0ull;
+      mx[1] = 0ull;
+    }
+    wg_barrier();
+    row_atomic_max<T>(mx, ma, mb);
+    wg_barrier();
+    ma = __longlong_as_double((long long)mx[0]);
+    mb = __longlong_as_double((long long)mx[1]);
+    int e = 0;
+    if (ma > 0.0 && mb > 0.0) e = ilogb(ma) - ilogb(mb);
+    e = e > 900 ? 900 : (e < -900 ? -900 : e);
+    const double sb = ldexp(1.0, e);
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      we[t].y *= sb;
+      wo[t].y *= sb;
+    }
+    NQ_EO_FENCE();
+    F::template run<false>(we, j, c, lds, twr);
+    NQ_EO_FENCE();
+    F::template run<false>(wo, j, c, lds, twr);
+    NQ_EO_FENCE();
+    eo_unpack_pair_store2<M, P, T, F>(we, wo, j, c, lds, wj, xrow<SLAB>(Ma, row), xrow<SLAB>(Mb, row), ldexp(1.0, -e));
   }
 }
 

@@ -317,6 +317,7 @@ class SlabSimulation(object):
         v = np.max(np.asarray(values, float).reshape(len(self.ranks), -1), axis=0)
         if self.link != "peers":
             import torch
+            self.sync()        # never two communicators active on the device (nq_sync drains the exchange stream too)
             t = torch.from_numpy(v.copy())
             if self.dist.get_backend() == "nccl":
                 t = t.to(torch.device("cuda", self.lead.device))
@@ -329,9 +330,12 @@ class SlabSimulation(object):
         return float(np.max(self.max_over_ranks([r.local_max() for r in self.ranks])))
 
     def counters(self, reset=0):
+        red = np.zeros(2)
+        self.lead._chk(self.L.nq_slab_allreduce_ms(self.lead.h, _lib._dptr(red)), "nq_slab_allreduce_ms")
         out = np.zeros(6)
         self.lead._chk(self.L.nq_slab_counters(self.lead.h, _lib._dptr(out), int(reset)), "nq_slab_counters")
-        return dict(host_calls=out[0], steps=out[1], exchange_chunks=out[2], bytes_sent=out[3], exchange_ms=out[4], nchunks=out[5])
+        return dict(host_calls=out[0], steps=out[1], exchange_chunks=out[2], bytes_sent=out[3], exchange_ms=out[4], nchunks=out[5],
+                    allreduce_ms=red[0], allreduces=red[1])
 
     # --- gathering -----------------------------------------------------------------------------------------
     def _gather(self, parts, axis):
@@ -339,6 +343,7 @@ class SlabSimulation(object):
         if self.link == "peers":
             return np.concatenate(parts, axis=axis)
         import torch
+        self.sync()            # the library's streams (compute AND exchange) are drained before torch's communicator runs
         mine = np.ascontiguousarray(parts[0])
         bufs = [None] * self.nranks
         self.dist.all_gather_object(bufs, mine)

@@ -16,13 +16,25 @@ namespace nq {
 
 constexpr int CL = 32;   // columns per workgroup in the y sub-passes
 
-template <int S> struct YPlan {
-  static constexpr int P = (S >= 128) ? 16 : 8;
+// CLX = CL: the tiles of the two-pass y transform (S = one radix of N = S1 * S2).  CLX = CLS: SINGLE-PASS columns for small
+// grids (S = N <= 512, S2 = 1): a tile of CLS whole columns fits a workgroup with room for the fused spectral kernels' four
+// arrays (8 points per thread) and the A sub-pass disappears: 12 instead of 20 launches per QGModel step.  These grids are
+// cache-resident and their steps are chains of dependent 5-10 microsecond kernels, so narrow tiles (more workgroups) beat
+// wide segments: CLS = 8 / 4 / 2 measured 3584 / 3855 / 3470 steps/s on UnCoupledModel 512^2 and 8805 / 8820 / 8440 on
+// QGModel 256^2, against 3450 / 8380 with the two-pass tiles (profiles/r03_small_grids_single_pass_columns.txt).
+#ifndef NQ_CLS
+#define NQ_CLS 4
+#endif
+constexpr int CLS = NQ_CLS;
+template <int S, int CLX = CL> struct YPlanT {
+  static constexpr int CLW = CLX;
+  static constexpr int P = (CLX != CL) ? 8 : ((S >= 128) ? 16 : 8);
   static constexpr int T = S / P;
-  static constexpr int THREADS = CL * T;
-  typedef WgFft<S, P, CL, false> F;
+  static constexpr int THREADS = CLX * T;
+  typedef WgFft<S, P, CLX, false> F;
   static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cd) + 512;   // + reduction scratch
 };
+template <int S> using YPlan = YPlanT<S, CL>;
 
 #ifndef NQ_XP
 #define NQ_XP 8      // points per thread in k_x_products: 8 -> 512 threads per 4096-point row, no spills
@@ -231,14 +243,14 @@ k_y_A(ArrayList al, int S1, const cd* __restrict__ tw, int tw_step_N /* NT/N */)
 // "B" sub-pass, out of place.  grid = (col tiles, S2, 1); S1 = transform length.
 // forward: in = half-transformed rows S1*l1 + y1, out = natural rows l1 + S2*l2
 // inverse: in = natural rows, out = half-transformed rows; `scale` applied on output.
-template <int S1, bool INV>
-__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+template <int S1, bool INV, int CLX = CL>
+__global__ void __launch_bounds__((YPlanT<S1, CLX>::THREADS))
 k_y_B(const cd* __restrict__ in, cd* __restrict__ out, int width, int pitch_in, int pitch_out, int S2, double scale,
       const cd* __restrict__ tw, int tw_step_N) {
-  typedef YPlan<S1> Y;
+  typedef YPlanT<S1, CLX> Y;
   constexpr int P = Y::P, T = Y::T;
-  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
-  const int col = blockIdx.x * CL + c;
+  const int c = threadIdx.x % CLX, j = threadIdx.x / CLX;
+  const int col = blockIdx.x * CLX + c;
   const int l1 = blockIdx.y;
   const bool ok = col < width;
   const int N = S1 * S2;

@@ -47,6 +47,7 @@ struct EqState {           // ETDRK4 state of one equation
 struct nq_ctx {
   nq_params p;
   int N = 0, S1 = 0, S2 = 0, nk = 0;
+  int CLy = CL;          // columns per workgroup of the y-side kernels: CL, or CLS with single-pass columns (S1 = N, S2 = 1)
   int WhG = 0;           // global half-spectrum width N/2+1
   int Wh = 0, Ph = 0;    // valid local half-spectrum columns and their pitch (== WhG, N/2+8 when P == 1)
   bool own_stream = true;
@@ -653,6 +654,7 @@ static void launch_A_s(nq_ctx* c, bool inv, const ArrayList& al, int n, int maxw
   else hipLaunchKernelGGL((k_y_A<S, false>), grid, block, Y::LDS_BYTES, c->stream, al, c->S1, c->tw, 1);
 }
 static void launch_A_list(nq_ctx* c, bool inv, const ArrayList& al, int n, int maxw) {
+  if (c->S2 == 1) return;                  // single-pass columns: the B sub-pass is the whole y transform
   ProfScope ps(c, PK_A);
   switch (c->S2) {
     case 8: launch_A_s<8>(c, inv, al, n, maxw); break;
@@ -696,20 +698,34 @@ static void launch_A_m(nq_ctx* c, bool inv, std::initializer_list<const MArr*> a
   for (int i = n; i < 6; ++i) { al.ptr[i] = nullptr; al.width[i] = 0; al.pitch[i] = 0; }
   if (maxw > 0) launch_A_list(c, inv, al, n, maxw);
 }
-template <int S>
+template <int S, int CLX = CL>
 static void launch_B_s(nq_ctx* c, bool inv, const cd* in, int pin, cd* out, int pout, int width, double scale) {
-  typedef YPlan<S> Y;
-  dim3 grid((width + CL - 1) / CL, c->S2), block(Y::THREADS);
-  if (inv) hipLaunchKernelGGL((k_y_B<S, true>), grid, block, Y::LDS_BYTES, c->stream, in, out, width, pin, pout, c->S2, scale, c->tw, 1);
-  else hipLaunchKernelGGL((k_y_B<S, false>), grid, block, Y::LDS_BYTES, c->stream, in, out, width, pin, pout, c->S2, scale, c->tw, 1);
+  typedef YPlanT<S, CLX> Y;
+  dim3 grid((width + CLX - 1) / CLX, c->S2), block(Y::THREADS);
+  if (inv) hipLaunchKernelGGL((k_y_B<S, true, CLX>), grid, block, Y::LDS_BYTES, c->stream, in, out, width, pin, pout, c->S2, scale, c->tw, 1);
+  else hipLaunchKernelGGL((k_y_B<S, false, CLX>), grid, block, Y::LDS_BYTES, c->stream, in, out, width, pin, pout, c->S2, scale, c->tw, 1);
 }
-static void launch_B_p(nq_ctx* c, bool inv, const cd* in, int pin, cd* out, int pout, int width, double scale) {
-  switch (c->S1) {
-    case 8: launch_B_s<8>(c, inv, in, pin, out, pout, width, scale); break;
-    case 16: launch_B_s<16>(c, inv, in, pin, out, pout, width, scale); break;
-    case 32: launch_B_s<32>(c, inv, in, pin, out, pout, width, scale); break;
-    case 64: launch_B_s<64>(c, inv, in, pin, out, pout, width, scale); break;
+// dispatch on the y plan: S1 = one radix of the two-pass transform (tiles of CL columns) or, with single-pass columns, N
+// itself (tiles of CLS columns for N >= 128)
+#define NQ_S1_SWITCH(c, CALL)                 \
+  if ((c)->CLy == CL) {                       \
+    switch ((c)->S1) {                        \
+      case 8: CALL(8, CL); break;             \
+      case 16: CALL(16, CL); break;           \
+      case 32: CALL(32, CL); break;           \
+      case 64: CALL(64, CL); break;           \
+    }                                         \
+  } else {                                    \
+    switch ((c)->S1) {                        \
+      case 128: CALL(128, CLS); break;        \
+      case 256: CALL(256, CLS); break;        \
+      case 512: CALL(512, CLS); break;        \
+    }                                         \
   }
+static void launch_B_p(nq_ctx* c, bool inv, const cd* in, int pin, cd* out, int pout, int width, double scale) {
+#define CALL_(s, clx) launch_B_s<s, clx>(c, inv, in, pin, out, pout, width, scale)
+  NQ_S1_SWITCH(c, CALL_)
+#undef CALL_
 }
 static void launch_B(nq_ctx* c, bool inv, const cd* in, cd* out, bool half, double scale) {
   const int width = half ? c->Wh : c->N, pitch = half ? c->Ph : c->N;
@@ -866,9 +882,9 @@ static EtdArrays etd_arrays(EqState& e, int stage, int* out_slot) {
   return ea;
 }
 
-template <int S>
+template <int S, int CLX>
 static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage, const MArr& huq, const MArr& hvq, bool q_equation) {
-  typedef YPlan<S> Y;
+  typedef YPlanT<S, CLX> Y;
   DualQ dq;
   EtdArrays eap = ea;
   memset(&dq, 0, sizeof(dq));
@@ -886,15 +902,15 @@ static void launch_sq_s(nq_ctx* c, const EtdArrays& ea, int stage, const MArr& h
   }
   const YGeom g = geom_half(c);
   if (g.width <= 0) return;
-  const dim3 grid((g.width + CL - 1) / CL, c->S2), block(Y::THREADS);
+  const dim3 grid((g.width + CLX - 1) / CLX, c->S2), block(Y::THREADS);
   EtdArrays ep;
   memset(&ep, 0, sizeof(ep));
   if (c->pass && q_equation) {             // the q equation itself, not the passive scalar's
     int slot = 0;
     ep = etd_arrays(c->qp, stage, &slot);
   }
-  if (c->dual) hipLaunchKernelGGL((k_s_q<S, true>), grid, block, Y::LDS_BYTES, c->stream, huq, hvq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq, ep);
-  else hipLaunchKernelGGL((k_s_q<S, false>), grid, block, Y::LDS_BYTES, c->stream, huq, hvq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq, ep);
+  if (c->dual) hipLaunchKernelGGL((k_s_q<S, true, CLX>), grid, block, Y::LDS_BYTES, c->stream, huq, hvq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq, ep);
+  else hipLaunchKernelGGL((k_s_q<S, false, CLX>), grid, block, Y::LDS_BYTES, c->stream, huq, hvq, eap, stage, g, c->kk, c->ll, c->tw, 1, dq, ep);
 }
 static BudgetW budget_w(nq_ctx* c, double* part, const cd* y_start) {
   BudgetW bw;
@@ -905,22 +921,22 @@ static BudgetW budget_w(nq_ctx* c, double* part, const cd* y_start) {
   bw.muw = c->p.muw;
   return bw;
 }
-template <int S>
+template <int S, int CLX>
 static void launch_sphi_s(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_start, const MArr& ophi, const MArr& ophiy) {
-  typedef YPlan<S> Y;
+  typedef YPlanT<S, CLX> Y;
   BudgetW bw = budget_w(c, c->partW + (size_t)stage * c->nww * NQ_PARTW, y_start);
   const cd* jpass = c->ybj ? nullptr : c->mUq.ys + c->mUq.W;     // YBJModel.jacobian_psi_phi keeps [0,0] (YBJModel.py:123-133)
-  hipLaunchKernelGGL((k_s_phi<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mW, jpass, c->mUq.pitch, ea, stage, geom_full(c), ophi, ophiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
+  hipLaunchKernelGGL((k_s_phi<S, CLX>), dim3(c->Wf / CLX, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mW, jpass, c->mUq.pitch, ea, stage, geom_full(c), ophi, ophiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
-template <int S>
+template <int S, int CLX>
 static void launch_emit_phi_s(nq_ctx* c, const cd* phih) {
-  typedef YPlan<S> Y;
+  typedef YPlanT<S, CLX> Y;
   BudgetW bw = budget_w(c, c->part0W, phih);
-  hipLaunchKernelGGL((k_s_emit_phi<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, phih, geom_full(c), c->mPhi, c->mPhiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
+  hipLaunchKernelGGL((k_s_emit_phi<S, CLX>), dim3(c->Wf / CLX, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, phih, geom_full(c), c->mPhi, c->mPhiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
-template <int S, int MODE>
+template <int S, int MODE, int CLX>
 static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud, const cd* c_hat = nullptr) {
-  typedef YPlan<S> Y;
+  typedef YPlanT<S, CLX> Y;
   // the second copy lives in the same rotating slot as qh
   const cd* qh_minus = nullptr;
   if (c->dual)
@@ -928,21 +944,14 @@ static void launch_invert_sm(nq_ctx* c, const cd* qh, bool store_aux, double* pa
       if (c->q.y[i] == qh) qh_minus = c->q2.y[i];
   const YGeom g = geom_half(c);
   if (g.width <= 0) return;
-  hipLaunchKernelGGL((k_s_invert<S, MODE>), dim3((g.width + CL - 1) / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mA, c->mB, qh, c->filt_h, c->mU, c->mP, c->mQ, c->mQw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, g, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->tw, 1, c->bud ? part : nullptr, q_bud, qh_minus, c->dual ? c->filt_m : nullptr, c_hat);
+  hipLaunchKernelGGL((k_s_invert<S, MODE, CLX>), dim3((g.width + CLX - 1) / CLX, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mA, c->mB, qh, c->filt_h, c->mU, c->mP, c->mQ, c->mQw, store_aux ? c->qwh : nullptr, store_aux ? c->ph : nullptr, g, 1.0 / ((double)c->N * c->N), c->p.f, c->kk, c->ll, c->tw, 1, c->bud ? part : nullptr, q_bud, qh_minus, c->dual ? c->filt_m : nullptr, c_hat);
 }
-#define NQ_S1_SWITCH(c, CALL)         \
-  switch ((c)->S1) {                  \
-    case 8: CALL(8); break;           \
-    case 16: CALL(16); break;         \
-    case 32: CALL(32); break;         \
-    case 64: CALL(64); break;         \
-  }
 
 static void launch_sq(nq_ctx* c, const EtdArrays& ea, int stage, const MArr* huq = nullptr, const MArr* hvq = nullptr) {
   ProfScope ps(c, PK_SQ);
   const MArr& a1 = huq ? *huq : c->mUq;
   const MArr& a2 = hvq ? *hvq : c->mVq;
-#define CALL_(s) launch_sq_s<s>(c, ea, stage, a1, a2, huq == nullptr)
+#define CALL_(s, clx) launch_sq_s<s, clx>(c, ea, stage, a1, a2, huq == nullptr)
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
@@ -951,27 +960,27 @@ static void launch_sphi(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y_s
   ProfScope ps(c, PK_SPHI);
   const MArr& o1 = ophi ? *ophi : c->mPhi;
   const MArr& o2 = ophiy ? *ophiy : c->mPhiy;
-#define CALL_(s) launch_sphi_s<s>(c, ea, stage, y_start, o1, o2)
+#define CALL_(s, clx) launch_sphi_s<s, clx>(c, ea, stage, y_start, o1, o2)
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
 static void launch_emit_phi(nq_ctx* c, const cd* phih) {
-#define CALL_(s) launch_emit_phi_s<s>(c, phih)
+#define CALL_(s, clx) launch_emit_phi_s<s, clx>(c, phih)
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
 static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux, double* part, const cd* q_bud, const cd* c_hat = nullptr) {
   ProfScope ps(c, PK_INVERT);
   if (c->passive) {
-#define CALL_(s) launch_invert_sm<s, MODE_QGC>(c, qh, store_aux, part, q_bud, c_hat)
+#define CALL_(s, clx) launch_invert_sm<s, MODE_QGC, clx>(c, qh, store_aux, part, q_bud, c_hat)
     NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
   } else if (c->p.model == NQ_MODEL_COUPLED) {
-#define CALL_(s) launch_invert_sm<s, MODE_COUPLED>(c, qh, store_aux, part, q_bud)
+#define CALL_(s, clx) launch_invert_sm<s, MODE_COUPLED, clx>(c, qh, store_aux, part, q_bud)
     NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
   } else {
-#define CALL_(s) launch_invert_sm<s, MODE_UNCOUPLED>(c, qh, store_aux, part, q_bud)
+#define CALL_(s, clx) launch_invert_sm<s, MODE_UNCOUPLED, clx>(c, qh, store_aux, part, q_bud)
     NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
   }
@@ -1545,14 +1554,14 @@ static int slab_settle(std::vector<nq_ctx*>& grp) {
 
 // ---------------------------------------------------------------------------------------------
 // diagnostics tick launches
-template <int S>
+template <int S, int CLX>
 static void launch_project_s(nq_ctx* c, double* part) {
-  typedef YPlan<S> Y;
-  hipLaunchKernelGGL((k_s_project<S>), dim3(c->Wf / CL, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mW,
+  typedef YPlanT<S, CLX> Y;
+  hipLaunchKernelGGL((k_s_project<S, CLX>), dim3(c->Wf / CLX, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mW,
                      (const cd*)c->w.y[c->w.cur], geom_full(c), c->kk, c->ll, c->tw, 1, c->p.nu4w, c->p.nuw, c->p.muw, part);
 }
 static void launch_project(nq_ctx* c, double* part) {
-#define CALL_(s) launch_project_s<s>(c, part)
+#define CALL_(s, clx) launch_project_s<s, clx>(c, part)
   NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
 }
@@ -1676,6 +1685,18 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
   c->N = p->nx;
   c->S1 = S1;
   c->S2 = S2;
+  c->CLy = CL;
+  {
+    // Small grids on one rank: SINGLE-PASS columns (a tile of whole columns per workgroup, no A sub-pass).  A step of these
+    // grids is a chain of dependent 5-microsecond kernels: what counts is how many there are.  NIWQG_AMD_SINGLE_PASS=0 keeps
+    // the two-pass tiles (A/B measurements; slab contexts always use them).
+    const char* e = getenv("NIWQG_AMD_SINGLE_PASS");
+    if (P == 1 && p->nx <= 512 && !(e && atoi(e) == 0)) {
+      c->S1 = p->nx;
+      c->S2 = 1;
+      c->CLy = p->nx >= 128 ? CLS : CL;
+    }
+  }
   c->P = P;
   c->rank = rank;
   c->Nloc = sg.Nloc;
@@ -1900,8 +1921,8 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
       c->mGy = make_marr(sg, c->Gs, gsy, 1, 1, false);
     }
     if (c->bud) {
-      c->nww = (c->Wf / CL) * c->S2;
-      c->nwq = ((c->Wh + CL - 1) / CL) * c->S2;
+      c->nww = (c->Wf / c->CLy) * c->S2;
+      c->nwq = ((c->Wh + c->CLy - 1) / c->CLy) * c->S2;
       if (c->nwq < 1) c->nwq = 1;
       ALLOC(c, c->partQ, (size_t)4 * c->nwq * (sg.passive ? 6 : 3));
       ALLOC(c, c->part0Q, (size_t)c->nwq * (sg.passive ? 6 : 3));
@@ -2543,7 +2564,7 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
   const bool waves = c0->kernel_family, coupled = c0->p.model == NQ_MODEL_COUPLED;
   for (nq_ctx* x : grp) {
     HIPCHK(x, hipSetDevice(x->device));
-    const int nxb = xdiag_blocks(x), nww = (x->Wf / CL) * x->S2;
+    const int nxb = xdiag_blocks(x), nww = (x->Wf / x->CLy) * x->S2;
     if (!x->diag_part) {
       size_t need = (size_t)NB * 9;
       if ((size_t)nxb * 8 > need) need = (size_t)nxb * 8;
@@ -2603,8 +2624,8 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
       launch_A_m(x, false, {&x->mUc, &x->mVc});
       const YGeom g = geom_half(x);
       if (g.width <= 0) continue;
-      const int nwc = ((g.width + CL - 1) / CL) * x->S2;
-#define CALL_(sz) hipLaunchKernelGGL((k_s_project_c<sz>), dim3((g.width + CL - 1) / CL, x->S2), dim3(YPlan<sz>::THREADS), YPlan<sz>::LDS_BYTES, x->stream, x->mUc, x->mVc, x->cq.y[x->cq.cur], g, x->kk, x->ll, x->tw, 1, x->diag_part)
+      const int nwc = ((g.width + x->CLy - 1) / x->CLy) * x->S2;
+#define CALL_(sz, clx) hipLaunchKernelGGL((k_s_project_c<sz, clx>), dim3((g.width + clx - 1) / clx, x->S2), dim3((YPlanT<sz, clx>::THREADS)), (YPlanT<sz, clx>::LDS_BYTES), x->stream, x->mUc, x->mVc, x->cq.y[x->cq.cur], g, x->kk, x->ll, x->tw, 1, x->diag_part)
       NQ_S1_SWITCH(x, CALL_)
 #undef CALL_
       hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, nwc, 1, 1, x->diag_out + 20);
@@ -2628,7 +2649,7 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
     for (nq_ctx* x : grp) launch_products(x, which == 0 ? 1.0 : 0.0, which == 0 ? 0.0 : 1.0);
     SLABTRY(exchange_now(grp, 0, true));
     for (nq_ctx* x : grp) {
-      const int nww = (x->Wf / CL) * x->S2;
+      const int nww = (x->Wf / x->CLy) * x->S2;
       launch_A_m(x, false, {&x->mW});
       launch_project(x, x->diag_part);
       hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, nww, 4, 4, x->diag_out + 24 + 4 * which);
@@ -3122,7 +3143,7 @@ int nq_diagnostics(nq_ctx* c, double* out) {
   const double M = (double)N * N;
   const bool waves = c->kernel_family;
   if (waves && !c->have_phi) NQ_FAIL(c, -4, "nq_diagnostics: set_phi has not been called");
-  const int nxb = xdiag_blocks(c), nww = (c->Wf / CL) * c->S2;
+  const int nxb = xdiag_blocks(c), nww = (c->Wf / c->CLy) * c->S2;
   if (!c->diag_part) {
     size_t need = (size_t)NB * 9;
     if ((size_t)nxb * 8 > need) need = (size_t)nxb * 8;
@@ -3171,8 +3192,8 @@ int nq_diagnostics(nq_ctx* c, double* out) {
     launch_products(c);
     launch_A_m(c, false, {&c->mUc, &c->mVc});
     const YGeom g = geom_half(c);
-    const int nwc = ((g.width + CL - 1) / CL) * c->S2;
-#define CALL_(sz) hipLaunchKernelGGL((k_s_project_c<sz>), dim3((g.width + CL - 1) / CL, c->S2), dim3(YPlan<sz>::THREADS), YPlan<sz>::LDS_BYTES, c->stream, c->mUc, c->mVc, ch, g, c->kk, c->ll, c->tw, 1, c->diag_part)
+    const int nwc = ((g.width + c->CLy - 1) / c->CLy) * c->S2;
+#define CALL_(sz, clx) hipLaunchKernelGGL((k_s_project_c<sz, clx>), dim3((g.width + clx - 1) / clx, c->S2), dim3((YPlanT<sz, clx>::THREADS)), (YPlanT<sz, clx>::LDS_BYTES), c->stream, c->mUc, c->mVc, ch, g, c->kk, c->ll, c->tw, 1, c->diag_part)
     NQ_S1_SWITCH(c, CALL_)
 #undef CALL_
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, nwc, 1, 1, d + 20);

@@ -1061,14 +1061,14 @@ k_x_diag(MArr Mq, MArr Mqw, MArr Mphi, const cd* __restrict__ tw, const double* 
 // a = B-fft of Hw (Hw already went through the A sub-pass).  part[workgroup][4] =
 //   sum Re(conj(lap_h) a), sum Im(conj(lap_h) a), sum Re(conj(diss_h) a), sum Im(conj(diss_h) a)
 // with lap_h = -wv2 phih, diss_h = -(nu4w wv4 + nuw wv2 + muw) phih: gamma1, gamma2, xi1, xi2 of ref Kernel.py:691-700.
-template <int S1>
-__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+template <int S1, int CLX = CL>
+__global__ void __launch_bounds__((YPlanT<S1, CLX>::THREADS))
 k_s_project(MArr Hw, const cd* __restrict__ phih, YGeom g, const double* __restrict__ kk, const double* __restrict__ ll,
             const cd* __restrict__ tw, int tw_step_N, double nu4w, double nuw, double muw, double* __restrict__ part) {
-  typedef YPlan<S1> Y;
+  typedef YPlanT<S1, CLX> Y;
   constexpr int P = Y::P, T = Y::T;
-  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
-  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int c = threadIdx.x % CLX, j = threadIdx.x / CLX;
+  const int k = blockIdx.x * CLX + c, l1 = blockIdx.y;
   const int kg = g.k0 + k, S2 = g.S2;
   const int N = S1 * S2;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
@@ -1100,14 +1100,14 @@ k_s_project(MArr Hw, const cd* __restrict__ phih, YGeom g, const double* __restr
 // ---- diagnostics tick of QGModel's passive scalar: Gamma_c = 2 mean(lap c * J(psi, c)) (ref QGModel.py:727-731) by Parseval ----
 // part[workgroup] = sum over the tile of w * Re(conj(-wv2 c-hat) * (i k F[u c] + i l F[v c])), w = 1 on the two self-mirrored
 // columns, 2 elsewhere; Huc, Hvc already went through the A sub-pass.
-template <int S1>
-__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+template <int S1, int CLX = CL>
+__global__ void __launch_bounds__((YPlanT<S1, CLX>::THREADS))
 k_s_project_c(MArr Huc, MArr Hvc, const cd* __restrict__ ch, YGeom g, const double* __restrict__ kk,
               const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N, double* __restrict__ part) {
-  typedef YPlan<S1> Y;
+  typedef YPlanT<S1, CLX> Y;
   constexpr int P = Y::P, T = Y::T;
-  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
-  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int c = threadIdx.x % CLX, j = threadIdx.x / CLX;
+  const int k = blockIdx.x * CLX + c, l1 = blockIdx.y;
   const int kg = g.k0 + k, S2 = g.S2;
   const bool ok = k < g.width;
   const int N = S1 * S2;
@@ -1220,14 +1220,14 @@ struct DualQ {
 };
 
 // ---- Sq: nonlinear term + stage update of q-hat on the half spectrum --------------------------------
-template <int S1, bool DUAL>
-__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+template <int S1, bool DUAL, int CLX = CL>
+__global__ void __launch_bounds__((YPlanT<S1, CLX>::THREADS))
 k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __restrict__ kk,
       const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N, DualQ dq, EtdArrays ep) {
-  typedef YPlan<S1> Y;
+  typedef YPlanT<S1, CLX> Y;
   constexpr int P = Y::P, T = Y::T;
-  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
-  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int c = threadIdx.x % CLX, j = threadIdx.x / CLX;
+  const int k = blockIdx.x * CLX + c, l1 = blockIdx.y;
   const int kg = g.k0 + k, S2 = g.S2, kernel_family = g.kernel_family;
   const bool ok = k < g.width;
   const int N = S1 * S2;
@@ -1318,15 +1318,15 @@ __device__ __forceinline__ void phi_outputs(const cd (&y)[P], cd (&a)[P], cd (&b
   }
 }
 
-template <int S1>
-__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+template <int S1, int CLX = CL>
+__global__ void __launch_bounds__((YPlanT<S1, CLX>::THREADS))
 k_s_phi(MArr Hw, const cd* __restrict__ jpass, int jpitch, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphiy,
         double invM, const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw,
         int tw_step_N, BudgetW bw) {
-  typedef YPlan<S1> Y;
+  typedef YPlanT<S1, CLX> Y;
   constexpr int P = Y::P, T = Y::T;
-  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
-  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int c = threadIdx.x % CLX, j = threadIdx.x / CLX;
+  const int k = blockIdx.x * CLX + c, l1 = blockIdx.y;
   const int kg = g.k0 + k, S2 = g.S2;
   const int N = S1 * S2;
   const bool bud = bw.part != nullptr;
@@ -1386,15 +1386,15 @@ k_s_phi(MArr Hw, const cd* __restrict__ jpass, int jpitch, EtdArrays ea, int sta
 }
 
 // emit-only variant (set_phi): phih -> Hphi, Hphiy (+ sums with budgets)
-template <int S1>
-__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+template <int S1, int CLX = CL>
+__global__ void __launch_bounds__((YPlanT<S1, CLX>::THREADS))
 k_s_emit_phi(const cd* __restrict__ phih, YGeom g, MArr Hphi, MArr Hphiy, double invM,
              const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N,
              BudgetW bw) {
-  typedef YPlan<S1> Y;
+  typedef YPlanT<S1, CLX> Y;
   constexpr int P = Y::P, T = Y::T;
-  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
-  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int c = threadIdx.x % CLX, j = threadIdx.x / CLX;
+  const int k = blockIdx.x * CLX + c, l1 = blockIdx.y;
   const int kg = g.k0 + k, S2 = g.S2;
   const int N = S1 * S2;
   const bool bud = bw.part != nullptr;
@@ -1426,8 +1426,8 @@ k_s_emit_phi(const cd* __restrict__ phih, YGeom g, MArr Hphi, MArr Hphiy, double
 // ---- Si: the psi inversion on the half spectrum + first half of the four inverse y transforms -----
 // MODE_COUPLED: ref CoupledModel.py:75-97 with ph = wv2i*(qwh - qh) instead of fft(ifft(.).real)
 // (oracle/reduced_pipeline.py proves the equivalence).  Other modes: ph = -wv2i*qh (Ha, Hb unused).
-template <int S1, int MODE>
-__global__ void __launch_bounds__(YPlan<S1>::THREADS)
+template <int S1, int MODE, int CLX = CL>
+__global__ void __launch_bounds__((YPlanT<S1, CLX>::THREADS))
 k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict__ filt, MArr Hu, MArr Hp, MArr Hq,
            MArr Hqw, cd* __restrict__ qwh_out, cd* __restrict__ ph_out, YGeom g, double invM, double f,
            const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw, int tw_step_N,
@@ -1438,10 +1438,10 @@ k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict
   // bud_part: [workgroup][3] Parseval sums for ep_psi (ref Kernel.py:635-640 / QGModel.py:588-593):
   //   sum w*wv4*Re(qb conj psi), sum w*wv2*Re(q conj psi), sum w*Re(qb conj psi); qb = q_bud (QGModel's
   //   stale q, QGModel.py:401) or q; w = 1 on the self-mirrored columns, 2 elsewhere.
-  typedef YPlan<S1> Y;
+  typedef YPlanT<S1, CLX> Y;
   constexpr int P = Y::P, T = Y::T;
-  const int c = threadIdx.x % CL, j = threadIdx.x / CL;
-  const int k = blockIdx.x * CL + c, l1 = blockIdx.y;
+  const int c = threadIdx.x % CLX, j = threadIdx.x / CLX;
+  const int k = blockIdx.x * CLX + c, l1 = blockIdx.y;
   const int kg = g.k0 + k, S2 = g.S2, kernel_family = g.kernel_family;
   const bool ok = k < g.width;
   const int N = S1 * S2;

@@ -149,6 +149,8 @@ int nq_irfft2(nq_ctx* ctx, const double* in_cplx, double* out_real);
  * nq_products_uq_vq has no reference counterpart: the two transforms fft(u q), fft(v q) themselves on k = 0..nx/2,
  *                        cplx (2, ny, nx/2+1) = 4*ny*(nx/2+1) doubles (tests; callers with their own flux forms). */
 int nq_jacobian_psi_q(nq_ctx* ctx, double* out_cplx);
+/* QGModel with its passive scalar: ik*fft(u c) + il*fft(v c), (ny, nx/2+1) cplx (QGModel.py:483-495), u, v of the current psi */
+int nq_jacobian_psi_c(nq_ctx* ctx, double* out_cplx);
 int nq_jacobian_psi_phi(nq_ctx* ctx, double* out_cplx);
 int nq_jacobian_phic_phi(nq_ctx* ctx, double* out_cplx);
 int nq_products_uq_vq(nq_ctx* ctx, double* out_cplx2);

@@ -174,6 +174,8 @@ class Model(object):
             # the step evaluated its fourth stage, not of the new state (QGModel.py:375 vs :396)
             ph4 = -self.wv2i * self._ctx.field(_lib.F_QH_STAGE4)
             u, v = self.ifft(-self.il * ph4), self.ifft(self.ik * ph4)
+        elif hasattr(self._ctx, "jacobian_psi_c"):
+            return self._ctx.jacobian_psi_c()          # u, v of the current psi: the row kernel's own products, as in a step
         else:
             u, v = self.u, self.v
         return self.ik * self.fft(u * self.c) + self.il * self.fft(v * self.c)

@@ -27,7 +27,7 @@ COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
 
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
            "nq_step", "nq_sync", "nq_get_field", "nq_get_qh_passenger", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
-           "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_diagnostics",
+           "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_c", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_diagnostics",
            "nq_stream_copy_gbs", "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
            "nq_reduce_buffer", "nq_reduce_read", "nq_reduce_write", "nq_device_bytes", "nq_stream",
@@ -87,7 +87,7 @@ def lib():
     L.nq_last_error.restype = ctypes.c_char_p
     for name in ("nq_destroy", "nq_invert", "nq_refresh_grad_phi", "nq_sync", "nq_timer_start"):
         getattr(L, name).argtypes = [vp]
-    for name in ("nq_set_q", "nq_set_c", "nq_set_phi", "nq_jacobian_psi_q", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi",
+    for name in ("nq_set_q", "nq_set_c", "nq_set_phi", "nq_jacobian_psi_q", "nq_jacobian_psi_c", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi",
                  "nq_products_uq_vq", "nq_refraction", "nq_diagnostics"):
         getattr(L, name).argtypes = [vp, dp]
     for name in ("nq_fft2", "nq_ifft2", "nq_rfft2", "nq_irfft2"):
@@ -318,6 +318,12 @@ class Context:
         """Kernel family: (ny, nx) with [0,0] = 0 (Kernel.py:471-486); QGModel: (ny, nx/2+1) (QGModel.py:469-481)"""
         out = np.empty((self.nx, self.nx if self.model != QG else self.nx // 2 + 1), np.complex128)
         self._chk(self.L.nq_jacobian_psi_q(self.h, _dptr(out.view(np.float64))), "nq_jacobian_psi_q")
+        return out
+
+    def jacobian_psi_c(self):
+        """QGModel's passive scalar: ik*fft(u c) + il*fft(v c), (ny, nx/2+1) (QGModel.py:483-495), through the row kernel"""
+        out = np.empty((self.nx, self.nx // 2 + 1), np.complex128)
+        self._chk(self.L.nq_jacobian_psi_c(self.h, _dptr(out.view(np.float64))), "nq_jacobian_psi_c")
         return out
 
     def products_uq_vq(self):

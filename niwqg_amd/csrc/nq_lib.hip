@@ -3109,6 +3109,22 @@ int nq_jacobian_psi_q(nq_ctx* c, double* out_cplx) {
   HIPCHK(c, hipMemcpyAsync(out_cplx, c->scr_f0, sizeof(cd) * (size_t)N * wout, hipMemcpyDeviceToHost, c->stream));
   return nq_sync(c);
 }
+// QGModel.jacobian_psi_c (ref QGModel.py:483-495): ik*fft(u c) + il*fft(v c) on (ny, nx/2+1), with u, v of the current psi;
+// formed by the row kernel exactly as inside a step (the scalar rides paired with q, its products leave as a second pair)
+int nq_jacobian_psi_c(nq_ctx* c, double* out_cplx) {
+  NQ_SINGLE_RANK(c, "nq_jacobian_psi_c");
+  if (!out_cplx) NQ_FAIL(c, -1, "nq_jacobian_psi_c: null output");
+  if (!c->passive) NQ_FAIL(c, -4, "nq_jacobian_psi_c: this context has no passive scalar");
+  HIPCHK(c, hipSetDevice(c->device));
+  launch_products(c);
+  launch_A_m(c, false, {&c->mUc, &c->mVc});
+  launch_B_p(c, false, c->mUc.ys, c->mUc.pitch, c->scr_h0, c->Ph, c->Wh, 1.0);
+  launch_B_p(c, false, c->mVc.ys, c->mVc.pitch, c->scr_h1, c->Ph, c->Wh, 1.0);
+  const int N = c->N, wout = c->WhG;
+  hipLaunchKernelGGL(k_expand_half, dim3((wout + 63) / 64, N), dim3(64), 0, c->stream, (const cd*)c->scr_h0, (const cd*)c->scr_h1, c->scr_f0, N, c->Ph, wout, 1, c->kk, c->ll);
+  HIPCHK(c, hipMemcpyAsync(out_cplx, c->scr_f0, sizeof(cd) * (size_t)N * wout, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
+}
 // the two transforms themselves, (2, ny, nx/2+1): fft(u q) then fft(v q) restricted to k = 0..nx/2 (no reference
 // counterpart: exported for tests and for callers that assemble their own flux forms)
 int nq_products_uq_vq(nq_ctx* c, double* out_cplx) {

@@ -339,3 +339,43 @@ def test_rough_coupled_ten_steps_against_the_reference_itself_at_2048(golden):
         for k, v in e.items():
             assert v < 1e-10, (n, k, v)
         assert np.allclose([m.Ke, m.Pw, m.Kw], g[t + "budgets"], rtol=1e-8)
+
+
+def test_qg_passive_scalar_row_kernel_8192_on_a_full_spectrum_against_numpy():
+    """QGModel with its passive scalar at 8192^2 (k_x_products_eo<8192, MODE_QGC>: q and c as ONE packed transform per parity, c
+    rescaled per row by a power of two, the products u c, v c leaving as a second packed pair): white-noise q (1e-5) and c (O(1)),
+    jacobian_psi_q and jacobian_psi_c (ref QGModel.py:469-495) against the reference's formulas evaluated with pocketfft."""
+    import scipy.fft
+    import niwqg_amd
+    import bench
+    nx = 8192
+    kw = bench.c3_kwargs(nx, "qg")
+    m = niwqg_amd.QGModel.Model(passive_scalar=True, nu4c=kw["nu4"], **kw)
+    rng = np.random.default_rng(31)
+    q0 = 1e-5 * rng.standard_normal((nx, nx))
+    c0 = 1.0 + rng.standard_normal((nx, nx))
+    m.set_q(q0)
+    m.set_c(c0)
+    kk, ll = np.asarray(m.kk).ravel(), np.asarray(m.ll).ravel()
+    ik, il = 1j * kk[None, :], 1j * ll[:, None]
+    wv2 = kk[None, :] ** 2 + ll[:, None] ** 2
+    wv2i = np.zeros_like(wv2)
+    wv2i[wv2 != 0] = 1.0 / wv2[wv2 != 0]
+
+    def F(a):
+        return scipy.fft.rfft2(a, workers=NW)
+
+    def Fi(a):
+        return scipy.fft.irfft2(a, s=(nx, nx), workers=NW)
+
+    ph = -wv2i * F(q0)
+    u, v = Fi(-il * ph), Fi(ik * ph)
+    jq = ik * F(u * q0) + il * F(v * q0)
+    e = rel(m.jacobian_psi_q(), jq)
+    print("8192^2 QG jacobian_psi_q %.2e" % e)
+    assert e < 1e-12
+    del jq
+    jc = ik * F(u * c0) + il * F(v * c0)
+    e = rel(m.jacobian_psi_c(), jc)
+    print("8192^2 QG jacobian_psi_c %.2e" % e)
+    assert e < 1e-12

@@ -379,3 +379,72 @@ def test_qg_passive_scalar_row_kernel_8192_on_a_full_spectrum_against_numpy():
     e = rel(m.jacobian_psi_c(), jc)
     print("8192^2 QG jacobian_psi_c %.2e" % e)
     assert e < 1e-12
+
+
+def test_uncoupled_and_qg_row_kernels_8192_on_a_full_spectrum_against_numpy():
+    """The other instantiations of the even/odd row kernel at 8192^2 on white noise, against the reference's formulas evaluated with
+    pocketfft: UnCoupledModel (k_x_products_eo<8192, MODE_UNCOUPLED>: q alone in its transform, phix / phiy from the rows as last
+    refreshed, phi's row read separately; ref Kernel.py:457-486, :332, UnCoupledModel.py:54-64) and QGModel without its passive scalar
+    (MODE_QG; ref QGModel.py:469-481)."""
+    import scipy.fft
+    import niwqg_amd
+    import bench
+    nx = 8192
+    rng = np.random.default_rng(41)
+    q0 = 1e-5 * rng.standard_normal((nx, nx))
+    # ---- QGModel, rfft2 semantics
+    m = niwqg_amd.QGModel.Model(**bench.c3_kwargs(nx, "qg"))
+    m.set_q(q0)
+    kk, ll = np.asarray(m.kk).ravel(), np.asarray(m.ll).ravel()
+    ik, il = 1j * kk[None, :], 1j * ll[:, None]
+    wv2 = kk[None, :] ** 2 + ll[:, None] ** 2
+    wv2i = np.zeros_like(wv2)
+    wv2i[wv2 != 0] = 1.0 / wv2[wv2 != 0]
+    ph = -wv2i * scipy.fft.rfft2(q0, workers=NW)
+    u = scipy.fft.irfft2(-il * ph, s=(nx, nx), workers=NW)
+    v = scipy.fft.irfft2(ik * ph, s=(nx, nx), workers=NW)
+    jq = ik * scipy.fft.rfft2(u * q0, workers=NW) + il * scipy.fft.rfft2(v * q0, workers=NW)
+    e = rel(m.jacobian_psi_q(), jq)
+    print("8192^2 QGModel (no scalar) jacobian_psi_q %.2e" % e)
+    assert e < 1e-12
+    m._ctx.close()
+    del m, jq, ph, u, v, wv2, wv2i
+    # ---- UnCoupledModel, c2c semantics with .real projections
+    kw = rough_kwargs(nx)
+    m = niwqg_amd.UnCoupledModel.Model(**kw)
+    phi0 = 0.05 * (rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx)))
+    m.set_q(q0)
+    m.set_phi(phi0)            # refreshes phix, phiy (Kernel.py:548-551 -> _calc_pe_niw)
+
+    def F(a):
+        return scipy.fft.fft2(a, workers=NW)
+
+    def Fi(a):
+        return scipy.fft.ifft2(a, workers=NW)
+
+    kk = np.asarray(m.kk).ravel()
+    ik, il = 1j * kk[None, :], 1j * np.asarray(m.ll).ravel()[:, None]
+    wv2 = kk[None, :] ** 2 + np.asarray(m.ll).ravel()[:, None] ** 2
+    wv2i = np.zeros_like(wv2)
+    wv2i[wv2 != 0] = 1.0 / wv2[wv2 != 0]
+    ph = F(Fi(-(wv2i * F(q0))).real)
+    del wv2, wv2i
+    u, v = Fi(-il * ph).real, Fi(ik * ph).real
+    del ph
+    jq = ik * F(u * q0) + il * F(v * q0)
+    jq[0, 0] = 0
+    e = rel(m.jacobian_psi_q(), jq)
+    print("8192^2 UnCoupledModel jacobian_psi_q %.2e" % e)
+    assert e < 1e-12
+    del jq
+    phih = F(phi0)
+    jp = F(u * Fi(ik * phih) + v * Fi(il * phih))
+    jp[0, 0] = 0
+    del phih, u, v
+    e = rel(m.jacobian_psi_phi(), jp)
+    print("8192^2 UnCoupledModel jacobian_psi_phi %.2e" % e)
+    assert e < 1e-12
+    del jp
+    e = rel(m._ctx.refraction(), F(phi0 * q0))         # q_psi = q without wave feedback (Kernel.py:492-501)
+    print("8192^2 UnCoupledModel refraction %.2e" % e)
+    assert e < 1e-12

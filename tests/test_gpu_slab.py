@@ -287,6 +287,11 @@ def test_bench_contract_with_two_ranks_rehearsed_over_gloo(model):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["config"]["host_dispatches_per_step"] <= 1.0 and d["config"]["exchange_GB_sent_per_rank_per_step"] > 0
+    # the per-step breakdown a first real multi-GPU run reads (HIP events on the two streams of rank 0)
+    for key in ("compute_ms_per_step", "exposed_exchange_ms_per_step", "exchange_ms_per_step", "allreduce_ms_per_step"):
+        assert key in d["config"] and d["config"][key] is not None, key
+    assert d["config"]["compute_ms_per_step"] > 0
+    assert d["roofline"]["peak_measured_copy"] > 1000.0           # the stream-copy denominator, GB/s
     assert "slab x2" in d["config"]["parallelism"]        # no silent fallback exists any more: a failed slab run exits non-zero
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])

@@ -4,11 +4,8 @@ Drop-in for ``niwqg.CoupledModel.Model`` (ref: niwqg/CoupledModel.py:5-152): sam
 keywords, ``set_q``/``set_phi``/``run`` and attributes; the wave-PV inversion and the ETDRK4 stages
 run in HIP kernels (niwqg_amd/csrc/nq_step.hpp: k_x_wavepv, k_s_invert, k_x_products, k_s_q, k_s_phi).
 """
-import numpy as np
-
 from . import Kernel, _lib
 from .Diagnostics import add_diagnostic
-from .Kernel import hermitian_full
 
 
 class Model(Kernel.Kernel):

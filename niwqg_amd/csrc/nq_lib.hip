@@ -537,7 +537,7 @@ __global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums
     for (int q = 0; q < 4; ++q) sw[s + 1][q] = sums[s * 11 + 3 + q];
     for (int q = 0; q < 2; ++q) sj[s][q] = sums[s * 11 + 7 + q];
   }
-  const double M = b.M, M2 = b.M * b.M;
+  const double M2 = b.M * b.M;
   if (!qg) {
     for (int q = 0; q < 3; ++q) sq[0][q] = b.carryQ[q];
     for (int q = 0; q < 4; ++q) sw[0][q] = b.carryW[q];
@@ -1161,7 +1161,7 @@ struct RcclApi {
   const char* (*GetErrorString)(int) = nullptr;
 };
 static RcclApi g_rccl;
-static const int kNcclDouble = 8, kNcclSum = 0, kNcclMax = 2;
+static const int kNcclDouble = 8, kNcclSum = 0;
 static bool rccl_load(std::string* err) {
   if (g_rccl.handle) return true;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};

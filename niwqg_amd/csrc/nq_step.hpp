@@ -631,12 +631,6 @@ __device__ __forceinline__ void eo_unpack_pair_store2(const cd (&e)[P], cd (&o)[
   wg_barrier();
 }
 
-#ifndef NQ_EO_PREFETCH_ROW
-#define NQ_EO_PREFETCH_ROW 0
-#endif
-#ifndef NQ_EO_HOLD_PHI
-#define NQ_EO_HOLD_PHI 1     // 1: the coupled model keeps phi's raw row in registers from the phix phase to the phi phase
-#endif
 // Phase boundary of the even/odd kernels: NQ_PHASE_FENCE plus a laundering of j, c and w^j.  Everything derived from
 // them (the eight w^k, kk[k], kk[k + M], row addresses) would otherwise be computed once and kept live across the whole
 // row by common-subexpression elimination: ~60 VGPRs that the two-problem live state cannot spare (500 B/lane of scratch).
@@ -797,9 +791,6 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(MODE == MODE_COUPLED ? Mphi : Mgx, row), j);
       NQ_EO_FENCE();
       eo_fold_regs<M, P, T>(we, x1, x2, j, 0, wj, kk, true);
-#if !NQ_EO_HOLD_PHI
-      eo_fold_regs<M, P, T>(wo, x1, x2, j, 1, wj, kk, true);
-#endif
       NQ_EO_FENCE();
       F::template run<true>(we, j, c, lds, twr);
 #pragma unroll
@@ -810,10 +801,8 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
         je[t] = cscale(je[t], cj);
       }
       NQ_EO_FENCE();
-#if NQ_EO_HOLD_PHI
       eo_fold_regs<M, P, T>(wo, x1, x2, j, 1, wj, kk, true);
       NQ_EO_FENCE();
-#endif
       F::template run<true>(wo, j, c, lds, twr);
 #pragma unroll
       for (int t = 0; t < P; ++t) {
@@ -824,11 +813,9 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       }
       // ---- phase 5: phi, the refraction factor: + i cr phi q_psi
       NQ_EO_FENCE();
-#if NQ_EO_HOLD_PHI
+      // Coupled: phi's raw row is still in x1, x2 (one read serves phix and phi; folding one parity at a time from the held row
+      // needs 36 B/lane of scratch, re-reading the row and folding both parities at once 84-296)
       if constexpr (MODE != MODE_COUPLED) eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, row), j);
-#else
-      eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, row), j);       // Coupled: the same row again, 6 us later (from cache)
-#endif
       NQ_EO_FENCE();
       eo_fold_regs<M, P, T>(we, x1, x2, j, 0, wj, kk, false);
       eo_fold_regs<M, P, T>(wo, x1, x2, j, 1, wj, kk, false);
@@ -894,24 +881,18 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
     wj_tid = cmake(z.x, -z.y);
   }
   wg_barrier_all();
-#if NQ_EO_PREFETCH_ROW
-  // the phi row of the NEXT row block is requested before the forward transforms and the stores of the current one
-  cd x1[P], x2[P];
-  eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, (size_t)blockIdx.x), j_tid);
-#endif
   for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
     int j = j_tid, c = 0;
     cd wj = wj_tid;
     asm volatile("" : "+v"(j), "+v"(c), "+v"(wj.x), "+v"(wj.y));
     const size_t row = (size_t)rb;
-    const bool more = rb + (int)gridDim.x < nblocks;
     cd we[P], wo[P], ge[P];
     double ae[P], ao[P];
-#if !NQ_EO_PREFETCH_ROW
+    // (requesting the NEXT row block's phi row before the forward transforms of this one keeps 64 VGPRs live across the loop's
+    // back edge, which the register allocator answers with 143 dwords of scratch: the row is loaded where it is used)
     cd x1[P], x2[P];
     eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, row), j);
     NQ_EO_FENCE();
-#endif
     // phi and phix = ifft(ik phi) of both parities from ONE read of the row
     eo_fold_regs<M, P, T>(we, x1, x2, j, 0, wj, kk, false);
     NQ_EO_FENCE();
@@ -963,11 +944,6 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
       mb = fmax(mb, fabs(b));
       wo[t] = cmake(ao[t], b);
     }
-#if NQ_EO_PREFETCH_ROW
-    NQ_EO_FENCE();
-    // the phi row of the next row block: in flight during the two forward transforms and the stores
-    if (more) eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, row + gridDim.x), j);
-#endif
     // |phi|^2 is typically 1e8 times J(phi*, phi): the second field is rescaled per row by a power of two (k_x_wavepv)
     if (j == 0) {
       mx[0] = 0ull;

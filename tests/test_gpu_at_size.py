@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 from oracle import niwqg_oracle as O
-from test_oracle_golden import notebook_kwargs, rel, L, K0, U0
+from test_oracle_golden import notebook_kwargs, rel, L, K0
 
 pytestmark = pytest.mark.gpu
 
@@ -59,7 +59,7 @@ def test_config2_qgmodel_2048_random_q_against_the_oracle():
 def test_config5_uncoupled_1024_member_against_the_oracle(member, tdiags):
     """ref: niwqg/UnCoupledModel.py:54-64 with quirk Q1 (stale phix, phiy: the trajectory depends on tdiags) at the size and
     on the initial condition of BASELINE.json configs[4] (niwqg_amd.ensemble.config5_member)."""
-    from niwqg_amd import ensemble, InitialConditions as ic
+    from niwqg_amd import ensemble
     nx = 1024
     m = ensemble.config5_member(member, nx=nx, tdiags=tdiags)
     kw = dict(L=m.L, nx=nx, tmax=1e30, dt=m.dt, m=m.m, N=m.N, f=m.f, twrite=10 ** 9, tdiags=tdiags, nu4=m.nu4, nu4w=m.nu4w,

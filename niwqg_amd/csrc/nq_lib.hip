@@ -1670,6 +1670,16 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
   const nq_params* p = &pp;
   int S1, S2;
   if (!plan_for(p->nx, &S1, &S2)) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: nx=%d unsupported (power of two in [64, 8192])", p->nx);
+  if (const char* e = getenv("NIWQG_AMD_Y_SPLIT")) {       // "S1,S2": another split of the two-pass y transform (measurements)
+    int a = 0, b = 0;
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && a * b == p->nx && (a == 8 || a == 16 || a == 32 || a == 64) &&
+        (b == 8 || b == 16 || b == 32 || b == 64 || b == 128)) {
+      S1 = a;
+      S2 = b;
+    } else {
+      NQ_FAIL((nq_ctx*)nullptr, -2, "NIWQG_AMD_Y_SPLIT=%s: S1 in {8,16,32,64}, S2 in {8..128}, S1*S2 = nx", e);
+    }
+  }
   if (p->model < 0 || p->model > 2) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: unknown model %d", p->model);
   if (P < 1 || rank < 0 || rank >= P || (P & (P - 1)) || p->nx / P < CL ||
       (P > 1 && (p->nx / 2 + 1 + P - 1) / P >= 2048))

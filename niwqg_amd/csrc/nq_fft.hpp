@@ -422,6 +422,16 @@ struct WgFft {
     stages_from<INV, 0, Src>(r, j, c, lds, twr);
   }
 
+  // the barriers of one run(), nothing else: for the waves of a workgroup that have no transform of their own while the
+  // others run one (array-parallel small-grid kernels: every wave must arrive at every workgroup barrier)
+  __device__ __forceinline__ static void idle() {
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) {
+      wg_barrier();
+      wg_barrier();
+    }
+  }
+
   // ---- two independent transforms, stage by stage, through two exchange areas ----------------------
   // The LDS stores of a stage are the expensive half of an exchange (ds_write_b128 moves 80 B/clk/CU against
   // 256 B/clk for the reads) and a lone transform leaves them fully exposed: every wave finishes its butterflies

@@ -48,6 +48,7 @@ struct nq_ctx {
   nq_params p;
   int N = 0, S1 = 0, S2 = 0, nk = 0;
   int CLy = CL;          // columns per workgroup of the y-side kernels: CL, or CLS with single-pass columns (S1 = N, S2 = 1)
+  int small_qg = 0;      // QGModel on a small grid: columns per workgroup of the array-parallel spectral kernel k_c_qg (0 = off)
   int WhG = 0;           // global half-spectrum width N/2+1
   int Wh = 0, Ph = 0;    // valid local half-spectrum columns and their pitch (== WhG, N/2+8 when P == 1)
   bool own_stream = true;
@@ -528,8 +529,7 @@ __global__ void k_budget_sums(BudgetAcc b, double* __restrict__ sums) {
 
 // One ETDRK4 step's worth of budget rates -> Ke, Pw, Kw increments (ref Kernel.py:319-322, :390-392;
 // QGModel.py:355-407).  Slot s of the spectral sums = state at the start of stage s.
-__global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void budget_accumulate_body(const BudgetAcc& b, const double* __restrict__ sums) {
   double sw[5][4], sj[4][2], sq[5][3];
   const bool qg = b.model == NQ_MODEL_QG;
   for (int s = 0; s < 4; ++s) {
@@ -577,6 +577,39 @@ __global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums
     for (int q = 0; q < 3; ++q) b.carryQ[q] = sq[4][q];
     for (int q = 0; q < 4; ++q) b.carryW[q] = sw[4][q];
   }
+}
+__global__ void k_budget_accumulate(BudgetAcc b, const double* __restrict__ sums) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  budget_accumulate_body(b, sums);
+}
+// Both in ONE launch of one workgroup, for grids whose kernels emit few partial sums (<= 256 workgroups; at 1024 partials one
+// workgroup reading them all is slower than the 44 of k_budget_sums): on the small grids a step is a chain of dependent
+// 5-15 us kernels and each of the two budget launches costs 4.6 us of it.
+__global__ void __launch_bounds__(1024) k_budget_small(BudgetAcc b, double* __restrict__ sums) {
+  __shared__ double ss[44];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (int i = wave; i < 44; i += nwaves) {          // every wave sums its own quantities: no workgroup barrier inside
+    const int s = i / 11, q = i % 11;
+    const double* part = nullptr;
+    int n = 0, stride = 0;
+    if (q < 3) {
+      part = b.partQ + (size_t)s * b.nwq * b.nqs + q; n = b.nwq; stride = b.nqs;
+    } else if (b.model == NQ_MODEL_QG) {
+      if (b.nqs == 6 && q < 6) { part = b.partQ + (size_t)s * b.nwq * 6 + q; n = b.nwq; stride = 6; }
+    } else if (q < 3 + NQ_PARTW) {
+      part = b.partW + (size_t)s * b.nww * NQ_PARTW + (q - 3); n = b.nww; stride = NQ_PARTW;
+    }
+    double x = 0.0;
+    for (int k = lane; k < n; k += 64) x += part[(size_t)k * stride];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if (lane == 0) {
+      ss[i] = x;
+      sums[i] = x;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) budget_accumulate_body(b, ss);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -986,6 +1019,23 @@ static void launch_invert(nq_ctx* c, const cd* qh, bool store_aux, double* part,
   }
 }
 
+template <int N_, int CW_>
+static void launch_cqg_t(nq_ctx* c, const EtdArrays& ea, int stage, bool store_aux, double* part, const cd* q_bud) {
+  typedef SmallColPlan<N_, CW_> Y;
+  hipLaunchKernelGGL((k_c_qg<N_, CW_>), dim3((c->Wh + CW_ - 1) / CW_), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mUq, c->mVq, ea, stage,
+                     geom_half(c), c->mU, c->mP, c->mQ, store_aux ? c->ph : nullptr, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw,
+                     c->bud ? part : nullptr, q_bud);
+}
+// QGModel, small grid: N_q, the stage update, the inversion and its three inverse y transforms in one launch
+static void launch_cqg(nq_ctx* c, const EtdArrays& ea, int stage, bool store_aux, double* part, const cd* q_bud) {
+  ProfScope ps(c, PK_SQ);
+  switch (c->N) {
+    case 128: launch_cqg_t<128, 4>(c, ea, stage, store_aux, part, q_bud); break;
+    case 256: launch_cqg_t<256, 2>(c, ea, stage, store_aux, part, q_bud); break;
+    case 512: launch_cqg_t<512, 2>(c, ea, stage, store_aux, part, q_bud); break;
+  }
+}
+
 static BudgetAcc budget_acc(nq_ctx* c) {
   BudgetAcc b;
   b.model = c->p.model;
@@ -1029,6 +1079,10 @@ static void phase_update(nq_ctx* c, int s) {
   if (c->passive) launch_A_m(c, false, {&c->mUq, &c->mVq, &c->mUc, &c->mVc});
   else launch_A_m(c, false, {&c->mUq, &c->mVq});
   EtdArrays eq = etd_arrays(c->q, s, &qslot);
+  if (c->small_qg) {          // QGModel.py:355,:401: ep_psi of stages 0..2 with the start-of-step q
+    launch_cqg(c, eq, s, s == 3, c->partQ + (size_t)s * c->nwq * 3, s < 3 ? c->q.y[c->q.cur] : nullptr);
+    return;
+  }
   launch_sq(c, eq, s);
   int cslot = 0;
   if (c->passive) {           // same update with the scalar's operator and its own products (ref QGModel.py:345-392)
@@ -1135,6 +1189,10 @@ static void do_step(nq_ctx* c) {      // P == 1
       phase_wavepv(c);
       phase_invert(c, s);
     }
+  }
+  if (c->bud && c->nww <= 256 && c->nwq <= 256) {            // few partials (grids <= 512): sums and accumulation in one launch
+    hipLaunchKernelGGL(k_budget_small, dim3(1), dim3(1024), 0, c->stream, budget_acc(c), c->bsums);
+    return;
   }
   phase_budget_sums(c);
   phase_budget_finish(c);
@@ -1705,6 +1763,11 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
       c->S1 = p->nx;
       c->S2 = 1;
       c->CLy = p->nx >= 128 ? CLS : CL;
+      // QGModel without its passive scalar: k_s_q + k_s_invert of a stage as ONE array-parallel kernel (k_c_qg); one wave per
+      // array and column tile (NIWQG_AMD_SMALL_QG=0: the separate kernels)
+      const char* e2 = getenv("NIWQG_AMD_SMALL_QG");
+      if (p->model == NQ_MODEL_QG && !p->passive_scalar && p->nx >= 128 && !(e2 && atoi(e2) == 0))
+        c->small_qg = p->nx == 128 ? 4 : 2;
     }
   }
   c->P = P;
@@ -1933,6 +1996,7 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
     if (c->bud) {
       c->nww = (c->Wf / c->CLy) * c->S2;
       c->nwq = ((c->Wh + c->CLy - 1) / c->CLy) * c->S2;
+      if (c->small_qg && (c->Wh + c->small_qg - 1) / c->small_qg > c->nwq) c->nwq = (c->Wh + c->small_qg - 1) / c->small_qg;
       if (c->nwq < 1) c->nwq = 1;
       ALLOC(c, c->partQ, (size_t)4 * c->nwq * (sg.passive ? 6 : 3));
       ALLOC(c, c->part0Q, (size_t)c->nwq * (sg.passive ? 6 : 3));

@@ -1529,6 +1529,167 @@ k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict
 }
 
 
+// ---- QGModel on small grids (one rank, N <= 512): the spectral side of a stage as ONE array-parallel kernel ---------------
+// A step of these grids is a chain of dependent kernels of 7-14 us each, bound by the latency inside every kernel: load ->
+// transform -> transform -> load state -> pointwise -> transform -> transform -> transform -> store, one after the other in each
+// workgroup (profiles/r03_small_grids_single_pass_columns.txt).  Here k_s_q and k_s_invert<MODE_UNCOUPLED> of the QG stage
+// graph are one kernel whose workgroup is three wave groups working side by side on a tile of whole columns:
+//   group 0: F[uq] = fft_y(Huq) ........................... later  u-hat = -i l psi -> ifft_y -> Hu
+//   group 1: F[vq] = fft_y(Hvq) ........................... later  psi-hat            -> ifft_y -> Hp
+//   group 2: requests the ETDRK4 operands of its points WHILE the other two transform, then does the pointwise work of both
+//            kernels (N_q, stage update, psi = -q/wv2, the ep_psi sums) ... q-hat -> ifft_y -> Hq
+// Values cross between the groups through LDS (same (row, column) slot in every group: no conflicts); the new q-hat never
+// makes the round trip through memory that separates k_s_q from k_s_invert.  Arithmetic: ref QGModel.py:328-407 (stage
+// updates), :469-481 (N_q, [0,0] kept), :497-505 (psi = -wv2i q), :588-593 (ep_psi with the stale q of :401) -- the same
+// expressions, in the same order, as k_s_q / etd_update / k_s_invert.
+template <int N, int CW>
+struct SmallColPlan {
+  static constexpr int P = 8, T = N / P, GROUP = CW * T, THREADS = 3 * GROUP;
+  typedef WgFft<N, P, CW, false> F;
+  // [3 exchange areas][3 hand-over planes of N x CW][reduction scratch]
+  static constexpr size_t LDS_BYTES = (size_t)(3 * F::LDS_ELEMS + 3 * N * CW) * sizeof(cd) + 512;
+};
+
+template <int N, int CW>
+__global__ void __launch_bounds__((SmallColPlan<N, CW>::THREADS))
+k_c_qg(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, MArr Hu, MArr Hp, MArr Hq, cd* __restrict__ ph_out, double invM,
+       const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw, double* __restrict__ bud_part,
+       const cd* __restrict__ q_bud) {
+  typedef SmallColPlan<N, CW> Y;
+  typedef typename Y::F F;
+  constexpr int P = Y::P, T = Y::T;
+  const int grp = threadIdx.x / Y::GROUP, tig = threadIdx.x % Y::GROUP;
+  const int c = tig % CW, j = tig / CW;
+  const int k = blockIdx.x * CW + c;
+  const bool ok = k < g.width;
+  cd* lds = reinterpret_cast<cd*>(nq_smem) + (size_t)grp * F::LDS_ELEMS;
+  cd* X1 = reinterpret_cast<cd*>(nq_smem) + 3 * (size_t)F::LDS_ELEMS;      // F[uq], then u-hat
+  cd* X2 = X1 + N * CW;                                                     // F[vq], then psi-hat
+  cd* X3 = X2 + N * CW;                                                     // the new q-hat (mirrored rows of the budget sums)
+  double* red = reinterpret_cast<double*>(X3 + N * CW);
+  typename F::Tw twr;
+  F::load_tw(twr, j, tw, 1);
+  const double kx = ok ? kk[k] : 0.0;
+  cd r[P];
+  double s3[3] = {0.0, 0.0, 0.0};
+  // ---- phase A: forward transforms (groups 0, 1) beside the operand requests (group 2)
+  cd o1[P], o2[P], o3[P], o4[P], o5[P];        // (fab, fc of the last stage are fetched where they are used: 64 VGPRs less)
+  constexpr bool QB_EARLY = Y::THREADS <= 192;   // (two waves per SIMD at 384 threads: 256 VGPRs, no room for it)
+  cd qb[P];                                    // the stale q of the ep_psi sums (stages 0..2)
+  double lyv[P];
+  if (grp < 2) {
+    const MArr& H = grp == 0 ? Huq : Hvq;
+#pragma unroll
+    for (int t = 0; t < P; ++t) r[t] = ok ? H.ys[(size_t)(j + t * T) * H.pitch + k] : cmake(0, 0);
+    F::template run<false>(r, j, c, lds, twr);
+#pragma unroll
+    for (int t = 0; t < P; ++t) (grp == 0 ? X1 : X2)[(j + t * T) * CW + c] = r[t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < P; ++t) lyv[t] = ll[j + t * T];
+    if (ok) {
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        const size_t idx = (size_t)(j + t * T) * g.pitch_s + k;
+        if (QB_EARLY && bud_part && q_bud) qb[t] = q_bud[idx];
+        o2[t] = ea.y_in[idx];
+        if (stage < 3) {
+          o1[t] = ea.Eh[idx];
+          o3[t] = ea.Q[idx];
+        } else {
+          o1[t] = ea.E[idx];
+          o3[t] = ea.f0[idx];
+        }
+        if (stage >= 2) {
+          o4[t] = ea.fn0[idx];
+          o5[t] = ea.fna[idx];
+        }
+      }
+    }
+    F::idle();
+  }
+  wg_barrier();
+  // ---- phase B: pointwise (group 2)
+  cd y[P];
+  if (grp == 2) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const int l = j + t * T;
+      const size_t idx = (size_t)l * g.pitch_s + k;
+      const double ly = lyv[t];
+      const cd f1 = X1[l * CW + c], f2 = X2[l * CW + c];
+      const cd Nl = cmake(kx * f1.y + ly * f2.y, -(kx * f1.x + ly * f2.x));          // N_q = -(ik F1 + il F2), [0,0] kept
+      cd yy = cmake(0, 0);
+      if (ok) {
+        if (stage == 0) {
+          yy = cadd(cmul(o1[t], o2[t]), cmul(o3[t], Nl));
+          ea.fn0[idx] = Nl;
+        } else if (stage == 1) {
+          yy = cadd(cmul(o1[t], o2[t]), cmul(o3[t], Nl));
+          ea.fna[idx] = Nl;
+        } else if (stage == 2) {
+          const cd comb = cmake(2.0 * Nl.x - o4[t].x, 2.0 * Nl.y - o4[t].y);
+          yy = cadd(cmul(o1[t], o2[t]), cmul(o3[t], comb));
+          ea.fna[idx] = cadd(o5[t], Nl);
+        } else {
+          yy = cadd(cadd(cmul(o1[t], o2[t]), cmul(o3[t], o4[t])), cadd(cscale(cmul(ea.fab[idx], o5[t]), 2.0), cmul(ea.fc[idx], Nl)));
+        }
+        ea.y_out[idx] = yy;
+      }
+      y[t] = yy;
+      X3[l * CW + c] = yy;
+    }
+  }
+  wg_barrier();
+  if (grp == 2) {
+    const bool special = ok && (k == 0 || k == N / 2);
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const int l = j + t * T;
+      const size_t idx = (size_t)l * g.pitch_s + k;
+      const double ly = lyv[t];
+      const double wv2 = kx * kx + ly * ly;
+      const double wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
+      const cd qv = y[t];
+      const cd psi = cmake(-wv2i * qv.x, -wv2i * qv.y);
+      if (ok && ph_out) ph_out[idx] = psi;
+      if (bud_part && ok) {
+        cd qB = q_bud ? (QB_EARLY ? qb[t] : q_bud[idx]) : qv, qQ = qv, ps = psi;
+        if (special) {      // Hermitian part (in l) of the self-mirrored columns: what irfft2 keeps (k_s_invert)
+          const int lm = (N - l) % N;
+          const cd qm = X3[lm * CW + c];
+          const cd qbm = q_bud ? q_bud[(size_t)lm * g.pitch_s + k] : qm;
+          const cd psm = cmake(-wv2i * qm.x, -wv2i * qm.y);
+          qQ = cmake(0.5 * (qv.x + qm.x), 0.5 * (qv.y - qm.y));
+          qB = cmake(0.5 * (qB.x + qbm.x), 0.5 * (qB.y - qbm.y));
+          ps = cmake(0.5 * (psi.x + psm.x), 0.5 * (psi.y - psm.y));
+        }
+        const double wgt = special ? 1.0 : 2.0;
+        const double rb = wgt * (qB.x * ps.x + qB.y * ps.y), rq = wgt * (qQ.x * ps.x + qQ.y * ps.y);
+        s3[0] += wv2 * wv2 * rb;
+        s3[1] += wv2 * rq;
+        s3[2] += rb;
+      }
+      X1[l * CW + c] = cmake(ly * psi.y * invM, -ly * psi.x * invM);       // -i l psi (QGModel: literal irfft2 arithmetic)
+      X2[l * CW + c] = cscale(psi, invM);
+      r[t] = cscale(qv, invM);
+    }
+  }
+  wg_barrier();
+  // ---- phase C: the three inverse transforms side by side
+  if (grp < 2) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) r[t] = (grp == 0 ? X1 : X2)[(j + t * T) * CW + c];
+  }
+  F::template run<true>(r, j, c, lds, twr);
+  if (ok) {
+    const MArr& O = grp == 0 ? Hu : (grp == 1 ? Hp : Hq);
+#pragma unroll
+    for (int t = 0; t < P; ++t) O.ys[(size_t)(j + t * T) * O.pitch + k] = r[t];
+  }
+  if (bud_part) block_sum_store<3>(s3, red, bud_part + 3 * (size_t)blockIdx.x);
+}
+
 // ---- physical rows <-> mixed-space rows of the slab layout (set_q / set_phi / field reads of a slab context) --------
 // Same transforms as k_x_r2c / k_x_c2c / k_x_c2r (nq_generic.hpp), addressed through MArr so that the rows land in / come
 // from the x side of an exchange group.  `rows` are this rank's local rows, contiguous (nrows, N).

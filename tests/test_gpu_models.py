@@ -501,6 +501,28 @@ def test_ensemble_members_equal_individually_stepped_models():
     assert ens.member_steps() == 12
 
 
+@pytest.mark.parametrize("nx", [128, 256, 512])
+def test_qg_small_grid_array_parallel_kernel_against_the_oracle(nx):
+    """QGModel on the grids where the spectral side of a stage is ONE array-parallel kernel (k_c_qg: N_q, stage update,
+    inversion, three inverse y transforms; 4 / 2 / 2 columns per wave group at 128 / 256 / 512) and the budget kernels one
+    launch: white-noise q with beta, nu, mu and the filter on, 12 steps against the reference-pinned oracle (ref
+    QGModel.py:328-407, :469-505, :588-593) -- q, q-hat, psi-hat and Ke, whose ep_psi sums use the stale q of :401."""
+    kw = dict(L=L, nx=nx, tmax=1e30, dt=0.05 * TE * 128 / nx, twrite=10 ** 9, nu4=7.5e8 * (128.0 / nx) ** 4, nu=5.0, mu=1e-8,
+              use_filter=True, U=-U0, tdiags=10 ** 9, beta=2e-11)
+    q0 = 1e-5 * np.random.default_rng(nx).standard_normal((nx, nx))
+    m = models().QGModel.Model(**kw)
+    o = O.QGOracle(**kw)
+    for x in (m, o):
+        x.set_q(q0)
+    for _ in range(12):
+        o._step_forward()
+    steps(m, 12)
+    eq, eh, ep = rel(m.q, o.q), rel(m.qh, o.qh), rel(m.ph, o.ph)
+    print("QGModel %d^2 white noise, 12 steps: q %.2e qh %.2e ph %.2e, Ke %.10e vs %.10e" % (nx, eq, eh, ep, m.Ke, o.Ke))
+    assert eq < 1e-11 and eh < 1e-11 and ep < 1e-11
+    assert abs(m.Ke - o.Ke) < 1e-10 * abs(o.Ke)
+
+
 @pytest.mark.parametrize("use_filter", [True, False])
 def test_qg_passive_scalar_against_the_reference(golden, use_filter):
     """QGModel with passive_scalar=True through the reference itself (golden g10): q and c trajectories, Ke, cvar (the

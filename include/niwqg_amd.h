@@ -29,7 +29,8 @@ enum { NQ_MODEL_COUPLED = 0, NQ_MODEL_UNCOUPLED = 1, NQ_MODEL_QG = 2,
  * returns the number of doubles written.  Spectra of REAL fields (qh, ph, qwh, ch) always come as the HALF spectrum
  * (ny, nx/2+1), k = 0..nx/2, for every model: the reference's Kernel-family (ny,nx) arrays follow from
  * X(l,k) = conj X(-l,-k) for k > nx/2 (niwqg_amd/Kernel.py: hermitian_full; with dual_q the k < 0 side of qh is
- * NQ_F_QH_MINUS instead).  phih is a genuine full plane. */
+ * NQ_F_QH_MINUS instead; without it row ny/2 of qh additionally gets the passenger of nq_get_qh_passenger).  phih is a
+ * genuine full plane. */
 enum {
   NQ_F_Q = 0,      /* real (ny,nx)        q      = Re ifft(qh)                 Kernel.py:97/CoupledModel.py:97 */
   NQ_F_QH = 1,     /* cplx (ny,nx/2+1)    qh                                                                    */

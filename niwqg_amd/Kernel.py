@@ -71,8 +71,9 @@ class Kernel(object):
         self.use_filter = use_filter
         self.use_mkl, self.nthreads = use_mkl, nthreads
         # The reference's 2/3 mask (Kernel.py:277-281) is not mirror-symmetric, so its q-hat is not Hermitian:
-        # the device then keeps a second half-spectrum copy ("dual copy").  exact_qh=True asks for
-        # the same with symmetric filters, which reproduces the reference's qh on the Nyquist row as well.
+        # the device then keeps a second half-spectrum copy ("dual copy").  With symmetric filters the
+        # reference's qh is reproduced on the whole plane WITHOUT it (the Nyquist-row passenger is carried as one
+        # extra row: nq_get_qh_passenger); exact_qh=True still selects the dual copy explicitly.
         self._dual = bool(exact_qh) or (bool(dealias) and not use_filter)
         # ref: niwqg/CoupledModel.py:38-42 / UnCoupledModel.py / YBJModel.py (_allocate_variables): array types and shapes
         self.dtype_real, self.dtype_cplx = np.dtype('float64'), np.dtype('complex128')

@@ -9,13 +9,15 @@ fp64 (BASELINE.json configs[2]: LambDipole q, uniform phi, filter on), state res
 * `value` = K steps / wall time of the region bracketed by barrier + synchronize on both sides (max over ranks).
   The K steps are issued as 5 blocks with a HIP event between blocks (no synchronisation inside the region):
   `blocks_ms_per_step` / `median_block_steps_per_s` are SURVEY 8d's "median of 5".
-* `roofline` describes the DOMINANT kernel class of the timed region (largest total time among ALL six classes, every
-  launch bracketed by HIP events on the context's stream): achieved = algorithmic bytes per launch / average launch
-  duration.  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC summary, used only if that summary was
-  taken from the very sources that are running (sha256 of niwqg_amd/csrc + include/ stamped into it), else null.
+* `roofline` describes the DOMINANT kernel class (largest total time among all six classes in an untimed pass with every
+  launch bracketed by HIP events on the context's stream); INSIDE the timed region the launches of that class -- and only
+  those: bracketing all 44 launches of a step costs 4.6 % of it -- are bracketed again, and achieved = algorithmic bytes
+  per launch / their average duration.  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC summary, used
+  only if that summary was taken from the very sources that are running (sha256 of niwqg_amd/csrc + include/ stamped
+  into it), else null.  `peak_measured_copy` = a 1r + 1w stream copy timed in the untimed part of the same run.
 * `cpu_baseline` times the numpy oracle in its reference-faithful mode (104 c2c numpy.fft transforms per step, one thread)
-  at 2048^2 -- measured, >= 2 steps -- and scales by N^2 log2 N to the workload's grid (4.4x; `--cpu-baseline-nx 4096`
-  measures at the full size, about 6 minutes; the result of that run is kept in profiles/).
+  at 2048^2 -- measured, >= 2 steps; `value` is the measurement recorded once AT 4096^2 (`--cpu-baseline-nx 4096`, about 6
+  minutes, kept in profiles/), this run's own sample and its N^2 log2 N extrapolation ride along as the cross-check.
 With --gpus N > 1 and no WORLD_SIZE in the environment the script starts N ranks itself (torch.distributed.run, child
 process, before any GPU call); with WORLD_SIZE set it must equal --gpus.
 """
@@ -470,14 +472,24 @@ def main():
 
     NBLK = 5 if args.steps >= 5 else 1
     blocks = [args.steps // NBLK + (1 if i < args.steps % NBLK else 0) for i in range(NBLK)]
-    # HIP events around every launch of the six kernel classes: inside the timed region where a launch lasts tens of
-    # microseconds or more (nx >= 4096: two event records per launch are noise), in a separate pass right after it on the
-    # small grids, whose steps are launch-bound (at 256^2 the records alone would cost a quarter of the step)
+    # HIP events around kernel launches.  Bracketing EVERY launch of the six classes inside the timed region costs 4.6 % of a
+    # 4096^2 step (88 event records per step at ~4.5 us each: measured 101.8 against 106.5 steps/s on one box, round 3), a
+    # quarter of a 256^2 step.  So: nx >= 4096 -- an untimed pass brackets all six classes (the per-class table, and which
+    # class is dominant), then INSIDE the timed region only the launches of that dominant class are bracketed: the roofline's
+    # kernel is measured live over the timed region (20 of the 44 launches of a step at most); small grids -- everything in
+    # a separate pass right after the timed region.
     events_in_region = args.nx >= 4096
+    classes_all, ksteps_all = None, 0
     if events_in_region:
+        ksteps_all = min(args.steps, 5)
         ctx.profile_enable(-2)
-        advance(min(args.steps, 5))                         # untimed: creates the event pool the timed region re-uses
+        advance(ksteps_all)                                 # creates the event pool
         ctx.profile_read_all()
+        advance(ksteps_all)                                 # untimed, all six classes bracketed: the per-class table
+        classes_all = ctx.profile_read_all()
+        live = [k for k in classes_all if classes_all[k][0] > 0]
+        dom_class = max(live, key=lambda k: classes_all[k][1])
+        ctx.profile_enable(ctx.KERNEL_CLASSES[dom_class])   # timed region: the dominant class only
     if sim is not None:
         sim.counters(reset=2)                               # count host calls / exchange chunks / bytes, time the exchange stream
     barrier()
@@ -500,6 +512,10 @@ def main():
         advance(ksteps)
     classes = ctx.profile_read_all()
     ctx.profile_enable(-1)
+    dom_timed = None
+    if events_in_region:                                    # `classes` holds the dominant class over the timed region only
+        dom_timed = (dom_class, classes[dom_class])
+        classes, ksteps = classes_all, ksteps_all
     if sim is not None:
         # strong scaling: all ranks advance the SAME simulation; whole-job steps/s = steps / slowest rank
         wall = grp.max(wall)
@@ -545,6 +561,8 @@ def main():
         cands = [k for k in classes if k in table and classes[k][0] > 0]
         dom = max(cands, key=lambda k: classes[k][1])
         launches, kms = classes[dom]
+        if dom_timed is not None and dom_timed[0] in table and dom_timed[1][0] > 0:
+            dom, (launches, kms) = dom_timed                # measured live inside the timed region
         k_ms = kms / launches
         k_bytes = table[dom] * npts / share
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
@@ -573,7 +591,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_note,
                          "launches": launches, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
-                         "kernel_events": "inside the timed region" if events_in_region else "separate pass of %d steps after the timed region" % ksteps,
+                         "kernel_events": ("dominant class bracketed inside the timed region (%d launches); per-class table from an untimed pass of "
+                                           "%d steps right before it (bracketing all six classes in the region costs 4.6 %% of the step)"
+                                           % (launches, ksteps)) if events_in_region
+                                          else "separate pass of %d steps after the timed region" % ksteps,
                          "per_kernel_ms_per_step": {k: round(v[1] / ksteps, 4) for k, v in classes.items()},
                          "per_kernel_frac_of_peak": {k: round(table[k] * npts / share / (classes[k][1] / classes[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                      for k in cands},

@@ -435,3 +435,29 @@ def test_rccl_link_with_rank_threads_over_a_mock_librccl(tmp_path):
         print(out.stderr[-6000:])
     assert out.returncode == 0
     assert "rank threads over the mock RCCL agree with the single context" in out.stdout
+
+
+def test_bench_contract_on_one_gpu():
+    """`python bench.py` (N = 1): the JSON line's contract fields, the roofline object with both denominators, and the CPU-baseline
+    object (a small grid so that the oracle leg takes seconds)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--nx", "128",
+                          "--model", "coupled"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "peak_measured_copy", "frac_of_copy")) <= set(r)
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak_measured_copy"] > 1000.0
+    cb = d["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0

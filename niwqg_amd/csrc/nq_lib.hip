@@ -615,6 +615,8 @@ __global__ void __launch_bounds__(1024) k_budget_small(BudgetAcc b, double* __re
 // ---------------------------------------------------------------------------------------------
 // size dispatch
 #define M_SMALL(M) M(64, 8, 8) M(128, 8, 16) M(256, 16, 16) M(512, 16, 32) M(1024, 32, 32) M(2048, 32, 64)
+// sizes whose fused row kernels run one transform per row (8192-point rows: the even/odd kernels, k_x_products_eo / k_x_wavepv_eo)
+#define NQ_FOR_ROW_SIZES(M) M_SMALL(M) M(4096, 64, 64)
 #define NQ_FOR_SIZES(M) M(64, 8, 8) M(128, 8, 16) M(256, 16, 16) M(512, 16, 32) M(1024, 32, 32) M(2048, 32, 64) M(4096, 64, 64) M(8192, 64, 128)
 
 static bool plan_for(int N, int* S1, int* S2) {
@@ -825,14 +827,11 @@ static void launch_wavepv_t(nq_ctx* c) {
   switch (c->N) {
 #define CASE_(n, a, b) case n: { typedef XPlan1<n> X; hipLaunchKernelGGL((k_x_wavepv<n, SLAB>), dim3(c->nrows / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, mPhi, mPhiy, mA, mB, c->twx1, c->kk); } break;
     case 8192:
-      if (c->twx_half) {                              // even / odd samples as two 4096-point problems (no spills)
+      {                                               // even / odd samples as two 4096-point problems (no spills)
         typedef XPlan<4096> X;
         const int ncu = c->num_cu - c->reserve_cus, nb = c->nrows, grid = nb < ncu ? nb : ncu;
         const size_t ldsb = X::LDS_BYTES + (size_t)4096 * sizeof(cd) ;          // + the 64 KB of thread-private park slots
         hipLaunchKernelGGL((k_x_wavepv_eo<8192, SLAB>), dim3(grid), dim3(X::THREADS), ldsb, c->stream, mPhi, mPhiy, mA, mB, c->twx_half, c->tw, c->kk, nb);
-      } else {
-        typedef XPlan1<8192> X;
-        hipLaunchKernelGGL((k_x_wavepv<8192, SLAB>), dim3(c->nrows / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, mPhi, mPhiy, mA, mB, c->twx1, c->kk);
       }
       break;
     case 4096: {                                      // long rows: two transforms in flight, no spills
@@ -877,7 +876,7 @@ static void launch_products_t(nq_ctx* c, double cj, double cr, bool fresh_grad) 
     const int ncu = c->num_cu - c->reserve_cus; \
     const int grid = (X::LDS_BYTES > 80 * 1024 && X::THREADS <= 512 && nb > ncu) ? ncu : nb; \
     hipLaunchKernelGGL((k_x_products<n, MODE, SLAB>), dim3(grid), dim3(X::THREADS), X::LDS_BYTES, c->stream, mU, mP, mQ, mQw, mPhi, gx, gy, mUq, mVq, mW, c->twx, c->kk, vz, cj, cr, nb); } break;
-    NQ_FOR_SIZES(CASE_)
+    NQ_FOR_ROW_SIZES(CASE_)
 #undef CASE_
   }
 }

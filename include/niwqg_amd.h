@@ -183,6 +183,17 @@ int nq_diagnostics(nq_ctx* ctx, double* out32);
  * reference's expch, expch_h, Qh, f0, fab, fc (Kernel.py:417-454, QGModel.py:426-461).                           */
 int nq_get_coeff(nq_ctx* ctx, int eq, int which, double* out_cplx);
 
+/* The reference evaluates Qh, f0, fab, fc as the mean of 32 points on the unit circle around c dt (Kernel.py:424-433).  Where
+ * c dt lies within delta of minus one of those points, one term is a removable singularity evaluated by cancellation and the
+ * reference's value is its libm's rounding error amplified by eps / distance^3: to be identical there, those entries have to
+ * come from the same numpy expression.  nq_coeff_near_contour lists them for equation eq (as nq_get_coeff; on a slab context:
+ * this rank's columns): up to cap (l, k) pairs, k a GLOBAL column index; returns how many there are (call again with a larger cap
+ * if that exceeds cap), negative on error.  nq_coeff_patch replaces Qh, f0, fab, fc at n entries with vals (n x 4 complex128,
+ * the reference's values WITHOUT the filter; the library folds its filter in) in every plane set of that equation, and
+ * nq_get_coeff returns them from then on.  The host side calls both once, right after nq_create (niwqg_amd/_etdrk4.py).     */
+int nq_coeff_near_contour(nq_ctx* ctx, int eq, double delta, int cap, int* l_out, int* k_out);
+int nq_coeff_patch(nq_ctx* ctx, int eq, int n, const int* l, const int* k, const double* vals_cplx);
+
 /* ---- 1-D slab decomposition over nranks GPUs (one process per GPU) -----------------
  * Rows of the mixed-space planes are split over ranks on the "x side" (row kernels), columns on the "y side"
  * (spectral kernels).  Arrays that cross together form an exchange group g = 0..3; each group has an x-side

@@ -9,6 +9,8 @@ import subprocess
 
 import numpy as np
 
+from . import _etdrk4
+
 try:                      # torch bundles its own libamdhip64.so.7; load it first so that our library
     import torch          # binds to the same HIP runtime instance (one runtime per process)
 except Exception:         # pragma: no cover - torch is optional for single-GPU use
@@ -27,7 +29,7 @@ COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
 
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
            "nq_step", "nq_sync", "nq_get_field", "nq_get_qh_passenger", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
-           "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_c", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_diagnostics",
+           "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_c", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_coeff_near_contour", "nq_coeff_patch", "nq_diagnostics",
            "nq_stream_copy_gbs", "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
            "nq_reduce_buffer", "nq_reduce_read", "nq_reduce_write", "nq_device_bytes", "nq_stream",
@@ -99,6 +101,8 @@ def lib():
     L.nq_get_qh_passenger.argtypes = [vp, dp]
     L.nq_get_scalar.argtypes = [vp, ctypes.c_int, dp]
     L.nq_get_coeff.argtypes = [vp, ctypes.c_int, ctypes.c_int, dp]
+    L.nq_coeff_near_contour.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.nq_coeff_patch.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, dp]
     L.nq_stream_copy_gbs.argtypes = [vp, ctypes.c_longlong, ctypes.c_int, dp]
     L.nq_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.nq_event_record.argtypes = [vp, ctypes.c_int]
@@ -150,6 +154,29 @@ def _dptr(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
 
+def coeff_near_contour(L, h, eq, delta):
+    """(l, k) index arrays (k global) of the entries of equation eq within delta of the ETDRK4 contour (nq_coeff_near_contour)"""
+    cap = 1 << 16
+    while True:
+        li, ki = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        n = L.nq_coeff_near_contour(h, eq, float(delta), cap, li.ctypes.data, ki.ctypes.data)
+        if n < 0:
+            raise RuntimeError("nq_coeff_near_contour failed (%d): %s" % (n, L.nq_last_error(h).decode()))
+        if n <= cap:
+            return li[:n].astype(np.int64), ki[:n].astype(np.int64)
+        cap = n
+
+
+def coeff_patch(L, h, eq, li, ki, vals):
+    li, ki = np.ascontiguousarray(li, np.int32), np.ascontiguousarray(ki, np.int32)
+    vals = np.ascontiguousarray(vals, np.complex128)
+    if vals.shape != (len(li), 4) or len(ki) != len(li):
+        raise ValueError("coeff_patch: %d entries, values of shape %s" % (len(li), vals.shape))
+    rc = L.nq_coeff_patch(h, eq, len(li), li.ctypes.data, ki.ctypes.data, _dptr(vals.view(np.float64)))
+    if rc != 0:
+        raise RuntimeError("nq_coeff_patch failed (%d): %s" % (rc, L.nq_last_error(h).decode()))
+
+
 class Context:
     """Thin object wrapper over nq_ctx; all arrays in and out are numpy."""
 
@@ -177,6 +204,12 @@ class Context:
             raise RuntimeError("nq_create failed (%d): %s" % (rc, self.L.nq_last_error(None).decode()))
         self.h = h
         self.budgets_enabled = bool(budgets)
+        # the entries of Qh, f0, fab, fc next to the contour, recomputed as the reference computes them (_etdrk4.py)
+        prm = dict(U=U, f=f, kappa2=kappa2, nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw, beta=beta, nu4c=nu4c, nuc=nuc, muc=muc)
+        eqs = [0] + ([1] if model != QG else []) + ([2] if p.passive_scalar else [])
+        self.contour_patched = _etdrk4.patch_near_contour(
+            lambda eq, delta: coeff_near_contour(self.L, self.h, eq, delta), lambda eq, li, ki, v: coeff_patch(self.L, self.h, eq, li, ki, v),
+            model, self.nx, kk, ll, filtr, dt, prm, eqs)
 
     def take_budget_increments(self):
         """Ke, Pw, Kw increments accumulated on the device since the last call (Kernel.py:390-392)."""

@@ -77,6 +77,7 @@ struct nq_ctx {
   bool pass = false;
   EqState qp;
   cd* coefu[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // q coefficients without the filter
+  struct CoefPatch { int n = 0; int* l = nullptr; int* k = nullptr; cd* v = nullptr; } patch[3];   // nq_coeff_patch, per public eq
   double* filt_m = nullptr;                                                 // filter at (-l, -k)
   // half-spectrum aux spectra
   cd *qwh = nullptr, *ph = nullptr;
@@ -198,25 +199,23 @@ __device__ __forceinline__ cd cdiv(cd a, cd b) {
   return cmake((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
 }
 
+// the linear operator c(l, k) of equation eq (ref Kernel.py:417-418, :440-442, QGModel.py:426-428, :452-453)
+__device__ __forceinline__ cd linear_operator(int eq, const nq_params& p, double kx, double ly) {
+  const double wv2 = kx * kx + ly * ly, wv4 = wv2 * wv2;
+  if (eq == 0) return cmake(-p.nu4 * wv4 - p.nu * wv2 - p.mu, -kx * p.U);
+  if (eq == 1) return cmake(-p.nu4w * wv4 - p.nuw * wv2 - p.muw, -kx * p.U - 0.5 * p.f * (wv2 / p.kappa2));
+  if (eq == 3) return cmake(-p.nu4c * wv4 - p.nuc * wv2 - p.muc, 0.0);      // QGModel's passive scalar: no mean flow, no beta
+  const double wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
+  return cmake(-p.nu4 * wv4 - p.nu * wv2 - p.mu, -kx * p.U + p.beta * kx * wv2i);
+}
+
 __global__ void k_etdrk4_coeffs(int eq, int N, int width, int pitch, int k0, nq_params p, const double* __restrict__ kk,
                                 const double* __restrict__ ll, const double* __restrict__ filt,
                                 const cd* __restrict__ contour, cd* E, cd* Eh, cd* Q, cd* f0, cd* fab, cd* fc) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int l = blockIdx.y;
   if (k >= width) return;
-  const double kx = kk[k0 + k], ly = ll[l];
-  const double wv2 = kx * kx + ly * ly, wv4 = wv2 * wv2;
-  cd c;
-  if (eq == 0) {
-    c = cmake(-p.nu4 * wv4 - p.nu * wv2 - p.mu, -kx * p.U);
-  } else if (eq == 1) {
-    c = cmake(-p.nu4w * wv4 - p.nuw * wv2 - p.muw, -kx * p.U - 0.5 * p.f * (wv2 / p.kappa2));
-  } else if (eq == 3) {       // QGModel's passive scalar: no mean-flow or beta term (ref QGModel.py:446-454)
-    c = cmake(-p.nu4c * wv4 - p.nuc * wv2 - p.muc, 0.0);
-  } else {
-    const double wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
-    c = cmake(-p.nu4 * wv4 - p.nu * wv2 - p.mu, -kx * p.U + p.beta * kx * wv2i);
-  }
+  const cd c = linear_operator(eq, p, kk[k0 + k], ll[l]);
   const cd ch = cscale(c, p.dt);
   cd sQ = cmake(0, 0), s0 = cmake(0, 0), sab = cmake(0, 0), sc = cmake(0, 0);
   for (int m = 0; m < 32; ++m) {
@@ -243,6 +242,42 @@ __global__ void k_etdrk4_coeffs(int eq, int N, int width, int pitch, int k0, nq_
   f0[idx] = cscale(s0, s);
   fab[idx] = cscale(sab, s);
   fc[idx] = cscale(sc, s);
+}
+
+// Entries whose c dt lies within delta of MINUS a contour point: there one of the 32 terms of the contour mean is the
+// removable singularity (e^z - 1 - z - ...) / z^3 at |z| < delta, evaluated by cancellation, and what the reference holds in Qh,
+// f0, fab, fc at such an entry is its own libm's rounding error amplified by eps / |z|^3 -- a function of numpy's exp, not of
+// the mathematics.  The host recomputes exactly these entries with the reference's numpy expression (niwqg_amd/_etdrk4.py) and
+// hands them back through nq_coeff_patch; everywhere else the two evaluations agree to ~1e-13.
+__global__ void k_coeff_flag(int eq, int N, int width, int k0, nq_params p, const double* __restrict__ kk,
+                             const double* __restrict__ ll, const cd* __restrict__ contour, double delta2, int cap,
+                             int* __restrict__ count, int* __restrict__ lo, int* __restrict__ ko) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+  if (k >= width) return;
+  const cd ch = cscale(linear_operator(eq, p, kk[k0 + k], ll[l]), p.dt);
+  double dmin = 1e300;
+  for (int m = 0; m < 32; ++m) {
+    const cd LR = cadd(ch, contour[m]);
+    dmin = fmin(dmin, LR.x * LR.x + LR.y * LR.y);
+  }
+  if (!(dmin >= delta2)) {        // also catches NaN
+    const int at = atomicAdd(count, 1);
+    if (at < cap) { lo[at] = l; ko[at] = k0 + k; }
+  }
+}
+// v: n x 4 values (Qh, f0, fab, fc of the reference, no filter); k is a global column
+__global__ void k_coeff_patch(int n, const int* __restrict__ li, const int* __restrict__ ki, const cd* __restrict__ v, int width,
+                              int pitch, int k0, const double* __restrict__ filt, cd* Q, cd* f0, cd* fab, cd* fc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k = ki[i] - k0;
+  if (k < 0 || k >= width) return;
+  const size_t idx = (size_t)li[i] * pitch + k;
+  const double fl = filt ? filt[idx] : 1.0;
+  Q[idx] = cscale(v[4 * i], fl);
+  f0[idx] = cscale(v[4 * i + 1], fl);
+  fab[idx] = cscale(v[4 * i + 2], fl);
+  fc[idx] = cscale(v[4 * i + 3], fl);
 }
 
 // small helper kernels -------------------------------------------------------------------------
@@ -417,9 +452,15 @@ __global__ void k_diag_phi(const cd* __restrict__ phih, int N, int width, int pi
 }
 // half spectra qh, qwh (may be null), ph; nine sums (see nq_diagnostics).  On the two self-mirrored columns the sums
 // that stand for means of REAL fields use the Hermitian part H(l) = (X(l) + conj X(-l))/2 (what `.real` keeps).
+// qp, qm (dual-copy contexts, else null): the two copies X+ = qh(l,k), X- = conj qh(-l,-k) that `qh` is the mean of.  The two
+// spec_var-type sums (chi_q, ke_qg_q: ref Kernel.py:644, CoupledModel.py:115-136 take |.|^2 over the reference's FULL plane,
+// which is not Hermitian under the 2/3 mask) then see |X+|^2 + |X-|^2 on the interior columns, not 2 |mean|^2.  filt_p, filt_m
+// (idem): the filter at (l,k) and at (-l,-k).  The stored qwh is the Hermitian part fs * qw of the reference's filtr * qw, fs =
+// (filt_p + filt_m)/2; ke_qg_w = spec_var over the full plane (CoupledModel.py:108) needs (filt_p^2 + filt_m^2)/2 |qw|^2 instead.
 __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, const cd* __restrict__ ph, int N,
                          int width, int pitch, int k0, const double* __restrict__ kk, const double* __restrict__ ll,
-                         double* __restrict__ part) {
+                         double* __restrict__ part, const cd* __restrict__ qp, const cd* __restrict__ qm_,
+                         const double* __restrict__ filt_p, const double* __restrict__ filt_m) {
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const size_t total = (size_t)N * width;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -438,11 +479,20 @@ __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, 
     }
     const double kx = kk[k], ly = ll[l];
     const double wv2 = kx * kx + ly * ly, wv4 = wv2 * wv2, wv2i = (wv2 != 0.0) ? 1.0 / wv2 : 0.0;
-    const double q2 = q.x * q.x + q.y * q.y;
+    double q2 = q.x * q.x + q.y * q.y;
+    if (qp != nullptr && wt == 2.0) {
+      const cd a = qp[idx], b = qm_[idx];
+      q2 = 0.5 * (a.x * a.x + a.y * a.y + b.x * b.x + b.y * b.y);
+    }
     v[0] += wt * (hq.x * hq.x + hq.y * hq.y);                     // sum |H q|^2            -> ens
     v[1] += wt * wv4 * q2;                                        // sum wv4 |q|^2          -> chi_q
     v[2] += wt * wv2i * q2;                                       // sum |q|^2 / wv2        -> ke_qg_q
-    v[3] += wt * wv2i * (w.x * w.x + w.y * w.y);                  // sum |qw|^2 / wv2       -> ke_qg_w
+    double w2 = w.x * w.x + w.y * w.y;
+    if (filt_p != nullptr) {
+      const double fp = filt_p[idx], fm = filt_m[idx], fs = 0.5 * (fp + fm);
+      if (fs > 0.0) w2 *= (wt == 2.0 ? 0.5 * (fp * fp + fm * fm) : fp * fp) / (fs * fs);
+    }
+    v[3] += wt * wv2i * w2;                                       // sum |qw|^2 / wv2       -> ke_qg_w
     v[4] += wt * wv2i * (hq.x * hw.x + hq.y * hw.y);              // sum Re(conj q qw)/wv2  -> ke_qg_qw
     v[5] += (l == 0 && k == 0) ? 0.0 : wt * wv2 * (p.x * p.x + p.y * p.y);   // -> ke_qg
     const double pq = hp.x * hq.x + hp.y * hq.y;                  // Re(conj(psi) q)
@@ -2041,6 +2091,7 @@ int nq_destroy(nq_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   for (void* p : c->allocs) hipFree(p);
+  for (auto& pt : c->patch) { (void)hipFree(pt.l); (void)hipFree(pt.k); (void)hipFree(pt.v); }
   for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
   for (hipEvent_t e : c->marks)
     if (e) hipEventDestroy(e);
@@ -2660,7 +2711,9 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
       if (x->kf0 == 0) HIPCHK(x, hipMemcpyAsync(d + 4, phih, sizeof(cd), hipMemcpyDeviceToDevice, x->stream));
     }
     if (x->Wh > 0) {
-      hipLaunchKernelGGL(k_diag_q, dim3(NB), dim3(256), 0, x->stream, qh, (const cd*)(coupled ? x->qwh : nullptr), (const cd*)x->ph, N, x->Wh, x->Ph, x->kh0, x->kk, x->ll, x->diag_part);
+      hipLaunchKernelGGL(k_diag_q, dim3(NB), dim3(256), 0, x->stream, qh, (const cd*)(coupled ? x->qwh : nullptr), (const cd*)x->ph, N, x->Wh, x->Ph, x->kh0, x->kk, x->ll, x->diag_part,
+                         (const cd*)(x->dual ? x->q.y[x->q.cur] : nullptr), (const cd*)(x->dual ? x->q2.y[x->q2.cur] : nullptr),
+                         (const double*)(x->dual ? x->filt_h : nullptr), (const double*)(x->dual ? x->filt_m : nullptr));
       hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, NB, 9, 9, d + 6);
     }
     if (x->kh0 == 0) {                              // [15] <- Re(qh - qwh)[0,0] (the owner of column 0 contributes it)
@@ -3138,6 +3191,14 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
   NQ_FAIL(c, -1, "nq_get_scalar: id %d not available", id);
 }
 
+// overwrite the entries nq_coeff_patch recorded for public equation eq in one set of coefficient planes
+static void apply_coeff_patch(nq_ctx* c, int eq, int width, int pitch, int k0, const double* filt, cd* const* coef) {
+  const nq_ctx::CoefPatch& pt = c->patch[eq];
+  if (pt.n == 0 || width == 0) return;
+  hipLaunchKernelGGL(k_coeff_patch, dim3((pt.n + 255) / 256), dim3(256), 0, c->stream, pt.n, pt.l, pt.k, pt.v, width, pitch, k0, filt,
+                     coef[2], coef[3], coef[4], coef[5]);
+}
+
 int nq_get_coeff(nq_ctx* c, int eq, int which, double* out) {
   if (!c || !out || which < 0 || which > 5 || eq < 0 || eq > 2) return -1;
   NQ_SINGLE_RANK(c, "nq_get_coeff");
@@ -3154,11 +3215,77 @@ int nq_get_coeff(nq_ctx* c, int eq, int which, double* out) {
   for (int i = 0; i < 6; ++i) tmp[i] = reinterpret_cast<cd*>(blockp) + (size_t)i * cnt;
   const int e = eq == 2 ? 3 : (half ? (c->kernel_family ? 0 : 2) : 1);
   hipLaunchKernelGGL(k_etdrk4_coeffs, dim3((width + 63) / 64, N), dim3(64), 0, c->stream, e, N, width, pitch, 0, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5]);
+  apply_coeff_patch(c, eq, width, pitch, 0, nullptr, tmp);
   hipError_t er = hipMemcpy2DAsync(out, sizeof(cd) * width, tmp[which], sizeof(cd) * pitch, sizeof(cd) * width, N, hipMemcpyDeviceToHost, c->stream);
   int rc = nq_sync(c);
   (void)hipFree(blockp);
   if (er != hipSuccess) NQ_FAIL(c, -5, "nq_get_coeff: copy failed");
   return rc;
+}
+
+// public eq (0: q, 1: phi, 2: QGModel's passive scalar) -> k_etdrk4_coeffs' operator code, local width and first column
+static int coeff_eq(nq_ctx* c, int eq, const char* what, int* code, int* width, int* k0) {
+  if (!c) NQ_FAIL((nq_ctx*)nullptr, -1, "%s: null context", what);
+  if (eq < 0 || eq > 2) NQ_FAIL(c, -1, "%s: eq %d (0: q, 1: phi, 2: passive scalar)", what, eq);
+  if (eq == 1 && !c->kernel_family) NQ_FAIL(c, -4, "%s: no phi equation in QGModel", what);
+  if (eq == 2 && !c->passive) NQ_FAIL(c, -4, "%s: no passive scalar in this context", what);
+  *code = eq == 2 ? 3 : (eq == 1 ? 1 : (c->kernel_family ? 0 : 2));
+  *width = eq == 1 ? c->Wf : c->Wh;
+  *k0 = eq == 1 ? c->kf0 : c->kh0;
+  return 0;
+}
+
+int nq_coeff_near_contour(nq_ctx* c, int eq, double delta, int cap, int* l_out, int* k_out) {
+  int code, width, k0;
+  if (int rc = coeff_eq(c, eq, "nq_coeff_near_contour", &code, &width, &k0)) return rc;
+  if (!(delta >= 0.0) || cap < 0 || (cap > 0 && (!l_out || !k_out))) NQ_FAIL(c, -1, "nq_coeff_near_contour: bad delta / cap / outputs");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (width == 0) return 0;
+  int* d = nullptr;                                     // [count | l (cap) | k (cap)]
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), sizeof(int) * (1 + 2 * (size_t)cap)));
+  hipError_t er = hipMemsetAsync(d, 0, sizeof(int), c->stream);
+  hipLaunchKernelGGL(k_coeff_flag, dim3((width + 63) / 64, c->N), dim3(64), 0, c->stream, code, c->N, width, k0, c->p, c->kk, c->ll,
+                     c->contour, delta * delta, cap, d, d + 1, d + 1 + cap);
+  int n = 0;
+  if (er == hipSuccess) er = hipMemcpyAsync(&n, d, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+  if (er == hipSuccess) er = hipStreamSynchronize(c->stream);
+  const int got = n < cap ? n : cap;
+  if (er == hipSuccess && got > 0) er = hipMemcpy(l_out, d + 1, sizeof(int) * got, hipMemcpyDeviceToHost);
+  if (er == hipSuccess && got > 0) er = hipMemcpy(k_out, d + 1 + cap, sizeof(int) * got, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (er != hipSuccess) NQ_FAIL(c, -5, "nq_coeff_near_contour: %s", hipGetErrorString(er));
+  return n;
+}
+
+int nq_coeff_patch(nq_ctx* c, int eq, int n, const int* l, const int* k, const double* vals) {
+  int code, width, k0;
+  if (int rc = coeff_eq(c, eq, "nq_coeff_patch", &code, &width, &k0)) return rc;
+  if (n < 0 || (n > 0 && (!l || !k || !vals))) NQ_FAIL(c, -1, "nq_coeff_patch: bad arguments");
+  for (int i = 0; i < n; ++i)
+    if (l[i] < 0 || l[i] >= c->N || k[i] < k0 || k[i] >= k0 + width)
+      NQ_FAIL(c, -1, "nq_coeff_patch: entry %d = (l %d, k %d) outside this context's columns [%d, %d)", i, l[i], k[i], k0, k0 + width);
+  HIPCHK(c, hipSetDevice(c->device));
+  nq_ctx::CoefPatch& pt = c->patch[eq];
+  HIPCHK(c, hipStreamSynchronize(c->stream));           // a previous patch may still be read by a queued kernel
+  (void)hipFree(pt.l); (void)hipFree(pt.k); (void)hipFree(pt.v);
+  pt = nq_ctx::CoefPatch();
+  if (n == 0) return 0;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&pt.l), sizeof(int) * n));
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&pt.k), sizeof(int) * n));
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&pt.v), sizeof(cd) * 4 * (size_t)n));
+  HIPCHK(c, hipMemcpy(pt.l, l, sizeof(int) * n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(pt.k, k, sizeof(int) * n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(pt.v, vals, sizeof(cd) * 4 * (size_t)n, hipMemcpyHostToDevice));
+  pt.n = n;
+  if (eq == 0) {
+    apply_coeff_patch(c, 0, c->Wh, c->Ph, c->kh0, c->filt_h, c->q.coef);
+    if (c->dual) apply_coeff_patch(c, 0, c->Wh, c->Ph, c->kh0, nullptr, c->coefu);
+  } else if (eq == 1) {
+    apply_coeff_patch(c, 1, c->Wf, c->Wf, c->kf0, c->filt_f, c->w.coef);
+  } else {
+    apply_coeff_patch(c, 2, c->Wh, c->Ph, c->kh0, c->filt_h, c->cq.coef);
+  }
+  return nq_sync(c);
 }
 
 // ---- the three Jacobians of the public API, in the reference's own array layouts ------------------------------
@@ -3254,7 +3381,9 @@ int nq_diagnostics(nq_ctx* c, double* out) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, NB, 4, 4, d);
     HIPCHK(c, hipMemcpyAsync(d + 4, phih, sizeof(cd), hipMemcpyDeviceToDevice, c->stream));
   }
-  hipLaunchKernelGGL(k_diag_q, dim3(NB), dim3(256), 0, c->stream, qh, (const cd*)(c->p.model == NQ_MODEL_COUPLED ? c->qwh : nullptr), (const cd*)c->ph, N, c->Wh, c->Ph, 0, c->kk, c->ll, c->diag_part);
+  hipLaunchKernelGGL(k_diag_q, dim3(NB), dim3(256), 0, c->stream, qh, (const cd*)(c->p.model == NQ_MODEL_COUPLED ? c->qwh : nullptr), (const cd*)c->ph, N, c->Wh, c->Ph, 0, c->kk, c->ll, c->diag_part,
+                     (const cd*)(c->dual ? c->q.y[c->q.cur] : nullptr), (const cd*)(c->dual ? c->q2.y[c->q2.cur] : nullptr),
+                     (const double*)(c->dual ? c->filt_h : nullptr), (const double*)(c->dual ? c->filt_m : nullptr));
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, NB, 9, 9, d + 6);
   double h[32];
   HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));

@@ -1465,11 +1465,21 @@ k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict
       if (MODE == MODE_QGC) {
         qw = ok ? c_hat[idx] : cmake(0, 0);
         if (bud_part && ok) {
-          const double wgt = (kg == 0 || kg == N / 2) ? 1.0 : 2.0;
+          // ep_c = -2 nu4c mean(lap c ^2) - 2 nu gradC2 - 2 muc C2 (ref QGModel.py:595-598): C2, gradC2 are spec_var sums of
+          // c-hat as it is; mean(lap c ^2) is a physical-space mean and sees only the Hermitian part (in l) of the two
+          // self-mirrored columns -- column nx/2 of c-hat picks up an anti-Hermitian part from the ik term of its Jacobian
+          const bool special = (kg == 0 || kg == N / 2);
+          const double wgt = special ? 1.0 : 2.0;
           const double m2 = wgt * (qw.x * qw.x + qw.y * qw.y);
+          double m2h = m2;
+          if (special) {
+            const cd cm = c_hat[(size_t)((N - l) % N) * g.pitch_s + k];
+            const double hx = 0.5 * (qw.x + cm.x), hy = 0.5 * (qw.y - cm.y);
+            m2h = hx * hx + hy * hy;
+          }
           sc[0] += (l == 0 && kg == 0) ? 0.0 : m2;
           sc[1] += wv2 * m2;
-          sc[2] += wv2 * wv2 * m2;
+          sc[2] += wv2 * wv2 * m2h;
         }
       }
     }

@@ -20,7 +20,7 @@ import ctypes
 
 import numpy as np
 
-from . import _lib
+from . import _etdrk4, _lib
 
 (PH_PRODUCTS, PH_UPDATE, PH_WAVEPV, PH_INVERT, PH_EMIT_PHI, PH_INVERT_NOW, PH_BUDGET_SUMS,
  PH_BUDGET_FINISH) = range(8)
@@ -78,6 +78,12 @@ class SlabRank(object):
         info = (ctypes.c_int * 8)()
         self.L.nq_slab_info(self.h, info)
         (_, _, self.nloc, self.wf, self.kf0, self.wh, self.kh0, self.ph) = list(info)
+        # this rank's columns of the contour-adjacent ETDRK4 entries, recomputed as the reference computes them (_etdrk4.py)
+        prm = {k: float(getattr(p, k)) for k in ("U", "f", "kappa2", "nu", "nu4", "mu", "nuw", "nu4w", "muw", "beta", "nu4c", "nuc", "muc")}
+        eqs = [0] + ([1] if model != _lib.QG else []) + ([2] if p.passive_scalar else [])
+        self.contour_patched = _etdrk4.patch_near_contour(
+            lambda eq, delta: _lib.coeff_near_contour(self.L, self.h, eq, delta),
+            lambda eq, li, ki, v: _lib.coeff_patch(self.L, self.h, eq, li, ki, v), model, self.nx, kk, ll, filtr, dt, prm, eqs)
         if torch_buffers and model == _lib.YBJ and nranks > 1:          # the stage-result group of YBJModel's step
             n = self.L.nq_group_elems(ctypes.byref(p), nranks, 4)
             self.gx[4] = torch.zeros(n, dtype=torch.complex128, device=dev)

@@ -111,11 +111,13 @@ def etdrk4_tables(c: np.ndarray, dt: float, rows_per_chunk: int = 64, workers: i
         LR = ch[sl, :, None] + r[None, None, :]
         LR2 = LR * LR
         LR3 = LR2 * LR
-        eLR = np.exp(LR)
-        out["Q"][sl] = dt * ((np.exp(LR / 2.0) - 1.0) / LR).mean(axis=-1)
-        out["f0"][sl] = dt * ((-4.0 - LR + eLR * (4.0 - 3.0 * LR + LR2)) / LR3).mean(axis=-1)
-        out["fab"][sl] = dt * ((2.0 + LR + eLR * (-2.0 + LR)) / LR3).mean(axis=-1)
-        out["fc"][sl] = dt * ((-4.0 - 3.0 * LR - LR2 + eLR * (4.0 - LR)) / LR3).mean(axis=-1)
+        # np.exp(LR) is written out in every line, as the reference writes it: with the exponential held in a variable numpy
+        # picks a different multiply loop (operand aliasing), the products differ in the last bit, and next to the contour
+        # (|LR| ~ 1e-5, where these means are eps / |LR|^3 rounding noise) that is a 1e-7 relative difference in f0
+        out["Q"][sl] = dt * (((np.exp(LR / 2.) - 1.) / LR).mean(axis=-1))
+        out["f0"][sl] = dt * (((-4. - LR + (np.exp(LR) * (4. - 3. * LR + LR2))) / LR3).mean(axis=-1))
+        out["fab"][sl] = dt * (((2. + LR + np.exp(LR) * (-2. + LR)) / LR3).mean(axis=-1))
+        out["fc"][sl] = dt * (((-4. - 3. * LR - LR2 + np.exp(LR) * (4. - LR)) / LR3).mean(axis=-1))
 
     starts = range(0, ch.shape[0], rows_per_chunk)
     if workers > 1:                 # numpy ufuncs release the GIL: row chunks in parallel, same arithmetic per element

@@ -27,6 +27,11 @@ Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
   g12_coupled_2048_10steps.npz  the REAL reference, CoupledModel 2048^2, the same white-noise state and parameters as g11's
                           coupled case, after 5 and 10 steps: projections, sub-samples, norms, budgets (round 3; ~8 minutes
                           and 16 GB here; not in the default list)
+  g13_contour_entries.npz the REAL reference where its ETDRK4 planes are ill-conditioned: two configurations with U = 0 (real q
+                          operator) whose c dt comes within 3e-5 of the contour point -1, found by the randomized parity
+                          test.  Qh, f0, fab, fc at every entry within 0.05 of the contour (there the reference's value is
+                          numpy's rounding error times eps / distance^3), and for the 256^2 CoupledModel (2/3-rule
+                          dealiasing, inviscid waves) q and phi after 6 steps from seeded white noise, which feeds them
 """
 import os
 import sys
@@ -388,6 +393,48 @@ def g12():
         out[tag + "budgets"] = np.array([m.Ke, m.Pw, m.Kw])
         print("g12: step", n, "done", flush=True)
     save("g12_coupled_2048_10steps.npz", **out)
+
+
+def contour_entries(model, names, ch, tag, out, delta=0.05):
+    r = np.exp(2j * np.pi * (np.arange(1., 33.) / 32.))
+    dist = np.abs(ch[..., None] + r).min(axis=-1)
+    li, ki = np.nonzero(dist < delta)
+    out[tag + "l"], out[tag + "k"], out[tag + "dist"] = li.astype(np.int32), ki.astype(np.int32), dist[li, ki]
+    for nm in names:
+        out[tag + nm] = getattr(model, nm)[li, ki]
+    print("g13:", tag, len(li), "entries within", delta, "closest", dist.min(), flush=True)
+
+
+def g13():
+    out = {}
+    # (a) QGModel 512^2, exponential filter, U = 0, beta, nu = mu = 0 (seed 140 of the randomized parity test)
+    kw = dict(L=L, nx=512, tmax=1e30, dt=625.0, twrite=10 ** 9, tdiags=10 ** 9, use_filter=True, dealias=False, U=0.0,
+              nu4=1887323331.1493955, nu=0.0, mu=0.0, beta=2e-11, save_to_disk=False)
+    m = QGModel.Model(**kw)
+    c = np.zeros((m.nl, m.nk), complex)
+    c += -m.nu4 * m.wv4 - m.nu * m.wv2 - m.mu - 1j * m.k * m.U
+    c += m.beta * m.ik * m.wv2i
+    contour_entries(m, ("Qh", "f0", "fab", "fc"), c * m.dt, "qg_", out)
+    rng = np.random.default_rng(13)
+    m.set_q(1e-5 * rng.standard_normal((512, 512)))
+    step_to(m, 6)
+    out["qg_q6_proj"], out["qg_q6_sub"], out["qg_q6_norm"] = projections(m.q, 401), m.q[::8, ::8].copy(), np.linalg.norm(m.q)
+    out["qg_qh6_proj"] = projections(m.qh, 402)
+    # (b) CoupledModel 256^2, 2/3-rule mask, U = 0, no wave dissipation but muw (seed 42 of the same test)
+    kw = dict(L=L, nx=256, tmax=1e30, dt=1250.0, twrite=10 ** 9, tdiags=10 ** 9, use_filter=False, dealias=True, U=0.0,
+              nu4=48273918940.97328, nu=20.0, mu=1e-8, nuw=0.0, nu4w=0.0, muw=2e-8, m=MZ, N=NB, f=F0, save_to_disk=False)
+    m = CoupledModel.Model(**kw)
+    cq = np.zeros((m.nl, m.nk), complex) - 1j * m.k * m.U
+    cq += -m.nu4 * m.wv4 - m.nu * m.wv2 - m.mu
+    contour_entries(m, ("Qh", "f0", "fab", "fc"), cq * m.dt, "cq_", out)
+    contour_entries(m, ("Qhw", "f0w", "fabw", "fcw"), m.c * m.dt, "cw_", out)      # the reference leaves the wave operator in m.c
+    rng = np.random.default_rng(14)
+    m.set_q(1e-5 * rng.standard_normal((256, 256)))
+    m.set_phi(0.05 * (rng.standard_normal((256, 256)) + 1j * rng.standard_normal((256, 256))))
+    step_to(m, 6)
+    out["c_q6"], out["c_phi6"] = m.q.copy(), m.phi.copy()
+    out["c_budgets"] = np.array([m.Ke, m.Pw, m.Kw])
+    save("g13_contour_entries.npz", **out)
 
 
 if __name__ == "__main__":

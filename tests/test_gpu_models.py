@@ -766,3 +766,107 @@ def test_malformed_and_degenerate_inputs(slab):
         for nx in (96, 32, 16384):
             with pytest.raises(RuntimeError):
                 M.CoupledModel.Model(**notebook_kwargs(nx, True))
+
+
+def test_contour_adjacent_etdrk4_entries_against_the_reference_itself(golden):
+    """Golden g13 (the REAL reference on the two U = 0 configurations the randomized test below tripped over): the device's
+    Qh, f0, fab, fc at every entry within 0.05 of the contour are the reference's bit for bit (QGModel; CoupledModel's phi
+    planes) or the Hermitian combination the half-plane q advances with (test_oracle_golden.g13_half_plane_q_values), and six
+    steps from white noise -- which puts energy into exactly those modes -- agree with the reference to 1e-11.  Without
+    nq_coeff_patch (NIWQG_AMD_CONTOUR_PATCH=0) the coupled case is off by 3e-5."""
+    import niwqg_amd as M
+    from test_oracle_golden import G13_QG, G13_COUPLED, G13_NAMES, g13_half_plane_q_values
+    g = golden("g13_contour_entries.npz")
+    m = M.QGModel.Model(**G13_QG)
+    li, ki = g["qg_l"].astype(int), g["qg_k"].astype(int)
+    assert m._ctx.contour_patched[0] == len(li)
+    for nm, _ in G13_NAMES:
+        assert np.array_equal(getattr(m, nm)[li, ki], g["qg_" + nm]), nm
+    m.set_q(1e-5 * np.random.default_rng(13).standard_normal((512, 512)))
+    for _ in range(6):
+        m._step_forward()
+    assert rel(m.q[::8, ::8], g["qg_q6_sub"]) < 1e-11
+    assert abs(np.linalg.norm(m.q) - float(g["qg_q6_norm"])) < 1e-11 * float(g["qg_q6_norm"])
+
+    c = M.CoupledModel.Model(**G13_COUPLED)
+    lw, kw_ = g["cw_l"].astype(int), g["cw_k"].astype(int)
+    for nm, _ in G13_NAMES:
+        assert np.array_equal(getattr(c, nm + "w")[lw, kw_], g["cw_" + nm + "w"]), nm
+    li, ki, want = g13_half_plane_q_values(g, np.asarray(c.filtr), 256)
+    assert c._ctx.contour_patched == {0: len(li), 1: len(lw)}
+    for j, (nm, _) in enumerate(G13_NAMES):
+        assert np.array_equal(getattr(c, nm)[li, ki], want[:, j]), nm
+    rng = np.random.default_rng(14)
+    c.set_q(1e-5 * rng.standard_normal((256, 256)))
+    c.set_phi(0.05 * (rng.standard_normal((256, 256)) + 1j * rng.standard_normal((256, 256))))
+    for _ in range(6):
+        c._step_forward()
+    print("g13 coupled 256^2, six steps vs the reference: q %.2e phi %.2e" % (rel(c.q, g["c_q6"]), rel(c.phi, g["c_phi6"])))
+    assert rel(c.q, g["c_q6"]) < 1e-11 and rel(c.phi, g["c_phi6"]) < 1e-11
+    assert np.allclose([c.Ke, c.Pw, c.Kw], g["c_budgets"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("NQ_FUZZ_SEEDS", "36")))))
+def test_randomly_drawn_configurations_against_the_oracle(seed):
+    """Seeded draws over what the constructors accept -- model class, grid (64..512: two-pass tiles, single-pass columns and the
+    array-parallel QG kernel all occur), filter / 2-3 mask / none, mean flow, every dissipation coefficient, beta, the passive scalar,
+    the diagnostics cadence (quirk Q1 acts through it) -- white-noise plus large-scale initial fields, 6 steps through
+    _step_forward, against the reference-pinned oracle: fields 1e-11, budgets 1e-8, and every diagnostics series the tick recorded."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["coupled", "uncoupled", "qg", "ybj", "coupled", "qg"][seed % 6]
+    nx = int(rng.choice([64, 128, 256, 512] if kind != "coupled" else [64, 128, 256]))
+    filt = int(rng.integers(0, 3))                     # 0: exponential filter, 1: the 2/3 mask, 2: nothing
+    if kind == "qg" and filt == 1:
+        filt = 0                                      # QGModel(dealias=True) raises TypeError, like the reference
+    dt = 0.025 * TE * 128 / nx * float(rng.choice([0.5, 1.0]))
+    tdiags = int(rng.choice([1, 2, 10 ** 9]))
+    kw = dict(L=L, nx=nx, tmax=1e30, dt=dt, twrite=10 ** 9, tdiags=tdiags, use_filter=filt == 0, dealias=filt == 1,
+              U=float(rng.choice([0.0, -U0, 0.5 * U0])), nu4=5e11 * (128.0 / nx) ** 4 * float(rng.uniform(0.2, 2.0)),
+              nu=float(rng.choice([0.0, 20.0])), mu=float(rng.choice([0.0, 1e-8])))
+    mods = models()
+    if kind == "qg":
+        passive = bool(rng.integers(0, 2))
+        kw.update(beta=float(rng.choice([0.0, 2e-11])), passive_scalar=passive, nu4c=kw["nu4"] * 0.5, nuc=2.0, muc=1e-8)
+        m, o = mods.QGModel.Model(**kw), O.QGOracle(**kw)
+    else:
+        kw.update(m=MZ, N=NB, f=F0, nuw=float(rng.choice([0.0, 50.0])), nu4w=float(rng.choice([0.0, 0.1])) * kw["nu4"],
+                  muw=float(rng.choice([0.0, 2e-8])))
+        cls = {"coupled": mods.CoupledModel, "uncoupled": mods.UnCoupledModel, "ybj": mods.YBJModel}[kind]
+        m, o = cls.Model(**kw), O.NIWQGOracle(kind, **kw)
+    q0 = O.lamb_dipole(o.grid, U=U0, R=2 * np.pi / K0) + 2e-6 * rng.standard_normal((nx, nx))
+    for x in (m, o):
+        x.set_q(q0)
+    if kind != "qg":
+        phi0 = 0.1 * O.wave_packet(o.grid, k=2 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2) + 0.02 * (
+            rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx)))
+        for x in (m, o):
+            x.set_phi(phi0)
+    elif kw["passive_scalar"]:
+        c0 = 1.0 + 0.3 * rng.standard_normal((nx, nx))
+        for x in (m, o):
+            x.set_c(c0)
+    for _ in range(6):
+        o._step_forward()
+    steps(m, 6)
+    tag = "%s %d filt=%d tdiags=%g" % (kind, nx, filt, tdiags)
+    tol = 1e-10       # BASELINE's bar; the draws hit the |c dt| ~ 1 shell of the contour-mean planes (DESIGN.md section 6: 1e-11)
+    if kind != "ybj":
+        assert rel(m.q, o.q) < tol and rel(m.qh, o.qh) < tol, tag
+    if kind != "qg":
+        assert rel(m.phi, o.phi) < tol and rel(m.phih, o.phih) < tol, tag
+        if kind != "ybj":
+            assert np.allclose([m.Ke, m.Pw, m.Kw], [o.Ke, o.Pw, o.Kw], rtol=1e-8, atol=1e-30), tag
+    else:
+        assert abs(m.Ke - o.Ke) <= 1e-9 * abs(o.Ke), tag
+        if kw["passive_scalar"]:
+            assert rel(m.c, o.c) < tol, tag
+    for name in o.diagnostics:
+        if name not in m.diagnostics:
+            continue
+        a = np.atleast_1d(np.asarray(m.diagnostics[name]["value"], float))       # (one entry: a scalar, as in the reference)
+        b = np.atleast_1d(np.asarray(o.diag(name), float))
+        assert a.shape == b.shape, (tag, name)
+        if name in ("skew", "conc_niw", "Gamma_c", "pi", "gamma_r", "gamma_a", "xi_r", "xi_a"):
+            continue        # nearly vanishing / cancellation-prone integrals: pinned with their own tolerances elsewhere
+        scale = np.abs(b).max() if b.size else 0.0
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * scale + 1e-300), (tag, name, a, b)

@@ -294,3 +294,76 @@ def test_oracle_against_the_reference_at_2048(golden):
     assert est < 1e-13
     assert rel(o.q[::32, ::32], g["qg_q_sub"]) < 1e-13
     assert abs(o.Ke - float(g["qg_Ke"])) < 1e-12 * abs(float(g["qg_Ke"]))
+
+
+# ---- golden g13: the REAL reference where its contour means are rounding noise (make_golden.py g13) ----------------------------
+G13_QG = dict(L=L, nx=512, tmax=1e30, dt=625.0, twrite=10 ** 9, tdiags=10 ** 9, use_filter=True, dealias=False, U=0.0,
+              nu4=1887323331.1493955, nu=0.0, mu=0.0, beta=2e-11)
+G13_COUPLED = dict(L=L, nx=256, tmax=1e30, dt=1250.0, twrite=10 ** 9, tdiags=10 ** 9, use_filter=False, dealias=True, U=0.0,
+                   nu4=48273918940.97328, nu=20.0, mu=1e-8, nuw=0.0, nu4w=0.0, muw=2e-8, m=2 * np.pi / 280.0, N=NB, f=F0)
+G13_NAMES = (("Qh", "Q"), ("f0", "f0"), ("fab", "fab"), ("fc", "fc"))
+
+
+def g13_half_plane_q_values(g, filtr, nx):
+    """What the Hermitian part of the reference's full-plane q advances with at the contour-adjacent entries of the half plane
+    k <= nx/2: the mean of F(l, k) and conj F(-l, -k), or the surviving mode's own coefficient where the 2/3-rule mask keeps
+    only one of the two (niwqg_amd/_etdrk4.py).  Returns l, k and an (n, 4) array (Qh, f0, fab, fc)."""
+    li, ki = g["cq_l"].astype(int), g["cq_k"].astype(int)
+    table = {(int(l), int(k)): i for i, (l, k) in enumerate(zip(li, ki))}
+    F = np.stack([g["cq_" + nm] for nm, _ in G13_NAMES], axis=-1)
+    keep = np.nonzero(ki <= nx // 2)[0]
+    out = np.empty((len(keep), 4), complex)
+    for n, i in enumerate(keep):
+        lm, km = (nx - li[i]) % nx, (nx - ki[i]) % nx
+        Fm = np.conj(F[table[(lm, km)]])        # a contour-adjacent entry's mirror image is one as well
+        fp, fm = filtr[li[i], ki[i]], filtr[lm, km]
+        out[n] = (fp * F[i] + fm * Fm) / (fp + fm) if (fp != fm) else 0.5 * (F[i] + Fm)
+    return li[keep], ki[keep], out
+
+
+def test_contour_adjacent_etdrk4_entries_are_the_references_bit_for_bit(golden):
+    """Where c dt sits next to a contour point the reference's Qh, f0, fab, fc are numpy's rounding error times eps / d^3 (f0 off
+    by O(1) at d ~ 1e-6): only the same numpy expression reproduces them.  The oracle's planes and the host recomputation of
+    the product (niwqg_amd/_etdrk4.py, which the device takes these entries from) against the reference's own values, bit for
+    bit, for QGModel 512^2 (2911 entries within 0.05, closest 3e-5) and CoupledModel 256^2 (q: 828, closest 2e-6; phi: 145)."""
+    from niwqg_amd import _etdrk4
+    g = golden("g13_contour_entries.npz")
+    o = O.QGOracle(**G13_QG)
+    li, ki = g["qg_l"].astype(int), g["qg_k"].astype(int)
+    assert float(g["qg_dist"].min()) < 1e-4
+    host = _etdrk4.contour_tables(_etdrk4.linear_operator(_etdrk4.QG, 0, o.kk[ki], o.ll[li], G13_QG) * G13_QG["dt"], G13_QG["dt"])
+    for j, (nm, key) in enumerate(G13_NAMES):
+        assert np.array_equal(o.coef_q[key][li, ki], g["qg_" + nm]), nm
+        assert np.array_equal(host[:, j], g["qg_" + nm]), nm
+    o.set_q(1e-5 * np.random.default_rng(13).standard_normal((512, 512)))
+    steps(o, 6)
+    assert rel(o.q[::8, ::8], g["qg_q6_sub"]) < 1e-13
+    assert abs(np.linalg.norm(o.q) - float(g["qg_q6_norm"])) < 1e-13 * float(g["qg_q6_norm"])
+
+    c = O.NIWQGOracle("coupled", **G13_COUPLED)
+    prm = dict(G13_COUPLED, kappa2=c.kappa2)
+    for eq, tag, co in ((0, "cq_", c.coef_q), (1, "cw_", c.coef_w)):
+        li, ki = g[tag + "l"].astype(int), g[tag + "k"].astype(int)
+        host = _etdrk4.contour_tables(_etdrk4.linear_operator(0, eq, c.kk[ki], c.ll[li], prm) * prm["dt"], prm["dt"])
+        for j, (nm, key) in enumerate(G13_NAMES):
+            ref = g[tag + nm + ("w" if eq else "")]
+            assert np.array_equal(co[key][li, ki], ref), (tag, nm)
+            assert np.array_equal(host[:, j], ref), (tag, nm)
+    # what patch_near_contour hands to the device for the half-plane q of the Kernel family, given the device's list
+    li, ki, want = g13_half_plane_q_values(g, c.filtr, 256)
+    got = {}
+    lw, kw_ = g["cw_l"].astype(int), g["cw_k"].astype(int)
+    counts = _etdrk4.patch_near_contour(lambda eq, delta: (li, ki) if eq == 0 else (lw, kw_),
+                                        lambda eq, l, k, v: got.__setitem__(eq, (l, k, v)), 0, 256, c.kk, c.ll, c.filtr, prm["dt"], prm, [0, 1])
+    assert counts == {0: len(li), 1: len(lw)}
+    order = np.lexsort((ki, li))
+    assert np.array_equal(got[0][0], li[order]) and np.array_equal(got[0][1], ki[order])
+    assert np.array_equal(got[0][2], want[order])
+    order = np.lexsort((kw_, lw))
+    assert np.array_equal(got[1][2], np.stack([g["cw_" + nm + "w"] for nm, _ in G13_NAMES], axis=-1)[order])
+    rng = np.random.default_rng(14)
+    c.set_q(1e-5 * rng.standard_normal((256, 256)))
+    c.set_phi(0.05 * (rng.standard_normal((256, 256)) + 1j * rng.standard_normal((256, 256))))
+    steps(c, 6)
+    assert rel(c.q, g["c_q6"]) < 1e-13 and rel(c.phi, g["c_phi6"]) < 1e-13
+    assert np.allclose([c.Ke, c.Pw, c.Kw], g["c_budgets"], rtol=1e-10)

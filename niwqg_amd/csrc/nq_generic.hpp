@@ -67,9 +67,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char nq_smem[];
 // Sum NV per-thread values over the workgroup and let thread 0 store them at dst[0..NV) (one slot per
 // workgroup: deterministic, no atomics; a later kernel adds the slots up).  `scratch` = 512 B of LDS.
 template <int NV>
-__device__ __forceinline__ void block_sum_thread0(double (&vals)[NV], double* scratch) {
+__device__ __forceinline__ void block_sum_thread0(double (&vals)[NV], double* scratch, int tid) {
   static_assert(NV <= 4, "scratch holds 16 waves x 4 values");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
   const int live = (int)blockDim.x - (wave << 6);        // lanes of this wave that exist (blocks of 32)
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -87,7 +87,7 @@ __device__ __forceinline__ void block_sum_thread0(double (&vals)[NV], double* sc
     for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = vals[i];
   }
   wg_barrier();
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       double x = 0.0;
@@ -97,12 +97,22 @@ __device__ __forceinline__ void block_sum_thread0(double (&vals)[NV], double* sc
   }
 }
 template <int NV>
-__device__ __forceinline__ void block_sum_store(double (&vals)[NV], double* scratch, double* __restrict__ dst) {
-  block_sum_thread0<NV>(vals, scratch);
-  if (threadIdx.x == 0) {
+__device__ __forceinline__ void block_sum_thread0(double (&vals)[NV], double* scratch) {
+  block_sum_thread0<NV>(vals, scratch, (int)threadIdx.x);
+}
+// tid: the caller's copy of threadIdx.x (the even/odd row kernels pass a laundered one, so that the wave's scratch address is
+// formed where it is used instead of being held -- or spilled -- across the whole row loop)
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&vals)[NV], double* scratch, double* __restrict__ dst, int tid) {
+  block_sum_thread0<NV>(vals, scratch, tid);
+  if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) dst[i] = vals[i];
   }
+}
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&vals)[NV], double* scratch, double* __restrict__ dst) {
+  block_sum_store<NV>(vals, scratch, dst, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------- x direction, generic

@@ -66,6 +66,20 @@ __device__ __forceinline__ XRowT<SLAB> xrow(const MArr& a, size_t row) {
   }
   return r;
 }
+// The same, with the block geometry (W, shift, magic) read from another array of the same width class: a kernel that walks
+// ten arrays then holds two copies of it in SGPRs instead of ten (the slab instantiation of k_x_products_eo spilled 41 SGPRs).
+template <bool SLAB>
+__device__ __forceinline__ XRowT<SLAB> xrow(const MArr& a, const MArr& geom, size_t row) {
+  XRowT<SLAB> r;
+  r.p = a.xs + row * (size_t)a.pitch;
+  if constexpr (SLAB) {
+    r.W = geom.W;
+    r.shift = geom.shift;
+    r.magic = geom.magic;
+    r.blk = a.blk;
+  }
+  return r;
+}
 // Column-slab geometry of the spectral (Y-side) kernels.
 struct YGeom {
   int k0;            // global column index of local column 0
@@ -326,8 +340,10 @@ k_x_wavepv2(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw, 
     }
     unsigned long long* mx = reinterpret_cast<unsigned long long*>(twl + F::TW_LDS_ELEMS) + 2 * c;
     if (j == 0) {
-      mx[0] = 0ull;
-      mx[1] = 0ull;
+      unsigned long long zero = 0ull;                    // formed here: held across the loop it is four VGPRs of zeros, spilled
+      asm volatile("" : "+v"(zero));
+      mx[0] = zero;
+      mx[1] = zero;
     }
     wg_barrier();
     row_atomic_max<T>(mx, ma, mb);
@@ -408,8 +424,10 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
     }
     unsigned long long* mx = reinterpret_cast<unsigned long long*>(nq_smem + X::LDS_BYTES - 512) + 2 * c;
     if (j == 0) {
-      mx[0] = 0ull;
-      mx[1] = 0ull;
+      unsigned long long zero = 0ull;                    // formed here: held across the loop it is four VGPRs of zeros, spilled
+      asm volatile("" : "+v"(zero));
+      mx[0] = zero;
+      mx[1] = zero;
     }
     wg_barrier();
     row_atomic_max<T>(mx, ma, mb);
@@ -650,7 +668,6 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
   typedef typename X::F F;
   constexpr int P = X::P, T = X::T;
   static_assert(X::C == 1 && P == 8, "one row per workgroup, 8 points per thread (w^(T t) = 16th roots of unity)");
-  const int j_tid = threadIdx.x;
   cd* lds = reinterpret_cast<cd*>(nq_smem);                             // [exchange][stage twiddles][park][red]
   cd* twl = lds + F::LDS_ELEMS;
   double* park = reinterpret_cast<double*>(twl + F::TW_LDS_ELEMS);      // [2][M] doubles, thread-private slots
@@ -658,19 +675,19 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
   for (int i = threadIdx.x; i < F::TW_LDS_ELEMS; i += X::THREADS) twl[i] = tw[i];
   typename F::TwLds twr;
   twr.base = twl;
-  cd wj_tid;
-  {
-    const cd z = wglob[j_tid];                           // global table holds exp(-2 pi i m / N2)
-    wj_tid = cmake(z.x, -z.y);
-  }
   wg_barrier_all();
   constexpr bool PAIRQ = (MODE == MODE_COUPLED || MODE == MODE_QGC);
   constexpr bool ONLYQ = (MODE == MODE_QG || MODE == MODE_QGC);
   for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
     // per-iteration copies the compiler cannot see through (loop-invariant addresses would be hoisted and spill)
-    int j = j_tid, c = 0;
-    cd wj = wj_tid;
-    asm volatile("" : "+v"(j), "+v"(c), "+v"(wj.x), "+v"(wj.y));
+    int j = threadIdx.x, c = 0;
+    asm volatile("" : "+v"(j), "+v"(c));
+    cd wj;                                               // w^j, re-read per row (a cache hit) instead of held across the loop:
+    {                                                    // four loop-invariant VGPRs less is what keeps the kernel out of scratch
+      const cd z = wglob[j];                             // global table holds exp(-2 pi i m / N2)
+      wj = cmake(z.x, -z.y);
+    }
+    asm volatile("" : "+v"(wj.x), "+v"(wj.y));
     const size_t row = (size_t)rb;
     cd we[P], wo[P];
     double qe[P], qo[P];
@@ -678,7 +695,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
     if constexpr (MODE == MODE_QGC) {
       // q and the passive scalar share one complex transform; c has arbitrary units: rescale it per row by a power of two
       // (k_x_products does the same).  One extra sweep over the two rows (they are re-read from cache by the fold).
-      const XRowT<SLAB> ra = xrow<SLAB>(Mq, row), rbw = xrow<SLAB>(Mqw, row);
+      const XRowT<SLAB> ra = xrow<SLAB>(Mq, Mq, row), rbw = xrow<SLAB>(Mqw, Mq, row);
       double ma = 0.0, mb = 0.0;
 #pragma unroll
       for (int t = 0; t < P; ++t) {
@@ -709,7 +726,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       wg_barrier();
     }
     // ---- phase 1: (q, qw | c) -> q, q_psi of both parities
-    eo_fold_pair2<M, P, T, PAIRQ>(we, wo, xrow<SLAB>(Mq, row), xrow<SLAB>(PAIRQ ? Mqw : Mq, row), j, wj, kk, false, false, c_scale);
+    eo_fold_pair2<M, P, T, PAIRQ>(we, wo, xrow<SLAB>(Mq, Mq, row), xrow<SLAB>(PAIRQ ? Mqw : Mq, Mq, row), j, wj, kk, false, false, c_scale);
     NQ_EO_FENCE();
     F::template run<true>(we, j, c, lds, twr);
 #pragma unroll
@@ -728,7 +745,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
     }
     // ---- phase 2: (u, v) = ifft of (-il psi, ik psi); u q + i v q of both parities -> Muq, Mvq
     NQ_EO_FENCE();
-    eo_fold_pair2<M, P, T, true>(we, wo, xrow<SLAB>(Mu, row), xrow<SLAB>(Mp, row), j, wj, kk, true, v_zero_nyq != 0, 1.0);
+    eo_fold_pair2<M, P, T, true>(we, wo, xrow<SLAB>(Mu, Mq, row), xrow<SLAB>(Mp, Mq, row), j, wj, kk, true, v_zero_nyq != 0, 1.0);
     NQ_EO_FENCE();
     F::template run<true>(we, j, c, lds, twr);
     double ue[P], ve[P], uo[P], vo[P];
@@ -751,7 +768,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
     NQ_EO_FENCE();
     F::template run<false>(wo, j, c, lds, twr);
     NQ_EO_FENCE();
-    eo_unpack_pair_store2<M, P, T, F>(we, wo, j, c, lds, wj, xrow<SLAB>(Muq, row), xrow<SLAB>(Mvq, row));
+    eo_unpack_pair_store2<M, P, T, F>(we, wo, j, c, lds, wj, xrow<SLAB>(Muq, Mq, row), xrow<SLAB>(Mvq, Mq, row));
     if constexpr (ONLYQ) {
       if constexpr (MODE == MODE_QGC) {          // second packed pair (u c, v c) -> Mgx, Mgy (= the Muc, Mvc arrays)
 #pragma unroll
@@ -765,7 +782,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
         NQ_EO_FENCE();
         F::template run<false>(wo, j, c, lds, twr);
         NQ_EO_FENCE();
-        eo_unpack_pair_store2<M, P, T, F>(we, wo, j, c, lds, wj, xrow<SLAB>(Mgx, row), xrow<SLAB>(Mgy, row));
+        eo_unpack_pair_store2<M, P, T, F>(we, wo, j, c, lds, wj, xrow<SLAB>(Mgx, Mq, row), xrow<SLAB>(Mgy, Mq, row));
       }
       continue;
     } else {
@@ -774,7 +791,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       cd x1[P], x2[P], je[P], jo[P];
       double js[2] = {0.0, 0.0};
       // ---- phase 3: phiy, times v
-      eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mgy, row), j);
+      eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mgy, Mgy, row), j);
       NQ_EO_FENCE();
       eo_fold_regs<M, P, T>(je, x1, x2, j, 0, wj, kk, false);
       eo_fold_regs<M, P, T>(jo, x1, x2, j, 1, wj, kk, false);
@@ -788,7 +805,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       for (int t = 0; t < P; ++t) jo[t] = cscale(jo[t], vo[t]);
       // ---- phase 4: phix = ifft(ik g), times u.  Coupled: g is the phi row itself.
       NQ_EO_FENCE();
-      eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(MODE == MODE_COUPLED ? Mphi : Mgx, row), j);
+      eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(MODE == MODE_COUPLED ? Mphi : Mgx, Mgy, row), j);
       NQ_EO_FENCE();
       eo_fold_regs<M, P, T>(we, x1, x2, j, 0, wj, kk, true);
       NQ_EO_FENCE();
@@ -815,7 +832,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       NQ_EO_FENCE();
       // Coupled: phi's raw row is still in x1, x2 (one read serves phix and phi; folding one parity at a time from the held row
       // needs 36 B/lane of scratch, re-reading the row and folding both parities at once 84-296)
-      if constexpr (MODE != MODE_COUPLED) eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, row), j);
+      if constexpr (MODE != MODE_COUPLED) eo_load_full<M, P, T>(x1, x2, xrow<SLAB>(Mphi, Mgy, row), j);
       NQ_EO_FENCE();
       eo_fold_regs<M, P, T>(we, x1, x2, j, 0, wj, kk, false);
       eo_fold_regs<M, P, T>(wo, x1, x2, j, 1, wj, kk, false);
@@ -840,7 +857,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       F::template run<false>(jo, j, c, lds, twr);
       NQ_EO_FENCE();
       {
-        const XRowT<SLAB> rp = xrow<SLAB>(Mw, row);
+        const XRowT<SLAB> rp = xrow<SLAB>(Mw, Mgy, row);
 #pragma unroll
         for (int t = 0; t < P; ++t) {
           const int k = j + t * T;
@@ -852,7 +869,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       }
       // sum of the Jacobian part over this row -> passenger slot of the row (padding column Muq.W of block 0)
       NQ_EO_FENCE();
-      block_sum_store<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)rb * Muq.pitch + Muq.W));
+      block_sum_store<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)rb * Muq.pitch + Muq.W), j);
     }
   }
 }
@@ -867,7 +884,6 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
   typedef typename X::F F;
   constexpr int P = X::P, T = X::T;
   static_assert(X::C == 1 && P == 8, "one row per workgroup, 8 points per thread");
-  const int j_tid = threadIdx.x;
   cd* lds = reinterpret_cast<cd*>(nq_smem);
   cd* twl = lds + F::LDS_ELEMS;
   cd* park = twl + F::TW_LDS_ELEMS;                        // [M] complex, thread-private slots: phix of the odd parity
@@ -875,16 +891,16 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
   for (int i = threadIdx.x; i < F::TW_LDS_ELEMS; i += X::THREADS) twl[i] = tw[i];
   typename F::TwLds twr;
   twr.base = twl;
-  cd wj_tid;
-  {
-    const cd z = wglob[j_tid];
-    wj_tid = cmake(z.x, -z.y);
-  }
   wg_barrier_all();
   for (int rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-    int j = j_tid, c = 0;
-    cd wj = wj_tid;
-    asm volatile("" : "+v"(j), "+v"(c), "+v"(wj.x), "+v"(wj.y));
+    int j = threadIdx.x, c = 0;
+    asm volatile("" : "+v"(j), "+v"(c));
+    cd wj;                                               // w^j, re-read per row (a cache hit) instead of held across the loop:
+    {                                                    // four loop-invariant VGPRs less is what keeps the kernel out of scratch
+      const cd z = wglob[j];                             // global table holds exp(-2 pi i m / N2)
+      wj = cmake(z.x, -z.y);
+    }
+    asm volatile("" : "+v"(wj.x), "+v"(wj.y));
     const size_t row = (size_t)rb;
     cd we[P], wo[P], ge[P];
     double ae[P], ao[P];
@@ -946,8 +962,10 @@ k_x_wavepv_eo(MArr Mphi, MArr Mphiy, MArr Ma, MArr Mb, const cd* __restrict__ tw
     }
     // |phi|^2 is typically 1e8 times J(phi*, phi): the second field is rescaled per row by a power of two (k_x_wavepv)
     if (j == 0) {
-      mx[0] = 0ull;
-      mx[1] = 0ull;
+      unsigned long long zero = 0ull;                    // formed here: held across the loop it is four VGPRs of zeros, spilled
+      asm volatile("" : "+v"(zero));
+      mx[0] = zero;
+      mx[1] = zero;
     }
     wg_barrier();
     row_atomic_max<T>(mx, ma, mb);

@@ -392,3 +392,23 @@ def test_qg_passive_scalar_on_four_slabs_equals_the_whole_plane_model():
     for name in w.diagnostics:
         a, b = np.asarray(s.diagnostics[name]['value']), np.asarray(w.diagnostics[name]['value'])
         assert np.allclose(a, b, rtol=1e-7 if name == "Gamma_c" else 1e-10, atol=1e-30), name
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_contour_adjacent_entries_are_patched_on_every_slab_rank(golden, P):
+    """Golden g13 (the REAL reference, CoupledModel 256^2 with the 2/3 mask, U = 0: c dt within 2e-6 of the ETDRK4 contour) on P
+    slab ranks: each rank lists and patches its own columns (nq_coeff_near_contour with global column indices), all of the
+    list is covered once, and six steps from white noise match the reference as the single context does."""
+    import niwqg_amd
+    from test_oracle_golden import G13_COUPLED, g13_half_plane_q_values
+    g = golden("g13_contour_entries.npz")
+    m = niwqg_amd.CoupledModel.Model(slab=P, **G13_COUPLED)
+    li, _, _ = g13_half_plane_q_values(g, np.asarray(m.filtr), 256)
+    counts = [r.contour_patched for r in m._ctx.sim.ranks]
+    assert sum(c[0] for c in counts) == len(li) and sum(c[1] for c in counts) == len(g["cw_l"])
+    rng = np.random.default_rng(14)
+    m.set_q(1e-5 * rng.standard_normal((256, 256)))
+    m.set_phi(0.05 * (rng.standard_normal((256, 256)) + 1j * rng.standard_normal((256, 256))))
+    for _ in range(6):
+        m._step_forward()
+    assert rel(m.q, g["c_q6"]) < 1e-11 and rel(m.phi, g["c_phi6"]) < 1e-11

@@ -115,6 +115,49 @@ __device__ __forceinline__ void block_sum_store(double (&vals)[NV], double* scra
   block_sum_store<NV>(vals, scratch, dst, (int)threadIdx.x);
 }
 
+// The same for workgroups made of FULL waves (every row plan), with the in-wave sum on DPP lane permutations instead of
+// ds_bpermute shuffles: a shuffle needs its source lane's address in a VGPR, six of them per reduction, all loop-invariant --
+// in the persistent row kernels they were hoisted out of the row loop and spilled (the only scratch k_x_products<4096> had).
+template <int CTRL>
+__device__ __forceinline__ double dpp_lanes(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_full(double x) {
+  x += dpp_lanes<0xB1>(x);          // quad_perm [1,0,3,2]
+  x += dpp_lanes<0x4E>(x);          // quad_perm [2,3,0,1]
+  x += dpp_lanes<0x141>(x);         // row_half_mirror
+  x += dpp_lanes<0x140>(x);         // row_mirror: every lane of a 16-lane row now holds the row's sum
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    s += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 16 * r), __builtin_amdgcn_readlane(__double2loint(x), 16 * r));
+  return s;                          // the wave's sum, in every lane
+}
+template <int NV>
+__device__ __forceinline__ void block_sum_store_full_waves(double (&vals)[NV], double* scratch, double* __restrict__ dst, int tid) {
+  static_assert(NV <= 4, "scratch holds 16 waves x 4 values");
+  const int wave = tid >> 6, nw = (int)blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) vals[i] = wave_sum_full(vals[i]);
+  wg_barrier();
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = vals[i];
+  }
+  wg_barrier();
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double x = 0.0;
+      for (int w = 0; w < nw; ++w) x += scratch[w * NV + i];
+      dst[i] = x;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- x direction, generic
 // mode 0: complex in (pitch_in) -> complex out; mode 1: multiply input by i*kk[kx] first
 template <int N, bool INV>

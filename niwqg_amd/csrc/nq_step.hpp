@@ -539,7 +539,8 @@ k_x_products(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr Mgy,
   // other rows of a multi-row workgroup stay zero); column Muq.W of block 0 is padding of the half-spectrum row
   NQ_PHASE_FENCE();
   double* red = reinterpret_cast<double*>(nq_smem + X::LDS_BYTES - 512);
-  block_sum_store<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)rb * X::C * Muq.pitch + Muq.W));
+  static_assert(X::THREADS % 64 == 0, "full waves");
+  block_sum_store_full_waves<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)rb * X::C * Muq.pitch + Muq.W), c * T + j);
   }   // row blocks
 }
 
@@ -869,7 +870,7 @@ k_x_products_eo(MArr Mu, MArr Mp, MArr Mq, MArr Mqw, MArr Mphi, MArr Mgx, MArr M
       }
       // sum of the Jacobian part over this row -> passenger slot of the row (padding column Muq.W of block 0)
       NQ_EO_FENCE();
-      block_sum_store<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)rb * Muq.pitch + Muq.W), j);
+      block_sum_store<2>(js, red, reinterpret_cast<double*>(Muq.xs + (size_t)rb * Muq.pitch + Muq.W), j);    // (the DPP variant tips this kernel into 4 dwords of scratch)
     }
   }
 }

@@ -48,8 +48,12 @@ enum {
   NQ_F_QH_MINUS = 13,/* cplx half spectrum conj(qh(-l,-k)), k = 0..nx/2 (dual_q contexts only)                  */
   NQ_F_C = 14,       /* real (ny,nx)       c      passive scalar of QGModel     QGModel.py:403-404               */
   NQ_F_CH = 15,      /* cplx (ny,nx/2+1)   ch                                                                     */
-  NQ_F_QH_STAGE4 = 16 /* cplx half spectrum qh at which the LAST step evaluated its fourth stage: the u, v that QGModel's
+  NQ_F_QH_STAGE4 = 16,/* cplx half spectrum qh at which the LAST step evaluated its fourth stage: the u, v that QGModel's
                          jacobian_psi_c sees at a diagnostics tick are still those (QGModel.py:375, :483-495, :727-731) */
+  NQ_F_PHIH_STAGE4 = 17,      /* cplx (ny,nx) phih of that same stage (Kernel family): with NQ_F_QH_STAGE4 it determines the
+                                 self.u, self.v a step leaves behind -- the reference's last jacobian_psi_q call of a step is
+                                 the fourth stage's (Kernel.py:364-368 vs :381-387), not the new state's                     */
+  NQ_F_QH_MINUS_STAGE4 = 18   /* the second copy (NQ_F_QH_MINUS) of that stage, dual_q contexts                              */
 };
 
 /* scalar ids for nq_get_scalar */
@@ -214,7 +218,8 @@ int nq_slab_info(const nq_ctx* ctx, int* info8);
 int nq_group_buffers(nq_ctx* ctx, int group, void** x_side, void** y_side, long long* elems);
 /* local column slab of qh (which 0: (ny, local half-spectrum columns)) or phih (which 1: (ny, nx/nranks)); download also
  * which 2: ph, 3: qwh, 4: the second copy of qh of a dual_q context, 5: ch of QGModel's passive scalar, 6: the q-hat the
- * last step's fourth stage was evaluated at (NQ_F_QH_STAGE4) (half-spectrum slabs like qh) */
+ * last step's fourth stage was evaluated at (NQ_F_QH_STAGE4) (half-spectrum slabs like qh), 7: the phih of that stage (like
+ * which 1), 8: the second copy of qh of that stage (like which 4) */
 int nq_upload_spectral(nq_ctx* ctx, int which, const double* host);
 int nq_download_spectral(nq_ctx* ctx, int which, double* host);
 enum {

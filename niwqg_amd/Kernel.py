@@ -223,10 +223,39 @@ class Kernel(object):
                 v = c.field(_lib.F_QW)
             elif name == "q_psi":
                 v = self._field("q") - self._field("qw") if self.model_id == _lib.COUPLED else self._field("q")
+            elif name in ("u", "v") and self._uv_stage4:
+                self._cache["u"], self._cache["v"] = self._uv_of_stage4()
+                return self._cache[name]
             else:
                 v = c.field(_DEVICE_FIELDS[name])
             self._cache[name] = v
         return self._cache[name]
+
+    # After a step the reference's self.u, self.v are NOT those of the new state: the last jacobian_psi_q call of
+    # _step_etdrk4 is the fourth stage's (Kernel.py:364-368), the final update and its _invert come after it (:381-397).
+    # They stay like that until the next jacobian_psi_q, set_q or diagnostics tick (Kernel.py:681).  The step keeps that
+    # stage's qh and phih in its rotating buffers until the next step, so u, v are rebuilt from them on demand, on the host
+    # side of the FFT seam, with the reference's own expressions (CoupledModel.py:75-97, UnCoupledModel.py:54-64).
+    _uv_stage4 = False
+
+    def _uv_of_stage4(self):
+        c, n = self._ctx, self.nx
+        qh4 = c.field(_lib.F_QH_STAGE4)
+        if self._dual:                   # physical space sees the Hermitian part: the mean of the two copies
+            qh4[:, 1:n // 2] = 0.5 * (qh4[:, 1:n // 2] + c.field(_lib.F_QH_MINUS_STAGE4)[:, 1:n // 2])
+        qh4 = hermitian_full(qh4)
+        pv = self.ifft(-(self.wv2i * qh4)).real
+        if self.model_id == _lib.COUPLED:
+            phih4 = c.field(_lib.F_PHIH_STAGE4)
+            phi4 = self.ifft(phih4)
+            phix, phiy = self.ifft(self.ik * phih4), self.ifft(self.il * phih4)
+            jh = self.fft((1j * (np.conj(phix) * phiy - np.conj(phiy) * phix)).real)
+            jh[0, 0] = 0
+            qwh = 0.5 * (0.5 * (-self.wv2 * self.fft(np.abs(phi4) ** 2)) + jh) / self.f
+            qwh *= self.filtr
+            pv = pv + self.ifft(self.wv2i * qwh).real
+        ph4 = self.fft(pv)
+        return self.ifft(-self.il * ph4).real, self.ifft(self.ik * ph4).real
 
     # ------------------------------------------------------------------ public API of the reference
     def fft(self, x):
@@ -240,6 +269,7 @@ class Kernel(object):
         """ref: niwqg/Kernel.py:520-535 -- inverts with the current phi (quirk Q2)"""
         self._ctx.set_q(q)
         self._dirty()
+        self._uv_stage4 = False                     # u, v of the new psi (Kernel.py:533-534)
         self._user["q"] = q
         if self._ctx.budgets_enabled:
             self._ctx.take_budget_increments()      # drop increments that belong to the old state
@@ -279,10 +309,19 @@ class Kernel(object):
 
     def jacobian_psi_q(self):
         """ik F[u q] + il F[v q], [0,0] = 0.  ref: niwqg/Kernel.py:471-486"""
+        if self._uv_stage4:                         # leaves the u, v of the CURRENT psi behind
+            self._uv_stage4 = False
+            self._cache.pop("u", None)
+            self._cache.pop("v", None)
         return self._ctx.jacobian_psi_q()
 
     def jacobian_psi_phi(self):
         """F[u phix + v phiy], [0,0] = 0.  ref: niwqg/Kernel.py:457-469"""
+        if self._uv_stage4:                         # the u, v a step left behind (see _uv_of_stage4), phix, phiy as last refreshed
+            jh = self.fft(self.u * self.phix + self.v * self.phiy)
+            if self.model_id != _lib.YBJ:
+                jh[0, 0] = 0
+            return jh
         return self._ctx.jacobian_psi_phi()
 
     def spec_var(self, ph):
@@ -299,6 +338,7 @@ class Kernel(object):
 
     def _after_steps(self):
         self._dirty()
+        self._uv_stage4 = self.model_id != _lib.YBJ          # (YBJModel: psi, u, v are steady)
         if self._ctx.budgets_enabled:
             dKe, dPw, dKw = self._ctx.take_budget_increments()
             self.Ke += dKe
@@ -373,7 +413,7 @@ class Kernel(object):
             self.ke = self._calc_ke_qg()
             self.kew = self._calc_ke_niw()
             self.pew = self._calc_pe_niw()
-            self.cfl = self._calc_cfl()
+            self.cfl = self._status_cfl()
             self.logger.info('Step: %4i, Time: %2.1e, P: %2.1e, Ke: %4.3e, Kw: %4.3e, Pw: %4.3e, CFL: %3.2f',
                              self.tc, self.t, self.t / self.tmax, self.ke, self.kew, self.pew, self.cfl)
             assert self.cfl < self.cflmax, self.logger.error('CFL condition violated')
@@ -396,8 +436,17 @@ class Kernel(object):
         self._grad2_mean = 4. * self.kappa2 * pe         # mean(|phix|^2 + |phiy|^2) of the refreshed gradients
         return pe
 
+    def _status_cfl(self):
+        """CFL of the status line: always the device maximum.  It takes u, v of the new state where the reference still holds the
+        fourth stage's after a step without a tick: ~1e-5 relative, below what the line prints; _calc_cfl() itself is exact."""
+        if not self._uv_stage4:
+            return self._calc_cfl()
+        return self._ctx.scalar(_lib.S_CFL) * self.dt / self.dx
+
     def _calc_cfl(self):
         """ref: niwqg/Kernel.py:660-662"""
+        if self._uv_stage4:              # u, v as a step left them (the fourth stage's): rebuilt on the host side, on demand
+            return np.abs(np.hstack([self.u, self.v, np.abs(self.phi)])).max() * self.dt / self.dx
         return self._ctx.scalar(_lib.S_CFL) * self.dt / self.dx      # max reduction on the device
 
     # Everything below is evaluated from the 32 raw sums of ONE device pass (nq_diagnostics): no plane is
@@ -521,6 +570,10 @@ class Kernel(object):
         self._calc_class_derived_fields()
 
     def _calc_kernel_derived_fields(self):
+        if self._uv_stage4:              # a tick recomputes u, v from the current psi (Kernel.py:681)
+            self._uv_stage4 = False
+            self._cache.pop("u", None)
+            self._cache.pop("v", None)
         self._calc_energy_conversion()
         self._calc_icke_niw()
 

@@ -116,7 +116,12 @@ class Model(object):
             if name in self._user:
                 return self._user[name]
             if name not in self._cache:
-                self._cache[name] = self._ctx.field(fields[name])
+                if name in ("u", "v") and self.__dict__.get("_uv_stage4"):
+                    # after a step the reference's u, v are those of its fourth stage (QGModel.py:375 vs :396-397)
+                    ph4 = -self.wv2i * self._ctx.field(_lib.F_QH_STAGE4)
+                    self._cache["u"], self._cache["v"] = self.ifft(-self.il * ph4), self.ifft(self.ik * ph4)
+                else:
+                    self._cache[name] = self._ctx.field(fields[name])
             return self._cache[name]
         raise AttributeError(name)
 
@@ -169,7 +174,7 @@ class Model(object):
     def jacobian_psi_c(self):
         """ik F[u c] + il F[v c] (ref: niwqg/QGModel.py:483-495); diagnostics ticks only -- inside a step the row
         kernel forms these products next to those of q."""
-        if getattr(self, "_stepped", False):
+        if self.__dict__.get("_uv_stage4"):
             # the reference's u, v at a tick are those of the last jacobian_psi_q call, i.e. of the state at which
             # the step evaluated its fourth stage, not of the new state (QGModel.py:375 vs :396)
             ph4 = -self.wv2i * self._ctx.field(_lib.F_QH_STAGE4)
@@ -200,7 +205,15 @@ class Model(object):
 
     def jacobian_psi_q(self):
         """ik F[u q] + il F[v q] on the half spectrum, [0,0] NOT zeroed.  ref: niwqg/QGModel.py:469-481"""
+        self._uv_current()
         return self._ctx.jacobian_psi_q()
+
+    def _uv_current(self):
+        """jacobian_psi_q and _calc_cfl leave the u, v of the CURRENT psi behind (QGModel.py:473-474, :626-627)"""
+        if self.__dict__.get("_uv_stage4"):
+            self._uv_stage4 = False
+            self._cache.pop("u", None)
+            self._cache.pop("v", None)
 
     def spec_var(self, ph):
         """ref: niwqg/QGModel.py:611-619"""
@@ -217,6 +230,7 @@ class Model(object):
     def _after_steps(self):
         self._dirty()
         self._stepped = True
+        self._uv_stage4 = True
         if self._ctx.budgets_enabled:
             self.Ke += self._ctx.scalar(_lib.S_KE)
             if self.passive_scalar:
@@ -314,6 +328,7 @@ class Model(object):
         return -self.nu4 * self._dsums()[7] / float(self.M) ** 2
 
     def _calc_cfl(self):
+        self._uv_current()
         return self._ctx.scalar(_lib.S_CFL) * self.dt / self.dx      # max reduction on the device
 
     # The passive scalar's tick entries come from five more device sums (nq_diagnostics [16..20]): nothing of c is

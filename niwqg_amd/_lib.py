@@ -24,7 +24,8 @@ HEADERS = [os.path.join(HERE, "csrc", h) for h in ("nq_fft.hpp", "nq_generic.hpp
     os.path.join(os.path.dirname(HERE), "include", "niwqg_amd.h")]
 
 COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
-(F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY, F_QH_MINUS, F_C, F_CH, F_QH_STAGE4) = range(17)
+(F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY, F_QH_MINUS, F_C, F_CH, F_QH_STAGE4,
+ F_PHIH_STAGE4, F_QH_MINUS_STAGE4) = range(19)
 (S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL) = range(7)
 
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
@@ -266,7 +267,7 @@ class Context:
 
     # --- reads
     _REAL = (F_Q, F_P, F_U, F_V, F_QPSI, F_QW, F_C)
-    _HALF = (F_QH, F_PH, F_QWH, F_QH_MINUS, F_CH, F_QH_STAGE4)
+    _HALF = (F_QH, F_PH, F_QWH, F_QH_MINUS, F_CH, F_QH_STAGE4, F_QH_MINUS_STAGE4)
 
     def field(self, fid):
         n, h = self.nx, self.nx // 2 + 1

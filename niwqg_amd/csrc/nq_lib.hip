@@ -383,10 +383,14 @@ __global__ void k_reduce(const cd* __restrict__ a, int width, int pitch, int N, 
   const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
   double v = 0.0;
   if (k < width) {
-    const cd z = a[(size_t)l * pitch + k];
+    cd z = a[(size_t)l * pitch + k];
+    if (kind == 4 && (k == 0 || k == N / 2)) {     // Kernel family: ph = fft of the REAL p, i.e. the Hermitian part (in l) of the
+      const cd zm = a[(size_t)((N - l) % N) * pitch + k];   // two self-mirrored columns (they differ under the 2/3 mask's dual copies)
+      z = cmake(0.5 * (z.x + zm.x), 0.5 * (z.y - zm.y));
+    }
     const double m2 = z.x * z.x + z.y * z.y;
     if (kind == 0) v = m2;
-    else if (kind == 1) {
+    else if (kind == 1 || kind == 4) {
       const double w = (k == 0 || k == N / 2) ? 1.0 : 2.0;
       v = (l == 0 && k == 0) ? 0.0 : w * (kk[k] * kk[k] + ll[l] * ll[l]) * m2;
     } else if (kind == 2) v = (kk[k] * kk[k] + ll[l] * ll[l]) * m2;
@@ -494,7 +498,10 @@ __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, 
     }
     v[3] += wt * wv2i * w2;                                       // sum |qw|^2 / wv2       -> ke_qg_w
     v[4] += wt * wv2i * (hq.x * hw.x + hq.y * hw.y);              // sum Re(conj q qw)/wv2  -> ke_qg_qw
-    v[5] += (l == 0 && k == 0) ? 0.0 : wt * wv2 * (p.x * p.x + p.y * p.y);   // -> ke_qg
+    // -> ke_qg.  Dual-copy (2/3 mask) contexts: the reference's ph = fft of the REAL p is the Hermitian part, and there the two
+    // self-mirrored columns of the stored psi-hat are not Hermitian in l.  (QGModel's ph = -wv2i qh is summed as it is.)
+    const cd pk = (qp != nullptr) ? hp : p;
+    v[5] += (l == 0 && k == 0) ? 0.0 : wt * wv2 * (pk.x * pk.x + pk.y * pk.y);
     const double pq = hp.x * hq.x + hp.y * hq.y;                  // Re(conj(psi) q)
     v[6] += wt * wv4 * pq;                                        // -> mean(q lap2 psi)
     v[7] += wt * wv2 * pq;                                        // -> -mean(psi lap q)
@@ -2357,15 +2364,16 @@ int nq_upload_spectral(nq_ctx* c, int which, const double* host) {
 int nq_download_spectral(nq_ctx* c, int which, double* host) {
   if (!c || !host) return -1;
   HIPCHK(c, hipSetDevice(c->device));
-  if (which == 0 || (which >= 2 && which <= 6)) {      // half-spectrum planes: qh, ph, qwh, second copy of qh, ch, stage-4 qh
+  if (which == 0 || (which >= 2 && which <= 6) || which == 8) {   // half-spectrum planes: qh, ph, qwh, second copy of qh, ch, stage-4 qh (both copies)
     if (which == 3 && c->p.model != NQ_MODEL_COUPLED) NQ_FAIL(c, -4, "qwh exists only in the coupled model");
-    if (which == 4 && !c->dual) NQ_FAIL(c, -4, "no second copy of qh in this context (dual_q)");
+    if ((which == 4 || which == 8) && !c->dual) NQ_FAIL(c, -4, "no second copy of qh in this context (dual_q)");
     if (which == 5 && !c->passive) NQ_FAIL(c, -4, "no passive scalar in this context");
-    const cd* src = which == 0 ? c->q.y[c->q.cur] : (which == 2 ? c->ph : (which == 3 ? c->qwh : (which == 4 ? c->q2.y[c->q2.cur] : (which == 5 ? c->cq.y[c->cq.cur] : c->q.y[(c->q.cur + 2) % 3]))));
+    const cd* src = which == 0 ? c->q.y[c->q.cur] : (which == 2 ? c->ph : (which == 3 ? c->qwh : (which == 4 ? c->q2.y[c->q2.cur] : (which == 5 ? c->cq.y[c->cq.cur] : (which == 8 ? c->q2.y[(c->q2.cur + 2) % 3] : c->q.y[(c->q.cur + 2) % 3])))));
     if (c->Wh > 0) HIPCHK(c, hipMemcpy2DAsync(host, sizeof(cd) * c->Wh, src, sizeof(cd) * c->Ph, sizeof(cd) * c->Wh, c->N, hipMemcpyDeviceToHost, c->stream));
-  } else if (which == 1) {
+  } else if (which == 1 || which == 7) {
     if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
-    HIPCHK(c, hipMemcpyAsync(host, c->w.y[c->w.cur], sizeof(cd) * (size_t)c->N * c->Wf, hipMemcpyDeviceToHost, c->stream));
+    const cd* src = which == 1 ? c->w.y[c->w.cur] : c->w.y[(c->w.cur + 2) % 3];
+    HIPCHK(c, hipMemcpyAsync(host, src, sizeof(cd) * (size_t)c->N * c->Wf, hipMemcpyDeviceToHost, c->stream));
   } else NQ_FAIL(c, -1, "nq_download_spectral: which = %d", which);
   return nq_sync(c);
 }
@@ -3053,6 +3061,13 @@ int nq_get_field(nq_ctx* c, int id, double* host) {
       if (!c->passive) NQ_FAIL(c, -4, "no passive scalar in this context");
       return get_half_spec(c, c->cq.y[c->cq.cur], host);
     case NQ_F_QH_STAGE4: return get_half_spec(c, c->q.y[(c->q.cur + 2) % 3], host);
+    case NQ_F_QH_MINUS_STAGE4:
+      if (!c->dual) NQ_FAIL(c, -4, "NQ_F_QH_MINUS_STAGE4 needs a dual_q context");
+      return get_half_spec(c, c->q2.y[(c->q2.cur + 2) % 3], host);
+    case NQ_F_PHIH_STAGE4:
+      if (!waves) NQ_FAIL(c, -4, "no wave field in QGModel");
+      HIPCHK(c, hipMemcpyAsync(host, c->w.y[(c->w.cur + 2) % 3], sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
+      return nq_sync(c);
     case NQ_F_C:
       if (!c->passive) NQ_FAIL(c, -4, "no passive scalar in this context");
       return get_real_from_half(c, c->cq.y[c->cq.cur], 0, host);
@@ -3145,7 +3160,7 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
   }
   NQ_SINGLE_RANK(c, "nq_get_scalar (ids other than the budget increments)");
   if (id == NQ_S_KE_QG) {
-    hipLaunchKernelGGL(k_reduce, dim3((c->Wh + 255) / 256, N), dim3(256), 0, c->stream, c->ph, c->Wh, c->Ph, N, 1, c->kk, c->ll, d);
+    hipLaunchKernelGGL(k_reduce, dim3((c->Wh + 255) / 256, N), dim3(256), 0, c->stream, c->ph, c->Wh, c->Ph, N, c->kernel_family ? 4 : 1, c->kk, c->ll, d);
     HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     int rc = nq_sync(c);
     *out = 0.5 * h[0] / (M * M);
@@ -3474,8 +3489,8 @@ long long nq_field_doubles(const nq_ctx* c, int id) {
   const long long n = c->N, h = c->N / 2 + 1;
   switch (id) {
     case NQ_F_Q: case NQ_F_P: case NQ_F_U: case NQ_F_V: case NQ_F_QPSI: case NQ_F_QW: case NQ_F_C: return n * n;
-    case NQ_F_QH: case NQ_F_PH: case NQ_F_QWH: case NQ_F_QH_MINUS: case NQ_F_CH: case NQ_F_QH_STAGE4: return 2 * n * h;
-    case NQ_F_PHI: case NQ_F_PHIH: case NQ_F_PHIX: case NQ_F_PHIY: return 2 * n * n;
+    case NQ_F_QH: case NQ_F_PH: case NQ_F_QWH: case NQ_F_QH_MINUS: case NQ_F_CH: case NQ_F_QH_STAGE4: case NQ_F_QH_MINUS_STAGE4: return 2 * n * h;
+    case NQ_F_PHI: case NQ_F_PHIH: case NQ_F_PHIX: case NQ_F_PHIY: case NQ_F_PHIH_STAGE4: return 2 * n * n;
     default: return -1;
   }
 }

@@ -104,7 +104,7 @@ class SlabRank(object):
         self._chk(self.L.nq_upload_spectral(self.h, which, _lib._dptr(arr.view(np.float64))), "nq_upload_spectral")
 
     def download(self, which):
-        w = self.wf if which == 1 else self.wh          # 0: qh, 2: ph, 3: qwh (half-spectrum slabs); 1: phih
+        w = self.wf if which in (1, 7) else self.wh     # 0: qh, 2: ph, 3: qwh ... (half-spectrum slabs); 1, 7: phih
         out = np.empty((self.nx, w), np.complex128)
         self._chk(self.L.nq_download_spectral(self.h, which, _lib._dptr(out.view(np.float64))), "nq_download_spectral")
         return out
@@ -487,7 +487,8 @@ class SlabContext(object):
         if fid == L.F_QPSI:
             q = self.sim.gather_rows(L.F_Q)
             return q - self.sim.gather_rows(L.F_QW) if self.model == L.COUPLED else q
-        which = {L.F_QH: 0, L.F_PHIH: 1, L.F_PH: 2, L.F_QWH: 3, L.F_QH_MINUS: 4, L.F_CH: 5, L.F_QH_STAGE4: 6}.get(fid)
+        which = {L.F_QH: 0, L.F_PHIH: 1, L.F_PH: 2, L.F_QWH: 3, L.F_QH_MINUS: 4, L.F_CH: 5, L.F_QH_STAGE4: 6, L.F_PHIH_STAGE4: 7,
+                 L.F_QH_MINUS_STAGE4: 8}.get(fid)
         if which is None:
             raise RuntimeError("field %d is not available on a slab-decomposed model" % fid)
         return self.sim.gather_spectral(which)

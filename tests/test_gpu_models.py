@@ -817,11 +817,9 @@ def test_randomly_drawn_configurations_on_slabs_against_the_oracle(seed):
     random_configuration_against_the_oracle(seed, on_slabs=True)
 
 
-def random_configuration_against_the_oracle(seed, on_slabs=False):
-    """Seeded draws over what the constructors accept -- model class, grid (64..512: two-pass tiles, single-pass columns and the
-    array-parallel QG kernel all occur), filter / 2-3 mask / none, mean flow, every dissipation coefficient, beta, the passive scalar,
-    the diagnostics cadence (quirk Q1 acts through it) -- white-noise plus large-scale initial fields, 6 steps through
-    _step_forward, against the reference-pinned oracle: fields 1e-11, budgets 1e-8, and every diagnostics series the tick recorded."""
+def draw_configuration(seed, on_slabs=False, order_rng=None):
+    """One seeded draw: the device model and the oracle, both initialised (see random_configuration_against_the_oracle).
+    order_rng: draw the set_q / set_phi order as well (quirk Q2)."""
     rng = np.random.default_rng(1000 + seed)
     kind = ["coupled", "uncoupled", "qg", "ybj", "coupled", "qg"][seed % 6]
     nx = int(rng.choice([64, 128, 256, 512] if kind != "coupled" else [64, 128, 256]))
@@ -848,21 +846,35 @@ def random_configuration_against_the_oracle(seed, on_slabs=False):
         cls = {"coupled": mods.CoupledModel, "uncoupled": mods.UnCoupledModel, "ybj": mods.YBJModel}[kind]
         m, o = cls.Model(**kw, **extra), O.NIWQGOracle(kind, **kw)
     q0 = O.lamb_dipole(o.grid, U=U0, R=2 * np.pi / K0) + 2e-6 * rng.standard_normal((nx, nx))
-    for x in (m, o):
-        x.set_q(q0)
+    phi_first = kind != "qg" and order_rng is not None and bool(order_rng.integers(0, 2))
+    if not phi_first:
+        for x in (m, o):
+            x.set_q(q0)
     if kind != "qg":
         phi0 = 0.1 * O.wave_packet(o.grid, k=2 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2) + 0.02 * (
             rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx)))
         for x in (m, o):
             x.set_phi(phi0)
+        if phi_first:
+            for x in (m, o):
+                x.set_q(q0)
     elif kw["passive_scalar"]:
         c0 = 1.0 + 0.3 * rng.standard_normal((nx, nx))
         for x in (m, o):
             x.set_c(c0)
+    tag = "%s %d filt=%d tdiags=%g %s%s" % (kind, nx, filt, tdiags, extra, " phi first" if phi_first else "")
+    return m, o, kind, kw, rng, tag
+
+
+def random_configuration_against_the_oracle(seed, on_slabs=False):
+    """Seeded draws over what the constructors accept -- model class, grid (64..512: two-pass tiles, single-pass columns and the
+    array-parallel QG kernel all occur), filter / 2-3 mask / none, mean flow, every dissipation coefficient, beta, the passive scalar,
+    the diagnostics cadence (quirk Q1 acts through it) -- white-noise plus large-scale initial fields, 6 steps through
+    _step_forward, against the reference-pinned oracle: fields 1e-11, budgets 1e-8, and every diagnostics series the tick recorded."""
+    m, o, kind, kw, rng, tag = draw_configuration(seed, on_slabs)
     for _ in range(6):
         o._step_forward()
     steps(m, 6)
-    tag = "%s %d filt=%d tdiags=%g %s" % (kind, nx, filt, tdiags, extra)
     tol = 1e-11       # (1e-10 is BASELINE's bar; before the contour-adjacent ETDRK4 entries came from numpy three of 160 draws missed it)
     if kind != "ybj":
         assert rel(m.q, o.q) < tol and rel(m.qh, o.qh) < tol, tag
@@ -884,3 +896,66 @@ def random_configuration_against_the_oracle(seed, on_slabs=False):
             continue        # nearly vanishing / cancellation-prone integrals: pinned with their own tolerances elsewhere
         scale = np.abs(b).max() if b.size else 0.0
         assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * scale + 1e-300), (tag, name, a, b)
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("NQ_FUZZ_CALL_SEEDS", "24")))))
+def test_randomly_drawn_call_sequences_against_the_oracle(seed):
+    """The class surface as a state machine: on a drawn configuration (set_q / set_phi in either order: quirk Q2) a drawn
+    sequence of twelve public calls -- steps, the three Jacobians (jacobian_psi_q leaves u, v behind, jacobian_psi_phi consumes
+    them and the phix, phiy that only _invert / _calc_pe_niw refresh: quirk Q1), the energy and CFL calls, set_q / set_phi in
+    mid-run, attribute reads -- on the device model and on the oracle side by side: every returned value and, at the end, every
+    field must agree (1e-10; the Jacobians of white noise relative to their own norm).  What this found: after a step without a
+    diagnostics tick the reference's u, v are still the fourth stage's (Kernel.py:364-368), and jacobian_psi_phi, _calc_cfl and
+    m.u, m.v must say so (Kernel._uv_of_stage4)."""
+    arng = np.random.default_rng(9000 + seed)
+    m, o, kind, kw, rng, tag = draw_configuration(seed, order_rng=arng)
+    nx = kw["nx"]
+    wave = kind in ("coupled", "uncoupled")
+    actions = ["step", "step", "step", "read", "energies", "cfl", "set_q"]
+    if kind != "ybj":
+        actions += ["jq", "jq"]
+    if wave:
+        actions += ["jphi", "set_phi", "pe"]
+    if kind == "coupled":
+        actions += ["jcc"]                  # (only CoupledModel defines jacobian_phic_phi: CoupledModel.py:59)
+    log = []
+    for n in range(12):
+        a = str(arng.choice(actions))
+        log.append(a)
+        where = (tag, log)
+        if a == "step":
+            o._step_forward()
+            m._step_forward()
+        elif a == "jq":
+            assert rel(m.jacobian_psi_q(), o.jacobian_psi_q()) < 1e-10, where
+            assert rel(m.u, o.u) < 1e-10 and rel(m.v, o.v) < 1e-10, where
+        elif a == "jphi":
+            assert rel(m.jacobian_psi_phi(), o.jacobian_psi_phi()) < 1e-10, where
+        elif a == "jcc":
+            assert rel(m.jacobian_phic_phi(), o.jacobian_phic_phi()) < 1e-10, where
+        elif a == "energies":
+            assert abs(m._calc_ke_qg() - o._calc_ke_qg()) <= 1e-10 * abs(o._calc_ke_qg()), where
+            if kind != "qg":
+                assert abs(m._calc_ke_niw() - o._calc_ke_niw()) <= 1e-10 * abs(o._calc_ke_niw()), where
+        elif a == "pe":
+            assert abs(m._calc_pe_niw() - o._calc_pe_niw()) <= 1e-10 * abs(o._calc_pe_niw()), where
+        elif a == "cfl":
+            assert abs(m._calc_cfl() - o._calc_cfl()) <= 1e-10 * abs(o._calc_cfl()), where
+        elif a == "set_q":
+            q1 = 1e-6 * arng.standard_normal((nx, nx)) + 0.5 * np.asarray(o.q)
+            for x in (m, o):
+                x.set_q(q1)
+        elif a == "set_phi":
+            p1 = 0.05 * (arng.standard_normal((nx, nx)) + 1j * arng.standard_normal((nx, nx))) + 0.5 * np.asarray(o.phi)
+            for x in (m, o):
+                x.set_phi(p1)
+        elif a == "read":
+            names = ["q", "qh", "ph"] + (["phi", "phih", "u", "v"] if kind != "qg" else []) + (["p"] if kind != "ybj" else [])
+            nm = str(arng.choice(names))
+            assert rel(getattr(m, nm), getattr(o, nm)) < 1e-10, (where, nm)
+    where = (tag, log)
+    if kind != "ybj":
+        assert rel(m.q, o.q) < 1e-10 and rel(m.qh, o.qh) < 1e-10 and rel(m.ph, o.ph) < 1e-10, where
+    if kind != "qg":
+        assert rel(m.phi, o.phi) < 1e-10 and rel(m.phih, o.phih) < 1e-10, where
+    assert m.tc == o.tc and m.t == o.t, where

@@ -82,7 +82,7 @@ def _bare_kernel(tdiags, twrite, dt, tmax):
     k._calc_derived_fields = lambda: k.ticks.append(k.tc)
     k._print_status_orig = Kernel.Kernel._print_status
     k._calc_ke_qg = k._calc_ke_niw = k._calc_pe_niw = lambda: 0.0
-    k._calc_cfl = lambda: 0.0
+    k._calc_cfl = k._status_cfl = lambda: 0.0
     k.cflmax = 1.0
 
     class Log(object):

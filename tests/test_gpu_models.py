@@ -983,3 +983,46 @@ def random_call_sequence_against_the_oracle(seed, on_slabs=False):
     if kind != "qg":
         assert rel(m.phi, o.phi) < 1e-10 and rel(m.phih, o.phih) < 1e-10, where
     assert m.tc == o.tc and m.t == o.t, where
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("NQ_FUZZ_RUN_SEEDS", "18")))))
+def test_randomly_drawn_runs_against_the_oracle(seed):
+    """run() itself on drawn configurations with drawn cadences of the status line (every 3, 5 steps or never: its
+    _calc_pe_niw refreshes UnCoupledModel's gradients, quirk Q1, its _calc_cfl QGModel's u, v) and of the diagnostics tick, for a
+    drawn number of steps, sometimes in two legs with tmax moved in between (the reference's tests do that): the library batches
+    the quiet steps in between, the oracle takes them one by one.  Clock, fields, budgets, every diagnostics series, the last
+    status values."""
+    rrng = np.random.default_rng(7000 + seed)
+    m, o, kind, kw, rng, tag = draw_configuration(seed, on_slabs=bool(seed % 3 == 2), order_rng=rrng)
+    twrite = int(rrng.choice([3, 5, 10 ** 9]))
+    legs = [int(rrng.integers(5, 14))] + ([int(rrng.integers(2, 9))] if rrng.integers(0, 2) else [])
+    tag = "%s twrite=%d legs=%s" % (tag, twrite, legs)
+    total = 0
+    for x in (m, o):
+        x.twrite = twrite
+    for n in legs:
+        total += n
+        for x in (m, o):
+            x.tmax = (total - 0.5) * x.dt
+            x.run()
+        assert m.tc == o.tc == total and m.t == o.t, tag
+        if kind != "ybj":
+            assert rel(m.q, o.q) < 1e-10 and rel(m.qh, o.qh) < 1e-10, tag
+        if kind != "qg":
+            assert rel(m.phi, o.phi) < 1e-10 and rel(m.phih, o.phih) < 1e-10, tag
+            if kind != "ybj":
+                assert np.allclose([m.Ke, m.Pw, m.Kw], [o.Ke, o.Pw, o.Kw], rtol=1e-8, atol=1e-30), tag
+        else:
+            assert abs(m.Ke - o.Ke) <= 1e-9 * abs(o.Ke), tag
+    if twrite < 10 ** 9 and total >= twrite:
+        assert abs(m.ke - o.ke) <= 1e-9 * abs(o.ke) and abs(m.cfl - o.cfl) <= 1e-3 * abs(o.cfl), tag
+        if kind != "qg":
+            assert abs(m.kew - o.kew) <= 1e-9 * abs(o.kew) and abs(m.pew - o.pew) <= 1e-9 * abs(o.pew), tag
+    for name in o.diagnostics:
+        if name not in m.diagnostics or name in ("skew", "conc_niw", "Gamma_c", "pi", "gamma_r", "gamma_a", "xi_r", "xi_a"):
+            continue
+        a = np.atleast_1d(np.asarray(m.diagnostics[name]["value"], float))
+        b = np.atleast_1d(np.asarray(o.diag(name), float))
+        assert a.shape == b.shape, (tag, name)
+        scale = np.abs(b).max() if b.size else 0.0
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * scale + 1e-300), (tag, name, a, b)

@@ -434,6 +434,24 @@ def g13():
     step_to(m, 6)
     out["c_q6"], out["c_phi6"] = m.q.copy(), m.phi.copy()
     out["c_budgets"] = np.array([m.Ke, m.Pw, m.Kw])
+    # (c) a mean flow: c dt off the real axis, the entries next to the contour points on either side of -1 (QGModel 256^2,
+    #     U = -U0, beta; CoupledModel 128^2 with U = U0/2: its phi operator has the dispersion term as well)
+    kw = dict(L=L, nx=256, tmax=1e30, dt=0.05 * TE, twrite=10 ** 9, tdiags=10 ** 9, use_filter=True, dealias=False, U=-U0,
+              nu4=3.1e10, nu=5.0, mu=1e-8, beta=2e-11, save_to_disk=False)
+    m = QGModel.Model(**kw)
+    c = np.zeros((m.nl, m.nk), complex)
+    c += -m.nu4 * m.wv4 - m.nu * m.wv2 - m.mu - 1j * m.k * m.U
+    c += m.beta * m.ik * m.wv2i
+    contour_entries(m, ("Qh", "f0", "fab", "fc"), c * m.dt, "qgu_", out)
+    out["qgu_params"] = np.array([kw["dt"], kw["nu4"], kw["nu"], kw["mu"], kw["U"], kw["beta"]])
+    kw = dict(L=L, nx=128, tmax=1e30, dt=0.025 * TE, twrite=10 ** 9, tdiags=10 ** 9, use_filter=True, dealias=False, U=0.5 * U0,
+              nu4=5e11, nu=20.0, mu=0.0, nuw=50.0, nu4w=5e10, muw=2e-8, m=MZ, N=NB, f=F0, save_to_disk=False)
+    m = CoupledModel.Model(**kw)
+    cq = np.zeros((m.nl, m.nk), complex) - 1j * m.k * m.U
+    cq += -m.nu4 * m.wv4 - m.nu * m.wv2 - m.mu
+    contour_entries(m, ("Qh", "f0", "fab", "fc"), cq * m.dt, "cuq_", out)
+    contour_entries(m, ("Qhw", "f0w", "fabw", "fcw"), m.c * m.dt, "cuw_", out)
+    out["cu_params"] = np.array([kw["dt"], kw["nu4"], kw["nu"], kw["nuw"], kw["nu4w"], kw["muw"], kw["U"]])
     save("g13_contour_entries.npz", **out)
 
 

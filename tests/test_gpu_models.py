@@ -802,6 +802,26 @@ def test_contour_adjacent_etdrk4_entries_against_the_reference_itself(golden):
     for _ in range(6):
         c._step_forward()
     print("g13 coupled 256^2, six steps vs the reference: q %.2e phi %.2e" % (rel(c.q, g["c_q6"]), rel(c.phi, g["c_phi6"])))
+    # with a mean flow (c dt off the real axis): the device's list is the reference's, the values bit for bit (QGModel, and the
+    # phi planes of CoupledModel; its half-plane q takes the Hermitian combination of F(l, k) and conj F(-l, -k))
+    from test_oracle_golden import G13_QG_U, G13_COUPLED_U
+    mu_ = M.QGModel.Model(**G13_QG_U)
+    li, ki = g["qgu_l"].astype(int), g["qgu_k"].astype(int)
+    assert mu_._ctx.contour_patched[0] == len(li)
+    for nm, _ in G13_NAMES:
+        assert np.array_equal(getattr(mu_, nm)[li, ki], g["qgu_" + nm]), nm
+    cu = M.CoupledModel.Model(**G13_COUPLED_U)
+    lw, kw_ = g["cuw_l"].astype(int), g["cuw_k"].astype(int)
+    assert cu._ctx.contour_patched[1] == len(lw)
+    for nm, _ in G13_NAMES:
+        assert np.array_equal(getattr(cu, nm + "w")[lw, kw_], g["cuw_" + nm + "w"]), nm
+    li, ki = g["cuq_l"].astype(int), g["cuq_k"].astype(int)
+    table = {(int(l), int(k)): i for i, (l, k) in enumerate(zip(li, ki))}
+    for nm, _ in G13_NAMES:
+        F, plane = g["cuq_" + nm], getattr(cu, nm)
+        for i in np.nonzero(ki <= 64)[0]:
+            mirror = np.conj(F[table[((128 - li[i]) % 128, (128 - ki[i]) % 128)]])
+            assert plane[li[i], ki[i]] == 0.5 * (F[i] + mirror), (nm, li[i], ki[i])
     assert rel(c.q, g["c_q6"]) < 1e-11 and rel(c.phi, g["c_phi6"]) < 1e-11
     assert np.allclose([c.Ke, c.Pw, c.Kw], g["c_budgets"], rtol=1e-8)
 

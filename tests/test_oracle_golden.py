@@ -302,6 +302,11 @@ G13_QG = dict(L=L, nx=512, tmax=1e30, dt=625.0, twrite=10 ** 9, tdiags=10 ** 9, 
 G13_COUPLED = dict(L=L, nx=256, tmax=1e30, dt=1250.0, twrite=10 ** 9, tdiags=10 ** 9, use_filter=False, dealias=True, U=0.0,
                    nu4=48273918940.97328, nu=20.0, mu=1e-8, nuw=0.0, nu4w=0.0, muw=2e-8, m=2 * np.pi / 280.0, N=NB, f=F0)
 G13_NAMES = (("Qh", "Q"), ("f0", "f0"), ("fab", "fab"), ("fc", "fc"))
+# with a mean flow (c dt off the real axis): make_golden.py g13 (c)
+G13_QG_U = dict(L=L, nx=256, tmax=1e30, dt=0.05 * TE, twrite=10 ** 9, tdiags=10 ** 9, use_filter=True, dealias=False, U=-U0,
+                nu4=3.1e10, nu=5.0, mu=1e-8, beta=2e-11)
+G13_COUPLED_U = dict(L=L, nx=128, tmax=1e30, dt=0.025 * TE, twrite=10 ** 9, tdiags=10 ** 9, use_filter=True, dealias=False,
+                     U=0.5 * U0, nu4=5e11, nu=20.0, mu=0.0, nuw=50.0, nu4w=5e10, muw=2e-8, m=2 * np.pi / 280.0, N=NB, f=F0)
 
 
 def g13_half_plane_q_values(g, filtr, nx):
@@ -349,6 +354,20 @@ def test_contour_adjacent_etdrk4_entries_are_the_references_bit_for_bit(golden):
             ref = g[tag + nm + ("w" if eq else "")]
             assert np.array_equal(co[key][li, ki], ref), (tag, nm)
             assert np.array_equal(host[:, j], ref), (tag, nm)
+    # with a mean flow: the entries next to the contour points on either side of -1 (q) and along the dispersion curve (phi)
+    ou = O.QGOracle(**G13_QG_U)
+    li, ki = g["qgu_l"].astype(int), g["qgu_k"].astype(int)
+    host = _etdrk4.contour_tables(_etdrk4.linear_operator(_etdrk4.QG, 0, ou.kk[ki], ou.ll[li], G13_QG_U) * G13_QG_U["dt"], G13_QG_U["dt"])
+    for j, (nm, key) in enumerate(G13_NAMES):
+        assert np.array_equal(ou.coef_q[key][li, ki], g["qgu_" + nm]) and np.array_equal(host[:, j], g["qgu_" + nm]), nm
+    cu = O.NIWQGOracle("coupled", **G13_COUPLED_U)
+    prmu = dict(G13_COUPLED_U, kappa2=cu.kappa2)
+    for eq, tag, co in ((0, "cuq_", cu.coef_q), (1, "cuw_", cu.coef_w)):
+        li, ki = g[tag + "l"].astype(int), g[tag + "k"].astype(int)
+        host = _etdrk4.contour_tables(_etdrk4.linear_operator(0, eq, cu.kk[ki], cu.ll[li], prmu) * prmu["dt"], prmu["dt"])
+        for j, (nm, key) in enumerate(G13_NAMES):
+            ref = g[tag + nm + ("w" if eq else "")]
+            assert np.array_equal(co[key][li, ki], ref) and np.array_equal(host[:, j], ref), (tag, nm)
     # what patch_near_contour hands to the device for the half-plane q of the Kernel family, given the device's list
     li, ki, want = g13_half_plane_q_values(g, c.filtr, 256)
     got = {}

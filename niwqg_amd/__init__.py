@@ -11,6 +11,7 @@ __version__ = '0.1'
 from ._lib import build   # noqa: F401
 from . import Diagnostics   # noqa: F401
 from . import InitialConditions   # noqa: F401
+from . import Saving   # noqa: F401
 from . import Kernel   # noqa: F401
 from . import CoupledModel   # noqa: F401
 from . import UnCoupledModel   # noqa: F401

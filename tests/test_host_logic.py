@@ -266,3 +266,22 @@ def test_package_surface_mirrors_the_references():
         assert callable(getattr(niwqg_amd.InitialConditions, name)), name
     for name in ("initialize_save_snapshots", "file_exist", "save_setup", "save_snapshots", "save_diagnostics"):
         assert callable(getattr(niwqg_amd.Saving, name)), name
+
+
+def test_constructor_signatures_are_the_references():
+    """Positional order, names and defaults of the two constructors, transcribed from ref niwqg/Kernel.py:70-98 and
+    niwqg/QGModel.py:65-91; what this package adds (device, budgets, exact_qh, slab, nchunks) comes after them."""
+    import inspect
+    import niwqg_amd
+    kernel = [('nx', 128), ('ny', None), ('L', 5e5), ('dt', 10000.), ('twrite', 1000.), ('tmax', 250000.), ('use_filter', True),
+              ('cflmax', 0.8), ('U', .0), ('f', 1e-4), ('N', 0.01), ('m', 0.025), ('g', 9.81), ('nu4', 0), ('nu4w', 0), ('nu', 20),
+              ('nuw', 50.), ('mu', 0), ('muw', 0), ('dealias', False), ('save_to_disk', False), ('overwrite', True),
+              ('tsave_snapshots', 10), ('tdiags', 10), ('path', 'output/'), ('use_mkl', False), ('nthreads', 1)]
+    qg = [('nx', 128), ('ny', None), ('L', 5e5), ('dt', 10000.), ('twrite', 1000), ('tswrite', 10), ('tmax', 250000.),
+          ('use_filter', True), ('U', .0), ('nu4', 5.e9), ('nu', 0), ('mu', 0), ('beta', 0), ('passive_scalar', False), ('nu4c', 5.e9),
+          ('nuc', 0), ('muc', 0), ('dealias', False), ('save_to_disk', False), ('overwrite', True), ('tsave_snapshots', 10),
+          ('tdiags', 10), ('path', 'output/'), ('use_mkl', False), ('nthreads', 1)]
+    for cls, want in ((niwqg_amd.Kernel.Kernel, kernel), (niwqg_amd.QGModel.Model, qg)):
+        got = [(k, v.default) for k, v in inspect.signature(cls.__init__).parameters.items() if k != "self"]
+        assert got[:len(want)] == want, cls
+        assert set(k for k, _ in got[len(want):]) <= {"device", "budgets", "exact_qh", "slab", "nchunks"}, got[len(want):]

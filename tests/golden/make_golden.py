@@ -32,6 +32,9 @@ Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
                           test.  Qh, f0, fab, fc at every entry within 0.05 of the contour (there the reference's value is
                           numpy's rounding error times eps / distance^3), and for the 256^2 CoupledModel (2/3-rule
                           dealiasing, inviscid waves) q and phi after 6 steps from seeded white noise, which feeds them
+  g14_instance_attributes.npz  what a freshly constructed instance of each of the four model classes carries (nx = 64, every other
+                          argument at its default): names and values of the scalar attributes, names, shapes, dtypes and two
+                          checksums of the array attributes
 """
 import os
 import sys
@@ -453,6 +456,38 @@ def g13():
     contour_entries(m, ("Qhw", "f0w", "fabw", "fcw"), m.c * m.dt, "cuw_", out)
     out["cu_params"] = np.array([kw["dt"], kw["nu4"], kw["nu"], kw["nuw"], kw["nu4w"], kw["muw"], kw["U"]])
     save("g13_contour_entries.npz", **out)
+
+
+def g14():
+    out = {}
+    for tag, mod in (("coupled", CoupledModel), ("uncoupled", UnCoupledModel), ("qg", QGModel), ("ybj", YBJModel)):
+        m = mod.Model(nx=64)
+        num, txt, arr = {}, {}, {}
+        for k, v in m.__dict__.items():
+            if isinstance(v, (bool, np.bool_)):
+                num[k] = float(v)
+            elif isinstance(v, (int, float, np.integer, np.floating)):
+                num[k] = float(v)
+            elif isinstance(v, str):
+                txt[k] = v
+            elif isinstance(v, np.ndarray):
+                arr[k] = v
+        out[tag + "_num_names"] = np.array(sorted(num), dtype="U32")
+        out[tag + "_num_values"] = np.array([num[k] for k in sorted(num)])
+        out[tag + "_txt_names"] = np.array(sorted(txt), dtype="U32")
+        out[tag + "_txt_values"] = np.array([txt[k] for k in sorted(txt)], dtype="U64")
+        names = sorted(arr)
+        out[tag + "_arr_names"] = np.array(names, dtype="U32")
+        out[tag + "_arr_shapes"] = np.array([list(arr[k].shape) + [0] * (2 - arr[k].ndim) for k in names])
+        out[tag + "_arr_dtypes"] = np.array([str(arr[k].dtype) for k in names], dtype="U16")
+        cs = []
+        for k in names:
+            a = arr[k].astype(complex).ravel()
+            w = np.cos(0.37 * np.arange(a.size))
+            cs.append([a.sum(), (a * w).sum()])
+        out[tag + "_arr_checksums"] = np.array(cs)
+        out[tag + "_other_names"] = np.array(sorted(k for k in m.__dict__ if k not in num and k not in txt and k not in arr), dtype="U32")
+    save("g14_instance_attributes.npz", **out)
 
 
 if __name__ == "__main__":

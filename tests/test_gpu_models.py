@@ -1055,3 +1055,33 @@ def test_randomly_drawn_runs_against_the_oracle(seed):
         assert a.shape == b.shape, (tag, name)
         scale = np.abs(b).max() if b.size else 0.0
         assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * scale + 1e-300), (tag, name, a, b)
+
+
+@pytest.mark.parametrize("tag", ["coupled", "uncoupled", "qg", "ybj"])
+def test_fresh_instance_carries_the_references_attributes(golden, tag):
+    """Golden g14 (make_golden.py g14): every attribute a freshly constructed reference instance has (nx = 64, defaults otherwise)
+    -- scalars by value, strings, arrays by shape, dtype and two checksums (grid, wavenumbers, filter, the linear operator the
+    constructor leaves in `c`, every ETDRK4 plane, the zero state), the rest by presence.  Exempt: qh0, qh1, the reference's
+    work copies inside a step."""
+    M = models()
+    g = golden("g14_instance_attributes.npz")
+    cls = {"coupled": M.CoupledModel, "uncoupled": M.UnCoupledModel, "qg": M.QGModel, "ybj": M.YBJModel}[tag]
+    m = cls.Model(nx=64)
+    for name, want in zip(g[tag + "_num_names"], g[tag + "_num_values"]):
+        got = getattr(m, str(name))
+        assert float(got) == float(want), (name, got, want)
+    for name, want in zip(g[tag + "_txt_names"], g[tag + "_txt_values"]):
+        assert getattr(m, str(name)) == str(want), name
+    for name in g[tag + "_other_names"]:
+        assert hasattr(m, str(name)), name
+    for name, shape, dtype, cs in zip(g[tag + "_arr_names"], g[tag + "_arr_shapes"], g[tag + "_arr_dtypes"], g[tag + "_arr_checksums"]):
+        name = str(name)
+        if name in ("qh0", "qh1"):
+            continue
+        a = np.asarray(getattr(m, name))
+        assert list(a.shape) + [0] * (2 - a.ndim) == list(shape), (name, a.shape, shape)
+        assert str(a.dtype) == str(dtype), (name, a.dtype, dtype)
+        z = a.astype(complex).ravel()
+        w = np.cos(0.37 * np.arange(z.size))
+        scale = np.abs(z).sum() + 1e-300
+        assert abs(z.sum() - cs[0]) <= 1e-12 * scale and abs((z * w).sum() - cs[1]) <= 1e-12 * scale, (name, z.sum(), cs)

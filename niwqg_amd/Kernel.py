@@ -161,6 +161,16 @@ class Kernel(object):
         if name == "upsilon":
             a2 = np.abs(self.phi) ** 2
             return a2 - a2.mean()
+        if self.__dict__.get("model_id", type(self).model_id) == _lib.COUPLED:
+            # what CoupledModel._invert leaves behind (ref: niwqg/CoupledModel.py:83-92), on demand through the FFT seam
+            if name == "phi2":
+                return np.abs(self.phi) ** 2
+            if name == "gphi2h":
+                return -self.wv2 * self.fft(self.phi2)
+            if name == "pw":
+                return self.ifft(self.wv2i * self.qwh).real
+            if name == "pv":
+                return self.ifft(-(self.wv2i * self.qh)).real
         raise AttributeError(name)
 
     def _build_planes(self):

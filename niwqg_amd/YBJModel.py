@@ -10,6 +10,8 @@ Drop-in for ``niwqg.YBJModel.Model`` (ref: niwqg/YBJModel.py:4-158).  Only phi i
 * the physical streamfunction ``p`` is allocated but never filled (YBJModel.py:45-46, :141-146), so the ``ep_psi``
   diagnostic (Kernel.py:635-640) sees p = 0 and keeps its nu4 term only.
 """
+import numpy as np
+
 from . import Kernel, _lib
 
 
@@ -34,6 +36,11 @@ class Model(Kernel.Kernel):
     def _invert(self):
         """ref: niwqg/YBJModel.py:141-146 (psi is steady: nothing to do after set_q)"""
         pass
+
+    @property
+    def p(self):
+        """the reference allocates p as zeros and its purely spectral _invert never fills it (niwqg/YBJModel.py:43, :141-146)"""
+        return np.zeros((self.ny, self.nx))
 
     def _calc_ep_psi(self):
         """ref: niwqg/Kernel.py:635-640 with the reference's p = 0 (see module docstring)"""

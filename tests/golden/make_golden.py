@@ -460,8 +460,39 @@ def g13():
 
 def g14():
     out = {}
+    attribute_inventory(out, "", lambda mod: mod.Model(nx=64))
+    save("g14_instance_attributes.npz", **out)
+
+
+def g15():
+    """the same inventory after set_q, set_phi (set_c) and three steps with a diagnostics tick and a status line at every step"""
+    out = {}
+
+    def stepped(mod):
+        if mod is QGModel:
+            m = mod.Model(L=L, nx=64, tmax=1e30, dt=0.05 * TE * 2, twrite=1, nu4=7.5e8 * 16, nu=5.0, mu=1e-8, use_filter=True, U=-U0,
+                          tdiags=1, beta=2e-11, passive_scalar=True, nu4c=3e9, nuc=2.0, muc=1e-8, save_to_disk=False)
+        else:
+            kw = notebook_kwargs(64, True, 10, tdiags=1)
+            kw.update(nu4w=1e10, mu=1e-8, muw=2e-8, twrite=1)
+            m = mod.Model(**kw)
+        rng = np.random.default_rng(15)
+        m.set_q(ic.LambDipole(m, U=U0, R=2 * np.pi / K0) + 1e-6 * rng.standard_normal((64, 64)))
+        if mod is QGModel:
+            m.set_c(1.0 + 0.3 * rng.standard_normal((64, 64)))
+        else:
+            m.set_phi(ic.WavePacket(m, k=2 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2) * 0.1
+                      + 0.01 * (rng.standard_normal((64, 64)) + 1j * rng.standard_normal((64, 64))))
+        step_to(m, 3)
+        return m
+    attribute_inventory(out, "", stepped)
+    save("g15_attributes_after_three_steps.npz", **out)
+
+
+def attribute_inventory(out, prefix, make):
     for tag, mod in (("coupled", CoupledModel), ("uncoupled", UnCoupledModel), ("qg", QGModel), ("ybj", YBJModel)):
-        m = mod.Model(nx=64)
+        tag = prefix + tag
+        m = make(mod)
         num, txt, arr = {}, {}, {}
         for k, v in m.__dict__.items():
             if isinstance(v, (bool, np.bool_)):
@@ -487,7 +518,6 @@ def g14():
             cs.append([a.sum(), (a * w).sum()])
         out[tag + "_arr_checksums"] = np.array(cs)
         out[tag + "_other_names"] = np.array(sorted(k for k in m.__dict__ if k not in num and k not in txt and k not in arr), dtype="U32")
-    save("g14_instance_attributes.npz", **out)
 
 
 if __name__ == "__main__":

@@ -1085,3 +1085,59 @@ def test_fresh_instance_carries_the_references_attributes(golden, tag):
         w = np.cos(0.37 * np.arange(z.size))
         scale = np.abs(z).sum() + 1e-300
         assert abs(z.sum() - cs[0]) <= 1e-12 * scale and abs((z * w).sum() - cs[1]) <= 1e-12 * scale, (name, z.sum(), cs)
+
+
+@pytest.mark.parametrize("tag", ["coupled", "uncoupled", "qg", "ybj"])
+def test_instance_attributes_after_three_steps_are_the_references(golden, tag):
+    """Golden g15 (make_golden.py g15): the same inventory after set_q, set_phi (QGModel with its passive scalar: set_c) and three
+    _step_forward calls with a diagnostics tick and a status line at every step -- everything the reference's instance then
+    carries: Ke, Kw, Pw, the status values ke, kew, pew, cfl, what the tick leaves behind (gamma1, gamma2, xi1, xi2, pi, ke_niw,
+    cke_niw, ike_niw, ke_qg_q/w/qw; C2, gradC2, cvar, Gamma_c) and its arrays (u, v, q_psi, qw, qwh, pv, pw, phi2, gphi2h, phix,
+    phiy, lapphi, upsilon, phq, phw, uq, vq, uw, vw; lapc, c, ch and the scalar's ETDRK4 planes).  Exempt: the work copies of the
+    step (qh0, qh1, phih0, phih1, ch0, ch1)."""
+    M = models()
+    from niwqg_amd import InitialConditions as ic
+    g = golden("g15_attributes_after_three_steps.npz")
+    cls = {"coupled": M.CoupledModel, "uncoupled": M.UnCoupledModel, "qg": M.QGModel, "ybj": M.YBJModel}[tag]
+    if tag == "qg":
+        m = cls.Model(L=L, nx=64, tmax=1e30, dt=0.05 * TE * 2, twrite=1, nu4=7.5e8 * 16, nu=5.0, mu=1e-8, use_filter=True, U=-U0,
+                      tdiags=1, beta=2e-11, passive_scalar=True, nu4c=3e9, nuc=2.0, muc=1e-8, save_to_disk=False)
+    else:
+        kw = notebook_kwargs(64, True, tdiags=1)
+        kw.update(nu4w=1e10, mu=1e-8, muw=2e-8, twrite=1)
+        kw["tmax"] = 9.5 * kw["dt"]
+        m = cls.Model(**kw)
+    rng = np.random.default_rng(15)
+    m.set_q(ic.LambDipole(m, U=U0, R=2 * np.pi / K0) + 1e-6 * rng.standard_normal((64, 64)))
+    if tag == "qg":
+        m.set_c(1.0 + 0.3 * rng.standard_normal((64, 64)))
+    else:
+        m.set_phi(ic.WavePacket(m, k=2 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2) * 0.1
+                  + 0.01 * (rng.standard_normal((64, 64)) + 1j * rng.standard_normal((64, 64))))
+    steps(m, 3)
+    bad = []
+    for name, want in zip(g[tag + "_num_names"], g[tag + "_num_values"]):
+        name = str(name)
+        if not hasattr(m, name):
+            bad.append((name, "missing"))
+            continue
+        got = float(getattr(m, name))
+        if not np.isclose(got, float(want), rtol=1e-7, atol=1e-30):
+            bad.append((name, got, float(want)))
+    for name, shape, dtype, cs in zip(g[tag + "_arr_names"], g[tag + "_arr_shapes"], g[tag + "_arr_dtypes"], g[tag + "_arr_checksums"]):
+        name = str(name)
+        if name in ("qh0", "qh1", "phih0", "phih1", "ch0", "ch1"):
+            continue
+        if not hasattr(m, name):
+            bad.append((name, "missing"))
+            continue
+        a = np.asarray(getattr(m, name))
+        if list(a.shape) + [0] * (2 - a.ndim) != list(shape) or str(a.dtype) != str(dtype):
+            bad.append((name, a.shape, str(a.dtype), list(shape), str(dtype)))
+            continue
+        z = a.astype(complex).ravel()
+        w = np.cos(0.37 * np.arange(z.size))
+        scale = np.abs(z).sum() + 1e-300
+        if not (abs(z.sum() - cs[0]) <= 1e-9 * scale and abs((z * w).sum() - cs[1]) <= 1e-9 * scale):
+            bad.append((name, "checksum", abs(z.sum() - cs[0]) / scale, abs((z * w).sum() - cs[1]) / scale))
+    assert not bad, bad

@@ -169,7 +169,7 @@ int nq_refraction(nq_ctx* ctx, double* out_cplx);
  *   [0..3]  sum wv2^n |phih|^2, n = 0..3      (ke_niw, pe_niw, ep_phi, chi_phi; Kernel.py:604-611, :629-652)
  *   [4,5]   phih[0,0]                         (cke_niw, pi; Kernel.py:701-706)
  *   [6]     sum |H qh|^2          -> ens      [7] sum wv4 |qh|^2 -> chi_q        [8]  sum |qh|^2/wv2  -> ke_qg_q
- *   [9]     sum |qwh|^2/wv2       -> ke_qg_w  [10] sum Re(conj(H qh) H qwh)/wv2 -> -ke_qg_qw
+ *   [9]     sum |qwh|^2/wv2       -> ke_qg_w  [10] sum Re(conj(H qh) H qwh) (l'^2 + k'^2)/wv2^2, l' = 0 on row ny/2, k' = 0 on column nx/2 -> -ke_qg_qw
  *   [11]    sum wv2 |ph|^2        -> ke_qg    [12..14] sum {wv4, wv2, 1} Re(conj(H ph) H qh) -> ep_psi (Kernel.py:635-640)
  *   [15]    mean(q_psi)
  *   [16..23] physical sums: q^2, q_psi^2, q_psi^3, (q_psi-mean)^2, ups^2, ups q_psi, q_psi Re(phi), q_psi Im(phi),

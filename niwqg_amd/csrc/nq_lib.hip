@@ -497,7 +497,11 @@ __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, 
       if (fs > 0.0) w2 *= (wt == 2.0 ? 0.5 * (fp * fp + fm * fm) : fp * fp) / (fs * fs);
     }
     v[3] += wt * wv2i * w2;                                       // sum |qw|^2 / wv2       -> ke_qg_w
-    v[4] += wt * wv2i * (hq.x * hw.x + hq.y * hw.y);              // sum Re(conj q qw)/wv2  -> ke_qg_qw
+    // -> ke_qg_qw = mean(uq uw + vq vw) of PHYSICAL fields (CoupledModel.py:110-112): u = Re ifft(-il psi) has nothing from the
+    // Nyquist row, v = Re ifft(ik psi) nothing from the Nyquist column (Hermitian psi: the two partners cancel), and qwh has no
+    // anti-Hermitian part for q-hat's to pair with.  Without a filter those two lines carry energy (2 of 460 random draws, 8e-6).
+    const double w2eff = ((l == N / 2) ? 0.0 : ly * ly) + ((k == N / 2) ? 0.0 : kx * kx);
+    v[4] += wt * wv2i * wv2i * w2eff * (hq.x * hw.x + hq.y * hw.y);
     // -> ke_qg.  Dual-copy (2/3 mask) contexts: the reference's ph = fft of the REAL p is the Hermitian part, and there the two
     // self-mirrored columns of the stored psi-hat are not Hermitian in l.  (QGModel's ph = -wv2i qh is summed as it is.)
     const cd pk = (qp != nullptr) ? hp : p;

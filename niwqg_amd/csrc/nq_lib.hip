@@ -464,7 +464,7 @@ __global__ void k_diag_phi(const cd* __restrict__ phih, int N, int width, int pi
 __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, const cd* __restrict__ ph, int N,
                          int width, int pitch, int k0, const double* __restrict__ kk, const double* __restrict__ ll,
                          double* __restrict__ part, const cd* __restrict__ qp, const cd* __restrict__ qm_,
-                         const double* __restrict__ filt_p, const double* __restrict__ filt_m) {
+                         const double* __restrict__ filt_p, const double* __restrict__ filt_m, const cd* __restrict__ passenger) {
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const size_t total = (size_t)N * width;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -487,6 +487,10 @@ __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, 
     if (qp != nullptr && wt == 2.0) {
       const cd a = qp[idx], b = qm_[idx];
       q2 = 0.5 * (a.x * a.x + a.y * a.y + b.x * b.x + b.y * b.y);
+    }
+    if (passenger != nullptr && l == N / 2 && wt == 2.0) {       // the reference's full-plane qh carries an anti-Hermitian part A on
+      const cd a = passenger[kl];                                  // this row: |qh(l,k)|^2 + |qh(l,-k)|^2 = 2 |H|^2 + 2 |A|^2 (spec_var sees it)
+      q2 += a.x * a.x + a.y * a.y;
     }
     v[0] += wt * (hq.x * hq.x + hq.y * hq.y);                     // sum |H q|^2            -> ens
     v[1] += wt * wv4 * q2;                                        // sum wv4 |q|^2          -> chi_q
@@ -2725,7 +2729,8 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
     if (x->Wh > 0) {
       hipLaunchKernelGGL(k_diag_q, dim3(NB), dim3(256), 0, x->stream, qh, (const cd*)(coupled ? x->qwh : nullptr), (const cd*)x->ph, N, x->Wh, x->Ph, x->kh0, x->kk, x->ll, x->diag_part,
                          (const cd*)(x->dual ? x->q.y[x->q.cur] : nullptr), (const cd*)(x->dual ? x->q2.y[x->q2.cur] : nullptr),
-                         (const double*)(x->dual ? x->filt_h : nullptr), (const double*)(x->dual ? x->filt_m : nullptr));
+                         (const double*)(x->dual ? x->filt_h : nullptr), (const double*)(x->dual ? x->filt_m : nullptr),
+                         (const cd*)(x->pass ? x->qp.y[x->qp.cur] : nullptr));
       hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, NB, 9, 9, d + 6);
     }
     if (x->kh0 == 0) {                              // [15] <- Re(qh - qwh)[0,0] (the owner of column 0 contributes it)
@@ -3402,7 +3407,8 @@ int nq_diagnostics(nq_ctx* c, double* out) {
   }
   hipLaunchKernelGGL(k_diag_q, dim3(NB), dim3(256), 0, c->stream, qh, (const cd*)(c->p.model == NQ_MODEL_COUPLED ? c->qwh : nullptr), (const cd*)c->ph, N, c->Wh, c->Ph, 0, c->kk, c->ll, c->diag_part,
                      (const cd*)(c->dual ? c->q.y[c->q.cur] : nullptr), (const cd*)(c->dual ? c->q2.y[c->q2.cur] : nullptr),
-                     (const double*)(c->dual ? c->filt_h : nullptr), (const double*)(c->dual ? c->filt_m : nullptr));
+                     (const double*)(c->dual ? c->filt_h : nullptr), (const double*)(c->dual ? c->filt_m : nullptr),
+                     (const cd*)(c->pass ? c->qp.y[c->qp.cur] : nullptr));
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->diag_part, NB, 9, 9, d + 6);
   double h[32];
   HIPCHK(c, hipMemcpyAsync(h, d, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));

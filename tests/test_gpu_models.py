@@ -837,7 +837,7 @@ def test_randomly_drawn_configurations_on_slabs_against_the_oracle(seed):
     random_configuration_against_the_oracle(seed, on_slabs=True)
 
 
-def draw_configuration(seed, on_slabs=False, order_rng=None, nx_force=None):
+def draw_configuration(seed, on_slabs=False, order_rng=None, nx_force=None, device_kw=None):
     """One seeded draw: the device model and the oracle, both initialised (see random_configuration_against_the_oracle).
     order_rng: draw the set_q / set_phi order as well (quirk Q2)."""
     rng = np.random.default_rng(1000 + seed)
@@ -854,10 +854,10 @@ def draw_configuration(seed, on_slabs=False, order_rng=None, nx_force=None):
               U=float(rng.choice([0.0, -U0, 0.5 * U0])), nu4=5e11 * (128.0 / nx) ** 4 * float(rng.uniform(0.2, 2.0)),
               nu=float(rng.choice([0.0, 20.0])), mu=float(rng.choice([0.0, 1e-8])))
     mods = models()
-    extra = {}
+    extra = dict(device_kw or {})          # keywords for the device model only (output files ...)
     if on_slabs:
         srng = np.random.default_rng(5000 + seed)
-        extra = dict(slab=int(srng.choice([2, 4] if nx >= 128 else [2])), nchunks=int(srng.choice([1, 2])))
+        extra.update(slab=int(srng.choice([2, 4] if nx >= 128 else [2])), nchunks=int(srng.choice([1, 2])))
     if kind == "qg":
         passive = bool(rng.integers(0, 2))
         kw.update(beta=float(rng.choice([0.0, 2e-11])), passive_scalar=passive, nu4c=kw["nu4"] * 0.5, nuc=2.0, muc=1e-8)
@@ -900,7 +900,10 @@ def random_configuration_against_the_oracle(seed, on_slabs=False, nx_force=None)
     array-parallel QG kernel all occur), filter / 2-3 mask / none, mean flow, every dissipation coefficient, beta, the passive scalar,
     the diagnostics cadence (quirk Q1 acts through it) -- white-noise plus large-scale initial fields, 6 steps through
     _step_forward, against the reference-pinned oracle: fields 1e-11, budgets 1e-8, and every diagnostics series the tick recorded."""
-    m, o, kind, kw, rng, tag = draw_configuration(seed, on_slabs, nx_force=nx_force)
+    # every fifth draw of the Kernel family carries the dual copy of q-hat without the 2/3 mask (exact_qh: the other spectral kernels)
+    kind0 = ["coupled", "uncoupled", "qg", "ybj", "coupled", "qg"][seed % 6]
+    device_kw = dict(exact_qh=True) if (seed % 5 == 4 and kind0 in ("coupled", "uncoupled")) else None
+    m, o, kind, kw, rng, tag = draw_configuration(seed, on_slabs, nx_force=nx_force, device_kw=device_kw)
     for _ in range(6):
         o._step_forward()
     steps(m, 6)
@@ -1141,3 +1144,62 @@ def test_instance_attributes_after_three_steps_are_the_references(golden, tag):
         if not (abs(z.sum() - cs[0]) <= 1e-9 * scale and abs((z * w).sum() - cs[1]) <= 1e-9 * scale):
             bad.append((name, "checksum", abs(z.sum() - cs[0]) / scale, abs((z * w).sum() - cs[1]) / scale))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("NQ_FUZZ_SAVE_SEEDS", "8")))))
+def test_randomly_drawn_runs_with_output_files_against_the_oracle(seed, tmp_path):
+    """run() with save_to_disk=True on drawn configurations (all four classes, sometimes on slab ranks: rank 0 writes), a drawn
+    snapshot period and drawn status / tick cadences, through a recording writer in place of h5py: the snapshot files are the
+    reference's (the initial condition, then every tsave_snapshots steps, named by the model time: Kernel.py:194-195, Saving.py:
+    59-86), each holds the ORACLE's state at that step although it left the device while later steps ran, and diagnostics.h5 holds
+    the series."""
+    from niwqg_amd import Saving
+
+    class Rec(object):
+        files = {}
+
+        def __init__(self, fno):
+            self.fno, self.data = fno, {}
+
+        def create_dataset(self, name, data=None, dtype=None):
+            self.data[name] = np.array(data, dtype=dtype)
+
+        def close(self):
+            open(self.fno, "w").write("stub")
+            Rec.files[self.fno] = self.data
+
+    srng = np.random.default_rng(11000 + seed)
+    tsave = int(srng.choice([2, 3, 5]))
+    path = str(tmp_path / "out")
+    Saving.set_writer(Rec)
+    try:
+        m, o, kind, kw, rng, tag = draw_configuration(seed, on_slabs=bool(seed % 4 == 3),
+                                                      device_kw=dict(save_to_disk=True, tsave_snapshots=tsave, path=path))
+        nsteps = int(srng.integers(6, 16))
+        twrite = int(srng.choice([4, 10 ** 9]))
+        tag = "%s tsave=%d twrite=%d nsteps=%d" % (tag, tsave, twrite, nsteps)
+        for x in (m, o):
+            x.twrite = twrite
+            x.tmax = (nsteps - 0.5) * x.dt
+        fields = ["q", "c"] if (kind == "qg" and kw["passive_scalar"]) else (["q"] if kind == "qg" else ["q", "phi"])
+        want = {'{:015.0f}.h5'.format(0.0): {f: np.array(getattr(o, f)) for f in fields}}
+        want['{:015.0f}.h5'.format(0.0)]["t"] = 0.0
+        m.run()
+        while o.t < o.tmax:
+            o._step_forward()
+            if o.tc % tsave == 0:
+                want['{:015.0f}.h5'.format(o.t)] = dict({f: np.array(getattr(o, f)) for f in fields}, t=o.t)
+        assert m.tc == o.tc == nsteps, tag
+        assert sorted(os.listdir(path + "/snapshots")) == sorted(want), (tag, sorted(os.listdir(path + "/snapshots")), sorted(want))
+        for name, ref in want.items():
+            snap = Rec.files[path + "/snapshots/" + name]
+            assert set(snap) == set(ref), (tag, name, set(snap))
+            assert float(snap["t"]) == float(ref["t"]), (tag, name)
+            for f in fields:
+                assert rel(snap[f], ref[f]) < 1e-10, (tag, name, f)
+        d = Rec.files[path + "/diagnostics.h5"]
+        assert set(d) == set(m.diagnostics), tag
+        for key in d:
+            assert np.array_equal(d[key], np.array(m.diagnostics[key]["value"])), (tag, key)
+    finally:
+        Saving.set_writer(None)

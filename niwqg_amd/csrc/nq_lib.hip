@@ -498,7 +498,10 @@ __global__ void k_diag_q(const cd* __restrict__ qh, const cd* __restrict__ qwh, 
     double w2 = w.x * w.x + w.y * w.y;
     if (filt_p != nullptr) {
       const double fp = filt_p[idx], fm = filt_m[idx], fs = 0.5 * (fp + fm);
-      if (fs > 0.0) w2 *= (wt == 2.0 ? 0.5 * (fp * fp + fm * fm) : fp * fp) / (fs * fs);
+      if (fs > 0.0) {                      // as ratios: fs * fs underflows in the far corner of the exponential filter (exact_qh)
+        const double a = fp / fs, b = fm / fs;
+        w2 *= (wt == 2.0) ? 0.5 * (a * a + b * b) : a * a;
+      }
     }
     v[3] += wt * wv2i * w2;                                       // sum |qw|^2 / wv2       -> ke_qg_w
     // -> ke_qg_qw = mean(uq uw + vq vw) of PHYSICAL fields (CoupledModel.py:110-112): u = Re ifft(-il psi) has nothing from the

@@ -837,7 +837,7 @@ def test_randomly_drawn_configurations_on_slabs_against_the_oracle(seed):
     random_configuration_against_the_oracle(seed, on_slabs=True)
 
 
-def draw_configuration(seed, on_slabs=False, order_rng=None, nx_force=None, device_kw=None):
+def draw_configuration(seed, on_slabs=False, order_rng=None, nx_force=None, device_kw=None, vary_physics=False):
     """One seeded draw: the device model and the oracle, both initialised (see random_configuration_against_the_oracle).
     order_rng: draw the set_q / set_phi order as well (quirk Q2)."""
     rng = np.random.default_rng(1000 + seed)
@@ -857,7 +857,7 @@ def draw_configuration(seed, on_slabs=False, order_rng=None, nx_force=None, devi
     extra = dict(device_kw or {})          # keywords for the device model only (output files ...)
     if on_slabs:
         srng = np.random.default_rng(5000 + seed)
-        extra.update(slab=int(srng.choice([2, 4] if nx >= 128 else [2])), nchunks=int(srng.choice([1, 2])))
+        extra.update(slab=int(srng.choice(([2, 4, 8] if nx >= 1024 else [2, 4]) if nx >= 128 else [2])), nchunks=int(srng.choice([1, 2])))
     if kind == "qg":
         passive = bool(rng.integers(0, 2))
         kw.update(beta=float(rng.choice([0.0, 2e-11])), passive_scalar=passive, nu4c=kw["nu4"] * 0.5, nuc=2.0, muc=1e-8)
@@ -865,6 +865,10 @@ def draw_configuration(seed, on_slabs=False, order_rng=None, nx_force=None, devi
     else:
         kw.update(m=MZ, N=NB, f=F0, nuw=float(rng.choice([0.0, 50.0])), nu4w=float(rng.choice([0.0, 0.1])) * kw["nu4"],
                   muw=float(rng.choice([0.0, 2e-8])))
+        if vary_physics:         # the vertical wavenumber and f set kappa2 and hslash: dispersion, refraction and wave-PV coefficients
+            vrng = np.random.default_rng(13000 + seed)
+            kw.update(m=MZ * float(vrng.choice([0.5, 1.0, 2.0])), f=F0 * float(vrng.choice([1.0, 2.0])),
+                      N=NB * float(vrng.choice([1.0, 0.5])))
         cls = {"coupled": mods.CoupledModel, "uncoupled": mods.UnCoupledModel, "ybj": mods.YBJModel}[kind]
         m, o = cls.Model(**kw, **extra), O.NIWQGOracle(kind, **kw)
     q0 = O.lamb_dipole(o.grid, U=U0, R=2 * np.pi / K0) + 2e-6 * rng.standard_normal((nx, nx))
@@ -893,6 +897,12 @@ def test_randomly_drawn_configurations_at_1024_against_the_oracle(seed):
     """The same draws on a 1024^2 grid: the two-pass column tiles (S1 x S2 = 32 x 32) and the 8-point row plan, which the grids
     <= 512 of the other draws never run, under every option combination (dual copy, passive scalar, YBJ, U = 0 ...)."""
     random_configuration_against_the_oracle(seed, nx_force=1024)
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("NQ_FUZZ_1024_SLAB_SEEDS", "2")))))
+def test_randomly_drawn_configurations_at_1024_on_slabs_against_the_oracle(seed):
+    """... and the 1024^2 draws on 2, 4 or 8 slab ranks with 1 or 2 row chunks (the slab instantiations of the 8-point row plan)."""
+    random_configuration_against_the_oracle(100 + seed, on_slabs=True, nx_force=1024)
 
 
 def random_configuration_against_the_oracle(seed, on_slabs=False, nx_force=None):
@@ -950,7 +960,10 @@ def random_call_sequence_against_the_oracle(seed, on_slabs=False):
     diagnostics tick the reference's u, v are still the fourth stage's (Kernel.py:364-368), and jacobian_psi_phi, _calc_cfl and
     m.u, m.v must say so (Kernel._uv_of_stage4)."""
     arng = np.random.default_rng(9000 + seed)
-    m, o, kind, kw, rng, tag = draw_configuration(seed, on_slabs=on_slabs, order_rng=arng)
+    kind0 = ["coupled", "uncoupled", "qg", "ybj", "coupled", "qg"][seed % 6]
+    device_kw = dict(exact_qh=True) if (seed % 7 == 3 and kind0 in ("coupled", "uncoupled")) else None
+    m, o, kind, kw, rng, tag = draw_configuration(seed, on_slabs=on_slabs, order_rng=arng, device_kw=device_kw,
+                                                  vary_physics=bool(seed % 2))
     nx = kw["nx"]
     wave = kind in ("coupled", "uncoupled")
     actions = ["step", "step", "step", "read", "energies", "cfl", "set_q"]
@@ -1025,7 +1038,10 @@ def test_randomly_drawn_runs_against_the_oracle(seed):
     the quiet steps in between, the oracle takes them one by one.  Clock, fields, budgets, every diagnostics series, the last
     status values."""
     rrng = np.random.default_rng(7000 + seed)
-    m, o, kind, kw, rng, tag = draw_configuration(seed, on_slabs=bool(seed % 3 == 2), order_rng=rrng)
+    kind0 = ["coupled", "uncoupled", "qg", "ybj", "coupled", "qg"][seed % 6]
+    device_kw = dict(exact_qh=True) if (seed % 7 == 3 and kind0 in ("coupled", "uncoupled")) else None
+    m, o, kind, kw, rng, tag = draw_configuration(seed, on_slabs=bool(seed % 3 == 2), order_rng=rrng, device_kw=device_kw,
+                                                  vary_physics=bool(seed % 2))
     twrite = int(rrng.choice([3, 5, 10 ** 9]))
     legs = [int(rrng.integers(5, 14))] + ([int(rrng.integers(2, 9))] if rrng.integers(0, 2) else [])
     tag = "%s twrite=%d legs=%s" % (tag, twrite, legs)

@@ -1219,3 +1219,50 @@ def test_randomly_drawn_runs_with_output_files_against_the_oracle(seed, tmp_path
             assert np.array_equal(d[key], np.array(m.diagnostics[key]["value"])), (tag, key)
     finally:
         Saving.set_writer(None)
+
+
+def test_error_behaviour_is_the_references(tmp_path):
+    """Python exceptions only, as in the reference: AssertionError when a status line finds CFL >= cflmax
+    (Kernel.py:598, QGModel.py:578), IOError when an output file exists and overwrite=False (Saving.py:36), AttributeError for the
+    base Kernel (it has no ``model``: Kernel.py:144), NotImplementedError for QGModel's undeclared hooks (QGModel.py:271-281)."""
+    M = models()
+    from niwqg_amd import Saving, InitialConditions as ic
+    kw = notebook_kwargs(64, True)
+    kw.update(twrite=1, dt=40 * kw["dt"])                    # forty times the stable step: CFL ~ 4
+    m = M.CoupledModel.Model(**kw)
+    m.set_q(ic.LambDipole(m, U=U0, R=2 * np.pi / K0))
+    m.set_phi((np.ones((64, 64)) + 1j) * (2 * U0) / np.sqrt(2))
+    with pytest.raises(AssertionError):
+        m._step_forward()
+    g = M.QGModel.Model(L=L, nx=64, tmax=1e30, dt=40 * 0.05 * TE * 2, twrite=1, nu4=7.5e8 * 16, use_filter=True, U=-U0, tdiags=10 ** 9)
+    g.set_q(ic.LambDipole(g, U=U0, R=2 * np.pi / K0))
+    with pytest.raises(AssertionError):
+        g._step_forward()
+    with pytest.raises(AttributeError):
+        M.Kernel.Kernel()
+    for hook in ("_initialize_background", "_initialize_forcing", "_initialize_inversion_matrix"):
+        if hasattr(g, hook):
+            with pytest.raises(NotImplementedError):
+                getattr(g, hook)()
+
+    class Rec(object):
+        def __init__(self, fno):
+            self.fno = fno
+
+        def create_dataset(self, name, data=None, dtype=None):
+            pass
+
+        def close(self):
+            open(self.fno, "w").write("stub")
+
+    Saving.set_writer(Rec)
+    try:
+        path = str(tmp_path / "out")
+        kw = notebook_kwargs(64, True)
+        M.CoupledModel.Model(save_to_disk=True, path=path, **kw)                 # writes setup.h5
+        assert os.path.exists(path + "/setup.h5")
+        M.CoupledModel.Model(save_to_disk=True, path=path, overwrite=True, **kw)  # replaces it
+        with pytest.raises(IOError):
+            M.CoupledModel.Model(save_to_disk=True, path=path, overwrite=False, **kw)
+    finally:
+        Saving.set_writer(None)

@@ -937,7 +937,8 @@ def random_configuration_against_the_oracle(seed, on_slabs=False, nx_force=None)
         # (the nearly vanishing integrals -- skew, conc_niw, Gamma_c, pi, gamma_r/a, xi_r/a -- included: over 120 draws they agree
         # to 7e-12 of their own magnitude, tools/diag/fuzz_skipped_diags.py)
         scale = np.abs(b).max() if b.size else 0.0
-        assert np.allclose(a, b, rtol=1e-10, atol=1e-12 * scale + 1e-300), (tag, name, a, b)
+        loose = name in ("skew", "conc_niw", "Gamma_c", "pi", "gamma_r", "gamma_a", "xi_r", "xi_a")    # differences of nearly equal terms
+        assert np.allclose(a, b, rtol=1e-8 if loose else 1e-10, atol=(1e-10 if loose else 1e-12) * scale + 1e-300), (tag, name, a, b)
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("NQ_FUZZ_CALL_SEEDS", "12")))))
@@ -1073,7 +1074,8 @@ def test_randomly_drawn_runs_against_the_oracle(seed):
         b = np.atleast_1d(np.asarray(o.diag(name), float))
         assert a.shape == b.shape, (tag, name)
         scale = np.abs(b).max() if b.size else 0.0
-        assert np.allclose(a, b, rtol=1e-10, atol=1e-12 * scale + 1e-300), (tag, name, a, b)
+        loose = name in ("skew", "conc_niw", "Gamma_c", "pi", "gamma_r", "gamma_a", "xi_r", "xi_a")    # differences of nearly equal terms
+        assert np.allclose(a, b, rtol=1e-8 if loose else 1e-10, atol=(1e-10 if loose else 1e-12) * scale + 1e-300), (tag, name, a, b)
 
 
 @pytest.mark.parametrize("tag", ["coupled", "uncoupled", "qg", "ybj"])

@@ -16,8 +16,8 @@ fp64 (BASELINE.json configs[2]: LambDipole q, uniform phi, filter on), state res
   only if that summary was taken from the very sources that are running (sha256 of niwqg_amd/csrc + include/ stamped
   into it), else null.  `peak_measured_copy` = a 1r + 1w stream copy timed in the untimed part of the same run.
 * `cpu_baseline` times the numpy oracle in its reference-faithful mode (104 c2c numpy.fft transforms per step, one thread)
-  at 2048^2 -- measured, >= 2 steps; `value` is the measurement recorded once AT 4096^2 (`--cpu-baseline-nx 4096`, about 6
-  minutes, kept in profiles/), this run's own sample and its N^2 log2 N extrapolation ride along as the cross-check.
+  AT THE TARGET GRID in this run: one `_step_etdrk4` at 4096^2 (about 60 s; `--cpu-baseline-nx 2048` for a shorter, scaled
+  sample).  `value` is always this run's own number; the round-2 recording rides along under its own key.
 With --gpus N > 1 and no WORLD_SIZE in the environment the script starts N ranks itself (torch.distributed.run, child
 process, before any GPU call); with WORLD_SIZE set it must equal --gpus.
 """
@@ -64,6 +64,7 @@ KERNEL_B_PER_PT = {
 KERNEL_SYMBOL = {"x_products": "k_x_products", "s_phi": "k_s_phi", "x_wavepv": "k_x_wavepv", "s_q": "k_s_q",
                  "s_invert": "k_s_invert", "y_A": "k_y_A"}
 HBM_PEAK_GBS = 8000.0
+GUIDE_COPY_GBS = 6290.0          # MI355X_MICROARCH.md: measured float4 copy, 79 % of the 8 TB/s data-sheet peak
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")
 
 
@@ -102,10 +103,18 @@ def measured_traffic(symbol):
 
 
 def c3_kwargs(nx, model):
+    """SURVEY.md 8(d) "synthetic inputs per BASELINE config": C3 / C4 for the Kernel family at any nx; for QGModel C1 at 256^2
+    (ref examples/LambDipole_qg.py:21-45: dt = 0.05 Te, nu4 = 7.5e8, use_filter=False) and C2 at 2048^2 (dt = 0.05 Te / 8,
+    nu4 = 7.5e8 / 64, filter on); at other sizes the dipole workload with the round-1 scaling"""
     dt = 0.025 * TE * 128 / nx
     kw = dict(L=L, nx=nx, tmax=1e30, dt=dt, twrite=10 ** 9, tdiags=10 ** 9, use_filter=True, U=-U0)
     if model == "qg":
-        kw.update(nu4=7.5e8 / 64 if nx == 2048 else 5e11 * (128.0 / nx) ** 4, dt=0.05 * TE * 128 / nx)
+        if nx == 256:
+            kw.update(nu4=7.5e8, dt=0.05 * TE, use_filter=False)
+        elif nx == 2048:
+            kw.update(nu4=7.5e8 / 64, dt=0.05 * TE / 8)
+        else:
+            kw.update(nu4=5e11 * (128.0 / nx) ** 4, dt=0.05 * TE * 128 / nx)
     else:
         kw.update(m=MZ, N=NB, f=F0, nu4=5e11 * (128.0 / nx) ** 4, nu4w=0.0, nu=20, nuw=50.0, mu=0.0, muw=0.0)
     return kw
@@ -164,9 +173,12 @@ class _SlabCtxView(object):
             setattr(self, name, getattr(_lib.Context, name).__get__(self))
 
 
-def build_slab(model, nx, grp, local_rank, nchunks=2, kind=None):
+def build_slab(model, nx, grp, local_rank, nchunks=2, kind=None, rank_of=0):
     """One slab-decomposed simulation over all ranks of `grp` (niwqg_amd.slab).  Two stages so that the ranks can agree
-    that every one of them got its memory BEFORE the first collective: allocate() then initialise()."""
+    that every one of them got its memory BEFORE the first collective: allocate() then initialise().
+    rank_of = P > 0: rank 0 of a P-rank decomposition ALONE on this GPU, with the library's null link (nq_slab_set_null_link):
+    every launch, stream, event and row chunk of a real rank, nothing on the wire -- the compute term of DESIGN.md section 9."""
+    nranks, myrank = (rank_of, 0) if rank_of else (grp.world, grp.rank)
     from niwqg_amd import _lib, slab
     kw = c3_kwargs(nx, model)
     dk = 2 * np.pi / L
@@ -176,6 +188,8 @@ def build_slab(model, nx, grp, local_rank, nchunks=2, kind=None):
     wvx = np.sqrt((kk[None, :] * dx) ** 2. + (ll[:, None] * dx) ** 2.)
     filtr = np.exp(-23.6 * (wvx - 0.65 * np.pi) ** 4.)
     filtr[wvx <= 0.65 * np.pi] = 1.
+    if not kw["use_filter"]:
+        filtr = np.ones_like(wvx)
     mid = {"coupled": _lib.COUPLED, "uncoupled": _lib.UNCOUPLED, "qg": _lib.QG}[model]
     budgets = True
     if kind == "ybj":                 # YBJModel: the UnCoupled workload, only phi is stepped, no budgets in the step
@@ -186,14 +200,14 @@ def build_slab(model, nx, grp, local_rank, nchunks=2, kind=None):
         phys.update(f=kw["f"], kappa2=kappa2, nuw=kw["nuw"], nu4w=kw["nu4w"], muw=kw["muw"])
 
     def allocate():
-        ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], grp.world, device=local_rank, only_rank=grp.rank,
-                                budgets=budgets, torch_buffers=True, **phys)
+        ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], nranks, device=local_rank, only_rank=myrank,
+                                budgets=budgets, torch_buffers=not rank_of, **phys)
         return ranks
 
     def initialise(ranks):
         # RCCL issued by the library itself (grouped send/recv per row chunk); with gloo the library calls back into
         # Python at every exchange
-        sim = slab.connect(ranks, grp.dist, nchunks)
+        sim = slab.SlabSimulation(ranks, "null", nchunks=nchunks) if rank_of else slab.connect(ranks, grp.dist, nchunks)
 
         nloc, r0 = ranks[0].nloc, ranks[0].rank * ranks[0].nloc
         cell = (np.arange(nx) + 0.5) / nx * L
@@ -236,11 +250,12 @@ def _oracle_for(model, nx, table_workers):
 
 
 def _time_oracle(m, budget_s, min_steps, max_steps=200):
-    m._step_forward()                      # untimed: includes the one-off tc == 0 diagnostics tick
+    """times `_step_etdrk4` -- the hot path the GPU side times, without the diagnostics tick and the status line of
+    `_step_forward` (negligible at tdiags = twrite = 1e9 anyway, except for the one-off tick at tc == 0)"""
     f0 = sum(m.fft_calls)
     t0, n = time.perf_counter(), 0
     while True:
-        m._step_forward()
+        m._step_etdrk4()
         n += 1
         el = time.perf_counter() - t0
         if (el > budget_s and n >= min_steps) or n >= max_steps:
@@ -249,10 +264,13 @@ def _time_oracle(m, budget_s, min_steps, max_steps=200):
 
 
 def cpu_baseline(model, nx_target, nx_sample=None, budget_s=20.0):
-    """Reference-faithful numpy oracle (oracle/niwqg_oracle.py: numpy.fft, the reference's 104/72/33 transforms per
-    step, ONE thread for the timed steps) MEASURED at nx_sample (default 2048, or the target when smaller), >= 2 steps,
-    and scaled to nx_target by N^2 log2 N.  The untimed constructor uses a thread pool for the coefficient tables.
-    A short 512^2 run is kept as a cross-check of that scaling law (`fit_check`)."""
+    """Reference-faithful numpy oracle (oracle/niwqg_oracle.py: numpy.fft, the reference's 104/72/33 transforms per step, ONE
+    thread for the timed steps) MEASURED IN THIS RUN, on this box's host cores, AT THE TARGET GRID by default: at 4096^2 one
+    `_step_etdrk4` is about 60 s, so the sample is exactly one step there (>= 2 steps or 20 s on smaller grids).  `value` is
+    always what this run measured (scaled by N^2 log2 N only when --cpu-baseline-nx asks for a smaller sample grid).  The
+    untimed constructor uses a thread pool for the coefficient tables.  Cross-checks that ride along under their own keys: a
+    short 512^2 run against the N^2 log2 N law (`fit_check`), and the 4096^2 measurement recorded in round 2 on another box
+    (`recorded_measurement_at_target_nx`, with its file)."""
     try:
         import threadpoolctl
         threadpoolctl.threadpool_limits(1)
@@ -260,31 +278,30 @@ def cpu_baseline(model, nx_target, nx_sample=None, budget_s=20.0):
         pass
     cores = os.cpu_count() or 1
     tw = max(1, min(16, cores - 1))
-    nx = nx_sample or min(nx_target, 2048)
+    nx = nx_sample or nx_target
 
     def cost(n):
         return n ** 2 * np.log2(n)
 
+    t_build = time.perf_counter()
     m = _oracle_for(model, nx, tw)
-    n, el, nfft = _time_oracle(m, budget_s, 2)
+    t_build = time.perf_counter() - t_build
+    n, el, nfft = _time_oracle(m, budget_s, 1 if nx >= 4096 else 2)
     del m
     sps = n / el
     out = {"value": sps * cost(nx) / cost(nx_target), "unit": "steps/s", "cores": 1, "kind": "port",
-           "sample": "%s oracle (numpy.fft, %d transforms/step, 1 thread) MEASURED at %d^2: %d steps in %.1f s = %.4f steps/s%s"
+           "value_source": "measured in this run" if nx == nx_target else "measured in this run at %d^2, scaled by N^2 log2 N" % nx,
+           "sample": "%s oracle (numpy.fft, %d transforms/step, 1 thread) MEASURED at %d^2 in this run: %d x _step_etdrk4 in %.1f s = %.4f steps/s%s"
                      % (model, nfft, nx, n, el, sps,
                         "" if nx == nx_target else "; scaled by N^2 log2 N (x%.2f) to %d^2" % (cost(nx_target) / cost(nx), nx_target)),
-           "measured_steps_per_s_at_sample": sps, "sample_nx": nx, "sample_steps": n, "host_cores_available": cores}
+           "measured_steps_per_s_at_sample": sps, "sample_nx": nx, "sample_steps": n, "host_cores_available": cores,
+           "untimed_setup_s": t_build}
     rec = os.path.join(ROOT, "profiles", "r02_bench_line_cpu_baseline_measured_at_4096.json")
-    if model == "coupled" and nx_target == 4096 and nx != 4096 and os.path.exists(rec):
+    if model == "coupled" and nx_target == 4096 and os.path.exists(rec):
         try:
-            # The same leg was MEASURED once AT the target size (bench.py --cpu-baseline-nx 4096, 59 s per step: too long for
-            # every run).  That measurement is the headline `value`; what this run measured at the smaller grid and its
-            # N^2 log2 N extrapolation (28 % optimistic) ride along as the cross-check.
             r = json.load(open(rec))["cpu_baseline"]
-            out["extrapolated_from_this_runs_sample"] = {"steps_per_s": out["value"], "sample": out["sample"]}
-            out["value"] = r["measured_steps_per_s_at_sample"]
-            out["sample"] = ("recorded measurement AT %d^2 (%s): %s; this run's own sample at %d^2 (%.4f steps/s) is the cross-check"
-                             % (nx_target, os.path.relpath(rec, ROOT), r["sample"], nx, sps))
+            out["recorded_measurement_at_target_nx"] = {"steps_per_s": r["measured_steps_per_s_at_sample"], "file": os.path.relpath(rec, ROOT),
+                                                        "host": "another box, round 2", "sample": r["sample"]}
         except Exception:
             pass
     if nx > 512:
@@ -365,13 +382,16 @@ def main():
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--model", default="coupled", choices=["coupled", "uncoupled", "qg", "ybj"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-nx", type=int, default=0, help="grid of the MEASURED CPU sample (default: min(nx, 2048))")
+    ap.add_argument("--cpu-baseline-nx", type=int, default=0, help="grid of the MEASURED CPU sample (default: nx itself)")
     ap.add_argument("--force-slab", action="store_true", help="use the slab path (and its collectives) even with one rank")
     ap.add_argument("--members", type=int, default=0, help="BASELINE config 5 instead of the headline: this many "
                     "independent UnCoupledModel 1024^2 members PER GPU (8 in the config), no collective")
     ap.add_argument("--chunks", type=int, default=2, help="row chunks per exchange of the slab path (1, 2, 4, 8)")
     ap.add_argument("--watchdog-seconds", type=int, default=600, help="multi-rank runs: abort (exit 124) when one phase "
                     "of the run makes no progress for this long (0 = off)")
+    ap.add_argument("--rank-of", type=int, default=0, help="measure ONE rank of a P-rank slab decomposition alone on this GPU "
+                    "(P = 2, 4, 8; no exchange, nq_slab_set_null_link): the per-rank compute term of the strong-scaling "
+                    "arithmetic, next to the single-GPU step of the same run")
     ap.add_argument("--replicas", action="store_true", help="with --gpus N > 1: N independent replicas instead of one "
                                                             "slab-decomposed simulation")
     args = ap.parse_args()
@@ -419,11 +439,13 @@ def main():
     phys_model = "uncoupled" if args.model == "ybj" else args.model       # YBJ: the UnCoupled workload, phi-only stepping
     mode = "single GPU"
     sim = None
-    if (world > 1 or (args.force_slab and grp.dist is not None)) and not args.replicas:
+    if args.rank_of and world > 1:
+        sys.exit("bench.py: --rank-of measures one rank alone: run it with --gpus 1")
+    if args.rank_of or ((world > 1 or (args.force_slab and grp.dist is not None)) and not args.replicas):
         # ONE simulation, slab-decomposed over the ranks.  Allocation is the only step allowed to fail
         # softly: the ranks agree on it BEFORE the first collective; from then on any error is fatal (a rank that
         # dropped out of a collective sequence cannot be recovered from inside the job).
-        allocate, initialise = build_slab(phys_model, args.nx, grp, local_rank, args.chunks, kind=args.model)
+        allocate, initialise = build_slab(phys_model, args.nx, grp, local_rank, args.chunks, kind=args.model, rank_of=args.rank_of)
         err, ranks = None, None
         try:
             ranks = allocate()
@@ -436,7 +458,7 @@ def main():
             grp.close()
             sys.exit(3)
         sim, ctx = initialise(ranks)
-        mode = "slab x%d: %s" % (world, sim.describe())
+        mode = "slab x%d: %s" % (args.rank_of or world, sim.describe())
     if sim is None:
         m = build_model(phys_model, args.nx, local_rank, kind=args.model)
         ctx = m._ctx
@@ -554,9 +576,26 @@ def main():
             extra["replicas_aggregate_steps_per_s"] = aggregate_throughput(grp, args.steps, time.perf_counter() - t1)[0]
             del m2
 
+    if sim is not None and args.rank_of:
+        # the single-GPU step on the same box in the same run: what the rank's compute is held against (gate: <= 1.15 x step / P)
+        sim.sync()
+        m1 = build_model(phys_model, args.nx, local_rank, kind=args.model)
+        m1._ctx.step(3)
+        m1._ctx.sync()
+        t1 = time.perf_counter()
+        n1 = max(5, min(args.steps, 20))
+        m1._ctx.step(n1)
+        m1._ctx.sync()
+        single_ms = 1e3 * (time.perf_counter() - t1) / n1
+        rank_ms = dev_ms / args.steps
+        extra.update(rank_of=args.rank_of, single_gpu_ms_per_step_same_run=single_ms,
+                     rank_compute_ms_per_step=rank_ms, ideal_ms_per_step=single_ms / args.rank_of,
+                     rank_compute_over_ideal=rank_ms / (single_ms / args.rank_of))
+        del m1
+
     if rank == 0:
         npts = float(args.nx) ** 2
-        share = world if sim is not None else 1            # a slab rank's launch covers 1/world of the grid
+        share = (args.rank_of or world) if sim is not None else 1     # a slab rank's launch covers 1/P of the grid
         table = KERNEL_B_PER_PT[args.model]
         cands = [k for k in classes if k in table and classes[k][0] > 0]
         dom = max(cands, key=lambda k: classes[k][1])
@@ -575,14 +614,16 @@ def main():
         s_per_step = wall / args.steps
         peak = HBM_PEAK_GBS * share
         out = {
-            "metric": "time-steps/sec, %sModel %d^2 fp64 (achieved HBM GB/s in roofline)" % (
+            "metric": ("rank-compute steps/sec of ONE rank of %d alone (no exchange; NOT a simulation rate), " % args.rank_of if args.rank_of else "")
+                      + "time-steps/sec, %sModel %d^2 fp64 (achieved HBM GB/s in roofline)" % (
                 {"coupled": "Coupled", "uncoupled": "UnCoupled", "qg": "QG", "ybj": "YBJ"}[args.model], args.nx),
             "value": sps, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * s_per_step, "higher_is_better": True,
             "scaling": "strong" if sim is not None else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%sModel %s %d^2 fp64, ETDRK4, filter on, budgets %s"
+            "config": {"workload": "%sModel %s %d^2 fp64, ETDRK4, filter %s, budgets %s"
                                    % (args.model, "random-q" if (args.model == "qg" and args.nx == 2048) else "LambDipole",
-                                      args.nx, "on" if ctx.budgets_enabled else "off"),
+                                      args.nx, "on" if c3_kwargs(args.nx, phys_model)["use_filter"] else "off",
+                                      "on" if ctx.budgets_enabled else "off"),
                        "parallelism": mode,
                        "device_ms_per_step_hip_events": dev_ms / args.steps,
                        "blocks_ms_per_step": [round(b, 5) for b in block_ms],
@@ -606,12 +647,16 @@ def main():
                          "step_real_GBs": real_bytes / s_per_step / 1e9,
                          "step_real_frac": real_bytes / s_per_step / 1e9 / peak,
                          # second denominator: the 1r + 1w stream-copy rate measured on this device in this run
+                         "peak_guide_copy": GUIDE_COPY_GBS,
+                         "frac_of_guide_copy": achieved / GUIDE_COPY_GBS,
+                         "step_frac_of_guide_copy": step_bytes / s_per_step / 1e9 / (GUIDE_COPY_GBS * share),
+                         "step_real_frac_of_guide_copy": real_bytes / s_per_step / 1e9 / (GUIDE_COPY_GBS * share),
                          "peak_measured_copy": copy_gbs,
                          "frac_of_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "step_frac_of_copy": (step_bytes / s_per_step / 1e9 / (copy_gbs * share)) if copy_gbs else None,
                          "step_real_frac_of_copy": (real_bytes / s_per_step / 1e9 / (copy_gbs * share)) if copy_gbs else None},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.rank_of:
             out["cpu_baseline"] = cpu_baseline(phys_model, args.nx, nx_sample=args.cpu_baseline_nx or None)
         print(json.dumps(out))
     watchdog("shutdown")

@@ -65,8 +65,10 @@ enum {
   NQ_S_KE_QG = 3,                          /* _calc_ke_qg()                        Kernel.py:600-602 */
   NQ_S_KE_NIW = 4,                         /* _calc_ke_niw()                       Kernel.py:604-606 */
   NQ_S_PE_NIW = 5,                         /* _calc_pe_niw() (no side effect here) Kernel.py:608-611 */
-  NQ_S_CFL = 6                             /* max(|u|,|v|,|phi|): _calc_cfl() without the dt/dx factor
+  NQ_S_CFL = 6,                            /* max(|u|,|v|,|phi|): _calc_cfl() without the dt/dx factor
                                                                                    Kernel.py:660-662 */
+  NQ_S_MAX_PHI = 7                         /* max |phi| alone (the status line's CFL combines it with the
+                                              fourth stage's max |u|, |v|: nq_get_stage4_max)        */
 };
 
 typedef struct nq_params {
@@ -112,6 +114,14 @@ int nq_refresh_grad_phi(nq_ctx* ctx);
 /* nsteps x Kernel._step_etdrk4 (Kernel.py:307-397) / QGModel._step_etdrk4 (QGModel.py:328-407).
  * Asynchronous on the context's stream.                                                              */
 int nq_step(nq_ctx* ctx, int nsteps);
+/* After a step WITHOUT a diagnostics tick the reference's self.u, self.v are still those of the fourth jacobian_psi_q call
+ * of _step_etdrk4 (Kernel.py:364-368), and its status line's CFL (Kernel.py:594, :660-662) is taken from them.
+ * nq_request_stage4_max: the last step of the NEXT nq_step / nq_slab_step call also records max |u|, max |v| of that stage
+ * over this rank's rows (two extra row passes in that one step, nothing otherwise); nq_get_stage4_max reads them
+ * (out2 = max|u|, max|v|; -4 when the last step call recorded none).  Kernel family only (QGModel._calc_cfl recomputes
+ * u, v from psi: QGModel.py:621-629; YBJModel's u, v are steady). */
+int nq_request_stage4_max(nq_ctx* ctx);
+int nq_get_stage4_max(nq_ctx* ctx, double* out2);
 int nq_sync(nq_ctx* ctx);
 
 /* copy a field to the host in the reference's layout (blocking) */
@@ -268,6 +278,10 @@ int nq_comm_unique_id(void* out128);
 int nq_comm_init(nq_ctx* ctx, const void* id128, int nranks, int rank);
 int nq_slab_attach_peers(nq_ctx* const* ctxs, int nranks);
 int nq_slab_set_callbacks(nq_ctx* ctx, nq_exchange_fn exchange, nq_allreduce_fn allreduce, void* user);
+/* Measurement aid (bench.py --rank-of P): the context is ONE rank of its nranks-rank decomposition and runs alone -- every
+ * stream, event, row chunk and kernel launch of a real rank, but only the rank's own block crosses (device copy) and nothing
+ * is all-reduced.  The fields are not a simulation; what it gives is a rank's compute time without the exchange. */
+int nq_slab_set_null_link(nq_ctx* ctx);
 /* YBJModel on more than one rank has a fifth exchange group (4, y -> x, shaped like group 1: the stage results whose
  * gradients the next stage reads, YBJModel.py:52-87).  The library owns its buffers unless the caller hands over two
  * device buffers of nq_group_elems(p, nranks, 4) complex elements here (callback link: the caller moves them). */

@@ -12,7 +12,7 @@ from numpy import pi
 
 from . import _lib
 from .Diagnostics import add_diagnostic, increment_diagnostics
-from .Saving import (initialize_save_snapshots, save_setup, save_snapshots, save_diagnostics, flush_snapshots)
+from .Saving import (initialize_save_snapshots, save_setup, save_snapshots, save_diagnostics, flush_snapshots, flush_pending_quietly)
 
 _DEVICE_FIELDS = {"q": _lib.F_Q, "p": _lib.F_P, "phi": _lib.F_PHI, "phih": _lib.F_PHIH, "u": _lib.F_U,
                   "v": _lib.F_V, "phix": _lib.F_PHIX, "phiy": _lib.F_PHIY}
@@ -343,6 +343,11 @@ class Kernel(object):
     # ------------------------------------------------------------------ stepping
     def _step_etdrk4(self):
         """One ETDRK4 step on the device.  ref: niwqg/Kernel.py:307-397"""
+        # a status line follows this step (Kernel.py:587-590) and no diagnostics tick refreshes u, v before it (Diagnostics.py:43):
+        # its CFL comes from the FOURTH stage's u, v (Kernel.py:594 with :364-368), so that stage's maxima are recorded on the way
+        self._cfl_recorded = (self.model_id != _lib.YBJ and ((self.tc + 1) % self.twrite) == 0 and (self.tc % self.tdiags) != 0)
+        if self._cfl_recorded:
+            self._ctx.request_stage4_max()
         self._ctx.step(1)
         self._after_steps()
 
@@ -404,7 +409,7 @@ class Kernel(object):
                 save_diagnostics(self)
         finally:
             self._defer_snapshots = False
-            flush_snapshots(self)
+            flush_pending_quietly(self)      # (a failure in here must not mask the exception that is already on its way)
 
     def run_with_snapshots(self, tsnapstart=0., tsnapint=432000.):
         """ref: niwqg/Kernel.py:161-181"""
@@ -446,12 +451,15 @@ class Kernel(object):
         self._grad2_mean = 4. * self.kappa2 * pe         # mean(|phix|^2 + |phiy|^2) of the refreshed gradients
         return pe
 
+    _cfl_recorded = False
+
     def _status_cfl(self):
-        """CFL of the status line: always the device maximum.  It takes u, v of the new state where the reference still holds the
-        fourth stage's after a step without a tick: ~1e-5 relative, below what the line prints; _calc_cfl() itself is exact."""
-        if not self._uv_stage4:
-            return self._calc_cfl()
-        return self._ctx.scalar(_lib.S_CFL) * self.dt / self.dx
+        """CFL of the status line (ref: niwqg/Kernel.py:594, :660-662).  After a step without a tick the reference's u, v are the
+        fourth stage's: _step_etdrk4 had that stage's max |u|, max |v| recorded on the device (nq_request_stage4_max), max |phi| is
+        the new state's."""
+        if self._uv_stage4 and self._cfl_recorded:
+            return self._ctx.status_cfl_max() * self.dt / self.dx
+        return self._calc_cfl()
 
     def _calc_cfl(self):
         """ref: niwqg/Kernel.py:660-662"""

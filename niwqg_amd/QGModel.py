@@ -12,7 +12,7 @@ from numpy import pi
 
 from . import _lib
 from .Diagnostics import add_diagnostic, increment_diagnostics
-from .Saving import (initialize_save_snapshots, save_setup, save_snapshots, save_diagnostics, flush_snapshots)
+from .Saving import (initialize_save_snapshots, save_setup, save_snapshots, save_diagnostics, flush_snapshots, flush_pending_quietly)
 
 
 class Model(object):
@@ -152,9 +152,15 @@ class Model(object):
         return self._ctx.irfft2(x)
 
     def set_q(self, q):
-        """ref: niwqg/QGModel.py:507-520"""
+        """ref: niwqg/QGModel.py:507-520.  The reference's set_q does not touch self.u, self.v: they stay whatever the last
+        jacobian_psi_q, _calc_cfl or step left behind, i.e. those of the OLD psi, until the next of these calls.  They are read
+        out before the new q goes in and kept as they are."""
+        keep = (self.u, self.v) if self.__dict__.get("_uv_defined") else None
         self._ctx.set_q(q)
         self._dirty()
+        if keep is not None:
+            self._uv_stage4 = False
+            self._user["u"], self._user["v"] = keep
         self._user["q"] = q
         if self._ctx.budgets_enabled:
             self._ctx.scalar(_lib.S_KE)             # drop increments that belong to the old state
@@ -174,7 +180,9 @@ class Model(object):
     def jacobian_psi_c(self):
         """ik F[u c] + il F[v c] (ref: niwqg/QGModel.py:483-495); diagnostics ticks only -- inside a step the row
         kernel forms these products next to those of q."""
-        if self.__dict__.get("_uv_stage4"):
+        if "u" in self._user:                          # u, v older than the current q (set_q leaves them alone: QGModel.py:507-520)
+            u, v = self._user["u"], self._user["v"]
+        elif self.__dict__.get("_uv_stage4"):
             # the reference's u, v at a tick are those of the last jacobian_psi_q call, i.e. of the state at which
             # the step evaluated its fourth stage, not of the new state (QGModel.py:375 vs :396)
             ph4 = -self.wv2i * self._ctx.field(_lib.F_QH_STAGE4)
@@ -210,6 +218,9 @@ class Model(object):
 
     def _uv_current(self):
         """jacobian_psi_q and _calc_cfl leave the u, v of the CURRENT psi behind (QGModel.py:473-474, :626-627)"""
+        self._uv_defined = True
+        self._user.pop("u", None)
+        self._user.pop("v", None)
         if self.__dict__.get("_uv_stage4"):
             self._uv_stage4 = False
             self._cache.pop("u", None)
@@ -230,7 +241,7 @@ class Model(object):
     def _after_steps(self):
         self._dirty()
         self._stepped = True
-        self._uv_stage4 = True
+        self._uv_stage4 = self._uv_defined = True
         if self._ctx.budgets_enabled:
             self.Ke += self._ctx.scalar(_lib.S_KE)
             if self.passive_scalar:
@@ -283,7 +294,7 @@ class Model(object):
                 save_diagnostics(self)
         finally:
             self._defer_snapshots = False
-            flush_snapshots(self)
+            flush_pending_quietly(self)      # (a failure in here must not mask the exception that is already on its way)
 
     def run_with_snapshots(self, tsnapstart=0., tsnapint=432000.):
         tsnapints = np.ceil(tsnapint / self.dt)

@@ -138,6 +138,25 @@ def flush_snapshots(self):
     self._pending_snapshots = []
 
 
+def flush_pending_quietly(self):
+    """flush_snapshots for a ``finally`` clause: when an exception (say, the CFL assertion) is already propagating, a second
+    failure in here -- the copy's completion, the file write -- is logged and dropped so that the first one is what the caller sees;
+    on the normal path (nothing pending any more) it does nothing."""
+    import sys
+    if not getattr(self, "_pending_snapshots", None):
+        return
+    if sys.exc_info()[0] is None:
+        return flush_snapshots(self)
+    try:
+        flush_snapshots(self)
+    except Exception as e:                           # pragma: no cover - needs a failing writer during a failing run
+        self._pending_snapshots = []
+        try:
+            self.logger.error("snapshot flush failed while another error was propagating: %r", e)
+        except Exception:
+            pass
+
+
 def save_diagnostics(self):
     """ref: niwqg/Saving.py:88-101"""
     if not _writes(self):

@@ -26,15 +26,15 @@ HEADERS = [os.path.join(HERE, "csrc", h) for h in ("nq_fft.hpp", "nq_generic.hpp
 COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
 (F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY, F_QH_MINUS, F_C, F_CH, F_QH_STAGE4,
  F_PHIH_STAGE4, F_QH_MINUS_STAGE4) = range(19)
-(S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL) = range(7)
+(S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL, S_MAX_PHI) = range(8)
 
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
-           "nq_step", "nq_sync", "nq_get_field", "nq_get_qh_passenger", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
+           "nq_step", "nq_request_stage4_max", "nq_get_stage4_max", "nq_sync", "nq_get_field", "nq_get_qh_passenger", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
            "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_c", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_coeff_near_contour", "nq_coeff_patch", "nq_diagnostics",
            "nq_stream_copy_gbs", "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
            "nq_reduce_buffer", "nq_reduce_read", "nq_reduce_write", "nq_device_bytes", "nq_stream",
-           "nq_comm_probe", "nq_comm_unique_id", "nq_comm_init", "nq_slab_attach_peers", "nq_slab_set_callbacks", "nq_slab_config", "nq_slab_set_stage_buffers", "nq_slab_spectral", "nq_slab_spectral_read",
+           "nq_comm_probe", "nq_comm_unique_id", "nq_comm_init", "nq_slab_attach_peers", "nq_slab_set_callbacks", "nq_slab_set_null_link", "nq_slab_config", "nq_slab_set_stage_buffers", "nq_slab_spectral", "nq_slab_spectral_read",
            "nq_slab_step", "nq_slab_put_rows", "nq_slab_commit", "nq_slab_get_rows", "nq_slab_diagnostics",
            "nq_slab_local_max", "nq_slab_counters", "nq_slab_allreduce_ms", "nq_snapshot_begin", "nq_snapshot_end"]
 
@@ -96,6 +96,8 @@ def lib():
     for name in ("nq_fft2", "nq_ifft2", "nq_rfft2", "nq_irfft2"):
         getattr(L, name).argtypes = [vp, dp, dp]
     L.nq_step.argtypes = [vp, ctypes.c_int]
+    L.nq_request_stage4_max.argtypes = [vp]
+    L.nq_get_stage4_max.argtypes = [vp, dp]
     L.nq_get_field.argtypes = [vp, ctypes.c_int, dp]
     L.nq_field_doubles.argtypes = [vp, ctypes.c_int]
     L.nq_field_doubles.restype = ctypes.c_longlong
@@ -129,6 +131,7 @@ def lib():
     L.nq_comm_init.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int]
     L.nq_slab_attach_peers.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
     L.nq_slab_set_callbacks.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp]
+    L.nq_slab_set_null_link.argtypes = [vp]
     L.nq_slab_config.argtypes = [vp, ctypes.c_int]
     L.nq_slab_set_stage_buffers.argtypes = [vp, vp, vp]
     L.nq_slab_spectral.argtypes = [vp, ctypes.c_int]
@@ -264,6 +267,17 @@ class Context:
 
     def sync(self):
         self._chk(self.L.nq_sync(self.h), "nq_sync")
+
+    def request_stage4_max(self):
+        """the last step of the next step() call also records max |u|, max |v| of its fourth stage (include/niwqg_amd.h)"""
+        self._chk(self.L.nq_request_stage4_max(self.h), "nq_request_stage4_max")
+
+    def status_cfl_max(self):
+        """max(|u|, |v|) of the fourth stage of the last step (as requested before it) and |phi| of the new state: what the
+        reference's status line takes its CFL from after a step without a tick (ref niwqg/Kernel.py:594, :660-662, :364-368)"""
+        uv = np.zeros(2)
+        self._chk(self.L.nq_get_stage4_max(self.h, _dptr(uv)), "nq_get_stage4_max")
+        return max(uv[0], uv[1], self.scalar(S_MAX_PHI))
 
     # --- reads
     _REAL = (F_Q, F_P, F_U, F_V, F_QPSI, F_QW, F_C)

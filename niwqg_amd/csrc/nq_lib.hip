@@ -114,6 +114,10 @@ struct nq_ctx {
   std::vector<int> prof_cls;                     // kernel class of each pair
   size_t prof_used = 0;
   bool have_q = false, have_phi = false, stepped = false;
+  // max |u|, max |v| of the FOURTH stage (what the reference's status line uses after a step without a tick: Kernel.py:594 with
+  // the self.u, self.v of :364-368): recorded by the last step of a call when asked for (nq_request_stage4_max)
+  bool want_uv4 = false, uv4_now = false, have_uv4 = false;
+  double* uv4 = nullptr;
   // snapshots (ref niwqg/Saving.py:59-86): physical q, phi in buffers of their own, copied out on a second stream
   double* snap_q = nullptr;
   cd* snap_phi = nullptr;
@@ -128,7 +132,7 @@ struct nq_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int overlap_cus = 0;
   // ---- slab step inside the library: how the exchange groups cross between the ranks
-  int link = 0;                        // LINK_*: 0 none, 1 peers in this process, 2 RCCL, 3 caller's callbacks
+  int link = 0;                        // LINK_*: 0 none, 1 peers in this process, 2 RCCL, 3 caller's callbacks, 4 nothing on the wire (nq_slab_set_null_link)
   std::vector<nq_ctx*> peers;          // LINK_PEERS: every rank's context (index = rank), the same list on all of them
   void* comm = nullptr;                // LINK_RCCL: ncclComm_t
   nq_exchange_fn xcb = nullptr;        // LINK_CALLBACK
@@ -1192,6 +1196,28 @@ static void do_invert_now(nq_ctx* c) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->part0Q, c->nwq, 3, 3, c->carryQ);
 }
 
+// max |u|, max |v| over this rank's rows of the fields the LAST inversion emitted (Mu, Mp on the x side): during a step, right
+// after stage index 2, these are the u, v of the reference's fourth jacobian_psi_q call (Kernel.py:364-368, :481-482)
+static int stage4_uv_max(nq_ctx* c) {
+  if (!c->uv4) ALLOC(c, c->uv4, (size_t)2);
+  if (!c->scr_f0) ALLOC(c, c->scr_f0, (size_t)c->Nloc * c->N);
+  HIPCHK(c, hipMemsetAsync(c->uv4, 0, sizeof(double) * 2, c->stream));
+  double* scr = reinterpret_cast<double*>(c->scr_f0);
+  const size_t n = (size_t)c->Nloc * c->N;
+  for (int which = 0; which < 2; ++which) {
+    const MArr& src = which == 0 ? c->mU : c->mP;
+    switch (c->N) {
+#define CASE_(nn, a, b) case nn: { typedef XPlan<nn> X; \
+      hipLaunchKernelGGL((k_x_get_real<nn, true>), dim3((c->Nloc + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, c->stream, src, scr, c->Nloc, c->tw, c->kk, which, (which == 1 && c->kernel_family) ? 1 : 0); } break;
+      NQ_FOR_SIZES(CASE_)
+#undef CASE_
+    }
+    hipLaunchKernelGGL(k_reduce_real_max, dim3(1024), dim3(256), 0, c->stream, (const double*)scr, n, c->uv4 + which);
+  }
+  c->have_uv4 = true;
+  return 0;
+}
+
 // niwqg.YBJModel._step_etdrk4 (YBJModel.py:52-87): psi, u, v, q are steady; phix, phiy are refreshed from the current
 // phih before every stage, but the refraction factor phi only after the step.  Two G1-shaped buffers do it without a
 // copy: A = G[1] holds phi, phiy of the start-of-step state (products read phi from it in all four stages, and the
@@ -1241,6 +1267,7 @@ static void do_step_overlap(nq_ctx* c) {
     phase_wavepv(c);
     (void)hipStreamWaitEvent(main_stream, c->ev_join, 0);
     phase_invert(c, s);
+    if (s == 2 && c->uv4_now) (void)stage4_uv_max(c);
   }
   phase_budget_sums(c);
   phase_budget_finish(c);
@@ -1256,6 +1283,7 @@ static void do_step(nq_ctx* c) {      // P == 1
       phase_wavepv(c);
       phase_invert(c, s);
     }
+    if (s == 2 && c->uv4_now) (void)stage4_uv_max(c);
   }
   if (c->bud && c->nww <= 256 && c->nwq <= 256) {            // few partials (grids <= 512): sums and accumulation in one launch
     hipLaunchKernelGGL(k_budget_small, dim3(1), dim3(1024), 0, c->stream, budget_acc(c), c->bsums);
@@ -1269,7 +1297,7 @@ static void do_step(nq_ctx* c) {      // P == 1
 // ==================================================================================================================
 // The slab step inside the library (include/niwqg_amd.h: nq_slab_step)
 // ==================================================================================================================
-enum { LINK_NONE = 0, LINK_PEERS = 1, LINK_RCCL = 2, LINK_CALLBACK = 3 };
+enum { LINK_NONE = 0, LINK_PEERS = 1, LINK_RCCL = 2, LINK_CALLBACK = 3, LINK_NULL = 4 };
 
 // RCCL, taken from the process at run time (torch ships its own librccl and has usually loaded it already)
 struct NcclId { char internal[128]; };
@@ -1378,12 +1406,16 @@ struct XTimer {                                  // optional HIP-event pair arou
   size_t& used;
   explicit XTimer(nq_ctx* c_, bool reduce = false) : c(c_), on(c_->xtime), ev(reduce ? c_->rev : c_->xev), used(reduce ? c_->rev_used : c_->xev_used) {
     if (!on) return;
-    if (used + 2 > ev.size())
+    if (used + 2 > ev.size()) {
+      // the pool only shrinks in nq_slab_counters(reset): a caller that leaves timing on for a long run() gets the first
+      // 16384 exchanges / all-reduces timed and the rest untimed instead of an event pool that grows without bound
+      if (ev.size() >= 2 * 16384) { on = false; return; }
       for (int i = 0; i < 2; ++i) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
         ev.push_back(e);
       }
+    }
     (void)hipEventRecord(ev[used], c->mstream);
   }
   ~XTimer() {
@@ -1424,6 +1456,8 @@ static int issue_chunk(std::vector<nq_ctx*>& grp, int g, bool to_y, int i, int n
           const cd* src = (to_y ? s->G[g].bx : s->G[g].by) + (size_t)c->rank * blk + off;
           HIPCHK(c, hipMemcpyAsync(recv + (size_t)s->rank * blk + off, src, cblk * sizeof(cd), hipMemcpyDeviceToDevice, c->mstream));
         }
+      } else if (c->link == LINK_NULL) {         // one rank of P measured alone: only its own block crosses (device copy)
+        HIPCHK(c, hipMemcpyAsync(recv + (size_t)c->rank * blk + off, send + (size_t)c->rank * blk + off, cblk * sizeof(cd), hipMemcpyDeviceToDevice, c->mstream));
       } else {                                   // RCCL: one grouped send/recv pair per peer, the own block by a device copy
         NCCLCHK(c, g_rccl.GroupStart());
         for (int p = 0; p < c->P; ++p) {
@@ -1436,7 +1470,7 @@ static int issue_chunk(std::vector<nq_ctx*>& grp, int g, bool to_y, int i, int n
       }
     }
     c->n_exch += 1;
-    c->bytes_sent += (double)cblk * 16.0 * (c->P - 1);
+    if (c->link != LINK_NULL) c->bytes_sent += (double)cblk * 16.0 * (c->P - 1);
     if (to_y) {
       if (i == nch - 1) HIPCHK(c, hipEventRecord(c->ev_done, c->mstream));
     } else {
@@ -1515,6 +1549,7 @@ static int slab_allreduce(std::vector<nq_ctx*>& grp, int which) {
     }
     return 0;
   }
+  if (c0->link == LINK_NULL) return 0;           // one rank of P measured alone: its partial sums stay partial
   if (c0->link == LINK_PEERS) {
     if (grp.size() == 1) return 0;
     PeerBufs pb;
@@ -1608,6 +1643,12 @@ static int slab_step_once(std::vector<nq_ctx*>& grp) {
   const bool coupled = c0->p.model == NQ_MODEL_COUPLED, waves = c0->kernel_family;
   const int nch = effective_chunks(c0);
   for (int s = 0; s < 4; ++s) {
+    if (s == 3 && c0->uv4_now)
+      for (nq_ctx* c : grp) {                   // the fourth stage's u, v have just arrived on the x side (group 3)
+        for (int i = 0; i < nch; ++i) SLABTRY(wait_arrival(c, 3, i, nch));
+        set_window(c, 0, 1);
+        SLABTRY(stage4_uv_max(c));
+      }
     // rows: nonlinear products, chunk by chunk; chunk i leaves as soon as it is done
     for (int i = 0; i < nch; ++i) {
       for (nq_ctx* c : grp) {
@@ -1712,6 +1753,37 @@ static int xdiag_blocks(const nq_ctx* c) {
   return 0;
 }
 
+// 1 read + 1 write stream copy, 16 B per lane: the rate a copy kernel reaches on THIS device, the second denominator of
+// bench.py's roofline fractions.  Three shapes are timed and the best is reported (tools/copy_shape_bench.hip
+// swept them, 4.4-6.5 TB/s): plain grid-stride; grid-stride with U loads then U stores in flight, non-temporal both ways (what
+// MI355X_MICROARCH.md's 6.29 TB/s float4 copy is); the same at twice the depth.  Buffers live only for the call.
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) k_stream_copy(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + (U - 1) * step < n; i += U * step) {
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (NT) {
+        v[u].x = __builtin_nontemporal_load(&src[i + u * step].x);
+        v[u].y = __builtin_nontemporal_load(&src[i + u * step].y);
+      } else {
+        v[u] = src[i + u * step];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (NT) {
+        __builtin_nontemporal_store(v[u].x, &dst[i + u * step].x);
+        __builtin_nontemporal_store(v[u].y, &dst[i + u * step].y);
+      } else {
+        dst[i + u * step] = v[u];
+      }
+    }
+  }
+  for (; i < n; i += step) dst[i] = src[i];
+}
 extern "C" {
 
 const char* nq_last_error(const nq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
@@ -1827,6 +1899,10 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
     // the two-pass tiles (A/B measurements; slab contexts always use them).
     const char* e = getenv("NIWQG_AMD_SINGLE_PASS");
     if (P == 1 && p->nx <= 512 && !(e && atoi(e) == 0)) {
+      if (getenv("NIWQG_AMD_Y_SPLIT")) {          // the knob would be silently overridden here: refuse instead
+        delete c;
+        NQ_FAIL((nq_ctx*)nullptr, -2, "NIWQG_AMD_Y_SPLIT has no effect on a single-rank grid <= 512 (single-pass columns); set NIWQG_AMD_SINGLE_PASS=0 with it");
+      }
       c->S1 = p->nx;
       c->S2 = 1;
       c->CLy = p->nx >= 128 ? CLS : CL;
@@ -2155,11 +2231,6 @@ int nq_sync(nq_ctx* c) {
   return 0;
 }
 
-// 1 read + 1 write stream copy, 16 B per lane, grid-stride: the rate a plain copy kernel reaches on THIS device, the second
-// denominator of bench.py's roofline fractions.  Buffers live only for the call.
-__global__ void __launch_bounds__(256) k_stream_copy(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
 int nq_stream_copy_gbs(nq_ctx* c, long long bytes, int reps, double* gbs_out) {
   if (!c || !gbs_out || bytes < (1 << 20) || reps < 1) return -1;
   HIPCHK(c, hipSetDevice(c->device));
@@ -2172,19 +2243,28 @@ int nq_stream_copy_gbs(nq_ctx* c, long long bytes, int reps, double* gbs_out) {
   }
   (void)hipMemsetAsync(a, 1, n * sizeof(double2), c->stream);
   (void)hipMemsetAsync(b, 0, n * sizeof(double2), c->stream);
-  const int grid = c->num_cu * 8;
-  hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, c->stream, (const double2*)a, b, n);      // untimed warm-up
+  auto launch = [&](int shape) {
+    const double2* src = a;
+    switch (shape) {
+      case 0: hipLaunchKernelGGL((k_stream_copy<1, false>), dim3(c->num_cu * 8), dim3(256), 0, c->stream, src, b, n); break;
+      case 1: hipLaunchKernelGGL((k_stream_copy<4, true>), dim3(c->num_cu * 8), dim3(256), 0, c->stream, src, b, n); break;
+      case 2: hipLaunchKernelGGL((k_stream_copy<4, true>), dim3(c->num_cu * 16), dim3(256), 0, c->stream, src, b, n); break;
+      default: hipLaunchKernelGGL((k_stream_copy<8, true>), dim3(c->num_cu * 8), dim3(256), 0, c->stream, src, b, n); break;
+    }
+  };
+  launch(0);                                                                                            // untimed warm-up
   double best = 0.0;
   int rc = 0;
-  for (int r = 0; r < reps && rc == 0; ++r) {
-    if (hipEventRecord(c->ev0, c->stream) != hipSuccess) { rc = -5; break; }
-    hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, c->stream, (const double2*)a, b, n);
-    float ms = 0.f;
-    if (hipEventRecord(c->ev1, c->stream) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
-        hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) { rc = -5; break; }
-    const double g = 2.0 * (double)(n * sizeof(double2)) / (ms * 1e-3) / 1e9;
-    best = g > best ? g : best;
-  }
+  for (int shape = 0; shape < 4 && rc == 0; ++shape)
+    for (int r = 0; r < reps && rc == 0; ++r) {
+      if (hipEventRecord(c->ev0, c->stream) != hipSuccess) { rc = -5; break; }
+      launch(shape);
+      float ms = 0.f;
+      if (hipEventRecord(c->ev1, c->stream) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
+          hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) { rc = -5; break; }
+      const double g = 2.0 * (double)(n * sizeof(double2)) / (ms * 1e-3) / 1e9;
+      best = g > best ? g : best;
+    }
   (void)hipStreamSynchronize(c->stream);
   (void)hipFree(a);
   (void)hipFree(b);
@@ -2333,10 +2413,31 @@ int nq_step(nq_ctx* c, int nsteps) {
   NQ_SINGLE_RANK(c, "nq_step");
   if (nsteps < 0) NQ_FAIL(c, -1, "nq_step: nsteps < 0");
   HIPCHK(c, hipSetDevice(c->device));
-  for (int i = 0; i < nsteps; ++i) do_step(c);
-  if (nsteps > 0) c->stepped = true;
+  for (int i = 0; i < nsteps; ++i) {
+    c->uv4_now = c->want_uv4 && i == nsteps - 1 && c->kernel_family && !c->ybj;
+    do_step(c);
+  }
+  if (nsteps > 0) {
+    c->stepped = true;
+    c->have_uv4 = c->uv4_now;
+    c->want_uv4 = c->uv4_now = false;
+  }
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+// The last step of the NEXT nq_step / nq_slab_step call also records max |u|, max |v| of its fourth stage over this rank's rows
+// (two extra row passes in that one step); nq_get_stage4_max reads them (-4 when the last call recorded none).
+int nq_request_stage4_max(nq_ctx* c) {
+  if (!c) return -1;
+  c->want_uv4 = true;
+  return 0;
+}
+int nq_get_stage4_max(nq_ctx* c, double* out2) {
+  if (!c || !out2) return -1;
+  if (!c->have_uv4 || !c->uv4) NQ_FAIL(c, -4, "nq_get_stage4_max: the last step call was not asked to record the fourth stage's maxima");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(out2, c->uv4, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+  return nq_sync(c);
 }
 
 // ---- slab decomposition API ------------------------------------------------------------------------
@@ -2502,6 +2603,19 @@ int nq_slab_attach_peers(nq_ctx* const* ctxs, int nranks) {
   }
   return 0;
 }
+// Measurement aid (bench.py --rank-of P): this context is ONE rank of its P-rank decomposition and runs alone.  Streams, events,
+// chunking and every kernel launch are those of a real rank; on the wire only the rank's own block moves (the device copy the RCCL
+// link makes as well), the other P-1 blocks of every group keep whatever they held, and nothing is all-reduced.  The fields are
+// therefore NOT a simulation -- what is measured is a rank's compute and launch structure without the exchange.
+int nq_slab_set_null_link(nq_ctx* c) {
+  if (!c) return -1;
+  if (c->link != LINK_NONE) NQ_FAIL(c, -4, "nq_slab_set_null_link: the context already has a link");
+  const char* e = getenv("NIWQG_AMD_SLAB_RESERVE_CUS");
+  c->reserve_cus = e ? atoi(e) : 0;
+  if (c->reserve_cus < 0 || c->reserve_cus >= c->num_cu) c->reserve_cus = 0;
+  c->link = LINK_NULL;
+  return slab_link_setup(c);
+}
 int nq_slab_set_callbacks(nq_ctx* c, nq_exchange_fn exchange, nq_allreduce_fn allreduce, void* user) {
   if (!c || !exchange || !allreduce) return -1;
   if (c->link != LINK_NONE && c->link != LINK_CALLBACK) NQ_FAIL(c, -4, "nq_slab_set_callbacks: the context already has a link");
@@ -2542,9 +2656,17 @@ int nq_slab_step(nq_ctx* c, int nsteps) {
   SLABTRY(slab_group(c, &grp));
   for (nq_ctx* x : grp) HIPCHK(x, hipSetDevice(x->device));
   c->n_calls += 1;
-  for (int i = 0; i < nsteps; ++i) SLABTRY(slab_step_once(grp));
+  for (int i = 0; i < nsteps; ++i) {
+    const bool now = c->want_uv4 && i == nsteps - 1 && c->kernel_family && !c->ybj;
+    for (nq_ctx* x : grp) x->uv4_now = now;
+    SLABTRY(slab_step_once(grp));
+  }
   if (nsteps > 0)
-    for (nq_ctx* x : grp) x->stepped = true;
+    for (nq_ctx* x : grp) {
+      x->stepped = true;
+      x->have_uv4 = x->uv4_now;
+      x->want_uv4 = x->uv4_now = false;
+    }
   SLABTRY(slab_settle(grp));
   for (nq_ctx* x : grp) HIPCHK(x, hipGetLastError());
   return 0;
@@ -3199,10 +3321,10 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
     *out = (id == NQ_S_KE_NIW) ? 0.5 * h[0] / (M * M) : 0.25 * h[0] / (M * M) / c->p.kappa2;
     return rc;
   }
-  if (id == NQ_S_CFL) {
-    // max(|u|, |v|, |phi|) on the device (the caller multiplies by dt/dx): ref Kernel.py:660-662
+  if (id == NQ_S_CFL || id == NQ_S_MAX_PHI) {
+    // max(|u|, |v|, |phi|) on the device (the caller multiplies by dt/dx): ref Kernel.py:660-662; NQ_S_MAX_PHI: max |phi| alone
     const size_t full = (size_t)N * N;
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < (id == NQ_S_CFL ? 2 : 0); ++which) {
       hipLaunchKernelGGL(k_spec_mul, dim3((c->Wh + 63) / 64, N), dim3(64), 0, c->stream, c->ph, c->scr_h1, c->Wh, c->Ph, which == 0 ? 1 : 2, c->kk, c->ll, N, 1);
       if (which == 1 && c->kernel_family) HIPCHK(c, hipMemset2DAsync(c->scr_h1 + N / 2, sizeof(cd) * c->Ph, 0, sizeof(cd), N, c->stream));
       inv2d_half(c, c->scr_h1, c->scr_r, c->scr_f1);

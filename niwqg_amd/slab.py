@@ -127,6 +127,11 @@ class SlabRank(object):
         self._chk(self.L.nq_slab_get_rows(self.h, fid, _lib._dptr(out.view(np.float64))), "nq_slab_get_rows(%d)" % fid)
         return out
 
+    def stage4_max(self):
+        out = np.zeros(2)
+        self._chk(self.L.nq_get_stage4_max(self.h, _lib._dptr(out)), "nq_get_stage4_max")
+        return out
+
     def local_max(self):
         out = np.zeros(3)
         self._chk(self.L.nq_slab_local_max(self.h, _lib._dptr(out)), "nq_slab_local_max")
@@ -264,6 +269,11 @@ class SlabSimulation(object):
             self._xcb = _lib.EXCHANGE_FN(exchange)       # keep the trampolines alive as long as the simulation
             self._rcb = _lib.ALLREDUCE_FN(allreduce)
             r._chk(self.L.nq_slab_set_callbacks(r.h, self._xcb, self._rcb, None), "nq_slab_set_callbacks")
+        elif link == "null":
+            # measurement aid (bench.py --rank-of P): ONE rank of the decomposition, alone; nothing crosses but its own block
+            if len(ranks) != 1:
+                raise ValueError("null link: exactly one rank")
+            self.lead._chk(self.L.nq_slab_set_null_link(self.lead.h), "nq_slab_set_null_link")
         else:
             raise ValueError("link %r" % (link,))
         for r in ranks:
@@ -278,7 +288,8 @@ class SlabSimulation(object):
     def describe(self):
         how = {"rccl": "grouped ncclSend/ncclRecv issued inside the library",
                "peers": "peer ranks in one process (device copies)",
-               "callback": "torch.distributed all_to_all_single from a library callback"}[self.link]
+               "callback": "torch.distributed all_to_all_single from a library callback",
+               "null": "NO exchange (one rank of the decomposition measured alone)"}[self.link]
         return "in-library step, %s, %d row chunks per exchange" % (how, int(self.counters()["nchunks"]))
 
     # --- initial state (same order semantics as Kernel.set_q / set_phi, quirk Q2) -------------------------
@@ -321,7 +332,7 @@ class SlabSimulation(object):
     def max_over_ranks(self, values):
         """element-wise max over all ranks of the simulation of a small vector this process computed for its ranks"""
         v = np.max(np.asarray(values, float).reshape(len(self.ranks), -1), axis=0)
-        if self.link != "peers":
+        if self.link not in ("peers", "null"):
             import torch
             self.sync()        # never two communicators active on the device (nq_sync drains the exchange stream too)
             t = torch.from_numpy(v.copy())
@@ -335,6 +346,13 @@ class SlabSimulation(object):
         """max over the whole grid of |u|, |v|, |phi| (Kernel._calc_cfl without dt/dx)"""
         return float(np.max(self.max_over_ranks([r.local_max() for r in self.ranks])))
 
+    def request_stage4_max(self):
+        self.lead._chk(self.L.nq_request_stage4_max(self.lead.h), "nq_request_stage4_max")
+
+    def status_cfl_max(self):
+        """Context.status_cfl_max over the ranks: the fourth stage's max |u|, |v| with the new state's max |phi|"""
+        return float(np.max(self.max_over_ranks([list(r.stage4_max()) + [r.local_max()[2]] for r in self.ranks])))
+
     def counters(self, reset=0):
         red = np.zeros(2)
         self.lead._chk(self.L.nq_slab_allreduce_ms(self.lead.h, _lib._dptr(red)), "nq_slab_allreduce_ms")
@@ -346,7 +364,7 @@ class SlabSimulation(object):
     # --- gathering -----------------------------------------------------------------------------------------
     def _gather(self, parts, axis):
         """parts: this process's pieces in rank order -> the whole array on every rank"""
-        if self.link == "peers":
+        if self.link in ("peers", "null"):
             return np.concatenate(parts, axis=axis)
         import torch
         self.sync()            # the library's streams (compute AND exchange) are drained before torch's communicator runs
@@ -406,7 +424,7 @@ def connect(ranks, dist, nchunks=2):
             if float(flag[0]) == 1.0:
                 return sim
         else:
-            err = ranks[0].L.nq_last_error(None)
+            err = ranks[0].L.nq_last_error(None).decode(errors="replace")
         import sys
         sys.stderr.write("niwqg_amd.slab rank %d: RCCL link not available on every rank (%s): falling back to "
                          "torch.distributed callbacks\n" % (ranks[0].rank, err or "another rank failed"))
@@ -474,6 +492,12 @@ class SlabContext(object):
 
     def sync(self):
         self.sim.sync()
+
+    def request_stage4_max(self):
+        self.sim.request_stage4_max()
+
+    def status_cfl_max(self):
+        return self.sim.status_cfl_max()
 
     def take_budget_increments(self):
         incs = [r.budget_increments() for r in self.sim.ranks]       # identical on every rank; reading resets each

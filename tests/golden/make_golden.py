@@ -32,6 +32,9 @@ Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
                           test.  Qh, f0, fab, fc at every entry within 0.05 of the contour (there the reference's value is
                           numpy's rounding error times eps / distance^3), and for the 256^2 CoupledModel (2/3-rule
                           dealiasing, inviscid waves) q and phi after 6 steps from seeded white noise, which feeds them
+  g16_coupled_lamb_<nx>_100steps.npz  the REAL reference, CoupledModel LambDipole (filter on) at 1024^2 / 2048^2 after 50 and 100
+                          steps: projections, sub-samples, spectral corners, norms, budgets (round 4; not in the default list)
+  g17_non_power_of_two.npz  the REAL reference on 96^2 and 192^2 grids, CoupledModel and QGModel, 1 / 10 / 100 steps (round 4)
   g14_instance_attributes.npz  what a freshly constructed instance of each of the four model classes carries (nx = 64, every other
                           argument at its default): names and values of the scalar attributes, names, shapes, dtypes and two
                           checksums of the array attributes
@@ -335,8 +338,9 @@ def projections(field, seed, n=256):
 def g11():
     nx = 2048
     out = {}
-    # BASELINE config 2 exactly as bench.py --model qg --nx 2048 builds it
-    dt, nu4 = 0.05 * TE * 128 / nx, 7.5e8 / 64
+    # BASELINE config 2 exactly as bench.py --model qg --nx 2048 builds it (dt = 0.05 Te / 8, nu4 = 7.5e8 / 64;
+    # round 4 -- rounds 2 and 3 ran it with half that dt)
+    dt, nu4 = 0.05 * TE / 8, 7.5e8 / 64
     m = QGModel.Model(L=L, nx=nx, tmax=1e30, dt=dt, twrite=10 ** 9, nu4=nu4, use_filter=True, save_to_disk=False,
                       U=-U0, tdiags=10 ** 9)
     q0 = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx))
@@ -487,6 +491,73 @@ def g15():
         return m
     attribute_inventory(out, "", stepped)
     save("g15_attributes_after_three_steps.npz", **out)
+
+
+def g16(sizes=None):
+    """round 4: BASELINE's literal criterion at size -- the REAL reference, CoupledModel, LambDipole q + uniform phi, notebook
+    parameters scaled to the grid (examples/LambDipole.py:45-58), FILTER ON, after 50 and 100 steps.  The dipole's vorticity has a
+    kink at r = R, so its spectrum reaches the filter band from step 0 and the cascade feeds it over the horizon.  One file per
+    size: `python make_golden.py g16` writes 1024^2 (~7 min, 4 GB here); `G16_SIZES=2048 python make_golden.py g16` the 2048^2 one
+    (~50 min, 16 GB)."""
+    sizes = sizes or [int(s) for s in os.environ.get("G16_SIZES", "1024").split(",")]
+    for nx in sizes:
+        out = {}
+        kw = notebook_kwargs(nx, True, 100, tdiags=10 ** 9)
+        m = CoupledModel.Model(**kw)
+        q0, phi0 = lamb_and_uniform(m)
+        m.set_q(q0)
+        m.set_phi(phi0)
+        out["params"] = np.array([nx, kw["dt"], kw["nu4"], kw["nu"], kw["nuw"], kw["U"]])
+        out["q0_sub"] = q0[::nx // 64, ::nx // 64].copy()
+        out["q0_norm"] = np.array(np.linalg.norm(q0))
+        for n in (50, 100):
+            step_to(m, n)
+            tag = "s%d_" % n
+            out[tag + "q_proj"] = projections(m.q, 401)
+            out[tag + "phi_proj"] = projections(m.phi, 402)
+            out[tag + "qh_proj"] = projections(m.qh, 403)
+            out[tag + "phih_proj"] = projections(m.phih, 404)
+            out[tag + "q_sub"], out[tag + "phi_sub"] = m.q[::nx // 64, ::nx // 64].copy(), m.phi[::nx // 64, ::nx // 64].copy()
+            # the low corner of the spectra (the energetic modes) and a strip inside the filter band, element by element
+            out[tag + "qh_low"], out[tag + "phih_low"] = m.qh[:32, :32].copy(), m.phih[:32, :32].copy()
+            b = int(0.36 * nx)
+            out[tag + "qh_band"], out[tag + "phih_band"] = m.qh[b:b + 8, b:b + 64].copy(), m.phih[b:b + 8, b:b + 64].copy()
+            # ... and a strip across the filter's cut-off (index 0.65 nx / 2 along k, l small), where the filtered cascade lives
+            c0 = int(0.65 * nx / 2) - 32
+            out[tag + "qh_edge"], out[tag + "phih_edge"] = m.qh[:8, c0:c0 + 64].copy(), m.phih[:8, c0:c0 + 64].copy()
+            out[tag + "norms"] = np.array([np.linalg.norm(m.q), np.linalg.norm(m.phi), np.linalg.norm(m.qh), np.linalg.norm(m.phih)])
+            out[tag + "budgets"] = np.array([m.Ke, m.Pw, m.Kw])
+            print("g16: nx", nx, "step", n, "done", flush=True)
+        save("g16_coupled_lamb_%d_100steps.npz" % nx, **out)
+        del m
+
+
+def g17():
+    """round 4: grids that are not powers of two (the reference takes any nx: niwqg/Kernel.py:100-103, numpy.fft any length).
+    CoupledModel and QGModel, LambDipole, filter on, 96^2 and 192^2, after 1, 10 and 100 steps: whole fields."""
+    out = {}
+    for nx in (96, 192):
+        kw = notebook_kwargs(nx, True, 100, tdiags=10 ** 9)
+        m = CoupledModel.Model(**kw)
+        q0, phi0 = lamb_and_uniform(m)
+        m.set_q(q0)
+        m.set_phi(phi0)
+        out["c%d_q0" % nx] = q0
+        for n in (1, 10, 100):
+            step_to(m, n)
+            t = "c%d_s%d_" % (nx, n)
+            out[t + "q"], out[t + "phi"], out[t + "qh"], out[t + "phih"] = m.q.copy(), m.phi.copy(), m.qh.copy(), m.phih.copy()
+            out[t + "budgets"] = np.array([m.Ke, m.Pw, m.Kw])
+        dt = 0.05 * TE * 128 / nx
+        m = QGModel.Model(L=L, nx=nx, tmax=1e30, dt=dt, twrite=10 ** 9, nu4=7.5e8 * (128.0 / nx) ** 4, use_filter=True, save_to_disk=False,
+                          U=-U0, tdiags=10 ** 9)
+        m.set_q(q0)
+        out["qg%d_params" % nx] = np.array([dt, m.nu4])
+        for n in (1, 10, 100):
+            step_to(m, n)
+            t = "qg%d_s%d_" % (nx, n)
+            out[t + "q"], out[t + "qh"], out[t + "Ke"] = m.q.copy(), m.qh.copy(), np.array(m.Ke)
+    save("g17_non_power_of_two.npz", **out)
 
 
 def attribute_inventory(out, prefix, make):

@@ -71,6 +71,10 @@ class _FakeCtx(object):
 
     def step(self, n):
         self.calls.append(n)
+        self.done = getattr(self, "done", 0) + n
+
+    def request_stage4_max(self):
+        self.requests = getattr(self, "requests", []) + [getattr(self, "done", 0) + 1]     # the step it will be recorded in
 
 
 def _bare_kernel(tdiags, twrite, dt, tmax):
@@ -107,6 +111,10 @@ def test_run_loop_batches_steps_but_keeps_the_reference_event_sequence(tdiags, t
     assert k.status == [n for n in range(1, nsteps + 1) if n % twrite == 0]
     if tdiags > nsteps and twrite > nsteps:
         assert len(k._ctx.calls) <= 3          # really batched
+    # the fourth stage's max |u|, |v| are asked for exactly in the steps that end with a status line and have no tick before
+    # it (ref Kernel.py:594 with :364-368; a tick recomputes u, v from the new psi: Kernel.py:681)
+    want = [n for n in range(1, nsteps + 1) if n % twrite == 0 and (n - 1) % tdiags != 0]
+    assert getattr(k._ctx, "requests", []) == want
 
 
 def test_float_clock_is_the_references():

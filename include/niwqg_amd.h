@@ -335,6 +335,58 @@ long long nq_device_bytes(const nq_ctx* ctx);
 /* stream handle (hipStream_t) so that callers can order their own work */
 void* nq_stream(nq_ctx* ctx);
 
+/* ---- the any-size engine: grids without a fused plan -----------------------------------------------------------------------
+ * The reference takes any nx (niwqg/Kernel.py:100-103; numpy.fft transforms any length, :562-566; QGModel.py:93-96, :551-552).
+ * The fused step above exists for powers of two in [64, 8192].  For every other even nx in [4, 4096] the model classes run the
+ * reference's own sequence of whole-plane operations (niwqg_amd/_anysize.py) on device planes through these calls: 1-D transforms
+ * of any length along either axis (Bluestein's chirp-z identity on the power-of-two row engine), element-wise operations,
+ * deterministic reductions.  Planes are contiguous arrays of complex128 owned by the engine; everything is asynchronous on the
+ * engine's stream except the calls that return data.  Same return codes as above; nq_any_last_error for the text. */
+typedef struct nq_any nq_any;
+enum {  /* nq_any_ew: d = ... element by element; s0, s1, s2 complex scalars (scalars6 = re, im of each; NULL: s0 = 1, s1 = s2 = 0) */
+  NQ_EW_COPY = 0,      /* a                                   */
+  NQ_EW_MUL = 1,       /* s0 a b                              */
+  NQ_EW_MULCONJ = 2,   /* s0 conj(a) b                        */
+  NQ_EW_AXPBY = 3,     /* s0 a + s1 b                         */
+  NQ_EW_AXPBYPCZ = 4,  /* s0 a + s1 b + s2 c                  */
+  NQ_EW_REAL = 5,      /* Re a (imaginary part zero): numpy's .real kept as a complex plane */
+  NQ_EW_ABS2 = 6,      /* |a|^2                               */
+  NQ_EW_SCALE = 7,     /* s0 a                                */
+  NQ_EW_CONJ = 8,      /* conj(a)                             */
+  NQ_EW_ADDS = 9,      /* a + s0                              */
+  NQ_EW_IMAG = 10,     /* Im a (as a real value)              */
+  NQ_EW_MULADD = 11    /* s0 a b + s1 c                       */
+};
+enum {  /* nq_any_reduce: out2 = (re, im) */
+  NQ_RD_SUM = 0, NQ_RD_SUMABS2 = 1, NQ_RD_DOT = 2 /* sum a b */, NQ_RD_DOTC = 3 /* sum conj(a) b */, NQ_RD_MAXABS = 4,
+  NQ_RD_WSUMABS2 = 5 /* sum Re(b) |a|^2 */, NQ_RD_MAXABSRE = 6 /* max |Re a| */
+};
+int nq_any_create(int device, nq_any** out);
+int nq_any_destroy(nq_any* eng);
+const char* nq_any_last_error(const nq_any* eng);
+int nq_any_sync(nq_any* eng);
+long long nq_any_device_bytes(const nq_any* eng);
+int nq_any_alloc(nq_any* eng, long long elems, void** plane);                 /* zero-filled */
+int nq_any_free(nq_any* eng, void* plane, long long elems);
+int nq_any_upload(nq_any* eng, void* plane, const double* host_cplx, long long elems);
+int nq_any_download(nq_any* eng, const void* plane, double* host_cplx, long long elems);
+/* numpy.fft.fft / ifft along one axis of a (rows, cols) plane (axis 1: the contiguous index); dst may be src */
+int nq_any_fft(nq_any* eng, void* dst, const void* src, int rows, int cols, int axis, int inverse);
+int nq_any_ew(nq_any* eng, int op, void* d, const void* a, const void* b, const void* c, long long elems, const double* scalars6);
+int nq_any_reduce(nq_any* eng, int op, const void* a, const void* b, long long elems, double* out2);
+/* (rows, n/2+1) -> (rows, n): full[l, n-k] = conj(half[-l, k]); project != 0 first takes the Hermitian part (in l) of columns 0
+ * and n/2, which is all numpy.fft.irfft2 sees of them (QGModel.py:552) */
+int nq_any_expand_half(nq_any* eng, void* full, const void* half, int rows, int n, int project);
+int nq_any_take_cols(nq_any* eng, void* dst, const void* src, int rows, int src_cols, int dst_cols);
+int nq_any_set_elem(nq_any* eng, void* plane, long long index, double re, double im);
+/* E = exp(c dt), Eh = exp(c dt / 2), Q, f0, fab, fc of the linear operator c(l, k) on a (n, cols) plane, WITHOUT the filter
+ * (Kernel.py:417-454, QGModel.py:426-466); eq 0: q of the Kernel family, 1: phi, 2: QGModel's q (beta term), 3: its passive
+ * scalar.  The entries within delta of the contour are listed (near_*; at most cap) for the host to recompute exactly as the
+ * reference does (niwqg_amd/_etdrk4.py) and hand back through nq_any_etdrk4_patch (vals: count x 4 complex: Qh, f0, fab, fc). */
+int nq_any_etdrk4(nq_any* eng, int eq, const nq_params* p, const double* kk, const double* ll, const double* contour32, int n, int cols,
+                  void* const* out6, double delta, int cap, int* near_count, int* near_l, int* near_k);
+int nq_any_etdrk4_patch(nq_any* eng, void* const* out6, int cols, int count, const int* l, const int* k, const double* vals);
+
 #ifdef __cplusplus
 }
 #endif

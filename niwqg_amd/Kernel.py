@@ -42,6 +42,18 @@ class Kernel(object):
 
     model_id = None
 
+    def __new__(cls, *args, **kwargs):
+        """Grids the fused kernels have no plan for (anything but a power of two in [64, 8192]) get the any-size mix-in in front
+        of the class: same class name, same surface, every device operation restated on whole planes (niwqg_amd/_anysize.py)."""
+        nx = kwargs.get("nx", args[0] if args else 128)
+        if not _lib.has_fused_plan(nx) and not getattr(cls, "_any_size", False):
+            from . import _anysize
+            if not _anysize.supported(nx):
+                raise RuntimeError("nx = %r: the fused kernels take powers of two in [64, 8192], the any-size path even nx in "
+                                   "[4, %d]" % (nx, _anysize.NX_MAX))
+            cls = _anysize.specialise(cls, _anysize.KernelFamily)
+        return object.__new__(cls)
+
     def __init__(self, nx=128, ny=None, L=5e5, dt=10000., twrite=1000., tmax=250000., use_filter=True,
                  cflmax=0.8, U=.0, f=1.e-4, N=0.01, m=0.025, g=9.81, nu4=0, nu4w=0, nu=20, nuw=50., mu=0,
                  muw=0, dealias=False, save_to_disk=False, overwrite=True, tsave_snapshots=10, tdiags=10,
@@ -89,16 +101,9 @@ class Kernel(object):
         # (ensemble members, replicas).
         import os
         if slab is None:
-            slab = int(os.environ.get("WORLD_SIZE", "1")) > 1
+            slab = int(os.environ.get("WORLD_SIZE", "1")) > 1 and _lib.has_fused_plan(nx)
         phys = dict(U=U, f=f, kappa2=self.kappa2, nu=nu, nu4=nu4, mu=mu, nuw=nuw, nu4w=nu4w, muw=muw)
-        if slab:
-            from .slab import SlabContext
-            self._ctx = SlabContext(self.model_id, nx, self.kk, self.ll, self.filtr, dt, peers=(slab if slab is not True else None),
-                                    nchunks=nchunks, device=(device if slab is not True else None), budgets=budgets,
-                                    dual_q=self._dual, **phys)
-        else:
-            self._ctx = _lib.Context(self.model_id, nx, self.kk, self.ll, self.filtr, dt, budgets=budgets, device=device,
-                                     dual_q=self._dual, **phys)
+        self._ctx = self._create_context(phys, budgets, device, slab, nchunks)
         self._cache = {}
         self._user = {}
         self._initialize_time()
@@ -110,6 +115,16 @@ class Kernel(object):
         self.Pw = self.Kw = 0.0
 
     # ------------------------------------------------------------------ setup
+    def _create_context(self, phys, budgets, device, slab, nchunks):
+        """the device side of the model: one fused-kernel context, or a slab-decomposed one (the any-size mix-in overrides this)"""
+        if slab:
+            from .slab import SlabContext
+            return SlabContext(self.model_id, self.nx, self.kk, self.ll, self.filtr, self.dt, peers=(slab if slab is not True else None),
+                               nchunks=nchunks, device=(device if slab is not True else None), budgets=budgets,
+                               dual_q=self._dual, **phys)
+        return _lib.Context(self.model_id, self.nx, self.kk, self.ll, self.filtr, self.dt, budgets=budgets, device=device,
+                            dual_q=self._dual, **phys)
+
     def _initialize_logger(self):
         """ref: niwqg/Kernel.py:286-304"""
         self.logger = logging.getLogger(__name__)

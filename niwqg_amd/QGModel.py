@@ -17,6 +17,17 @@ from .Saving import (initialize_save_snapshots, save_setup, save_snapshots, save
 
 class Model(object):
 
+    def __new__(cls, *args, **kwargs):
+        """grids without a fused plan: the any-size mix-in in front of the class (niwqg_amd/_anysize.py; see Kernel.Kernel.__new__)"""
+        nx = kwargs.get("nx", args[0] if args else 128)
+        if not _lib.has_fused_plan(nx) and not getattr(cls, "_any_size", False):
+            from . import _anysize
+            if not _anysize.supported(nx):
+                raise RuntimeError("nx = %r: the fused kernels take powers of two in [64, 8192], the any-size path even nx in "
+                                   "[4, %d]" % (nx, _anysize.NX_MAX))
+            cls = _anysize.specialise(cls, _anysize.QGFamily)
+        return object.__new__(cls)
+
     def __init__(self, nx=128, ny=None, L=5e5, dt=10000., twrite=1000, tswrite=10, tmax=250000.,
                  use_filter=True, U=.0, nu4=5.e9, nu=0, mu=0, beta=0, passive_scalar=False, nu4c=5.e9,
                  nuc=0, muc=0, dealias=False, save_to_disk=False, overwrite=True, tsave_snapshots=10,
@@ -44,24 +55,23 @@ class Model(object):
         self._initialize_filter()
         import os
         if slab is None:                 # under torch.distributed.run the model is slab-decomposed over the ranks (Kernel.py)
-            slab = int(os.environ.get("WORLD_SIZE", "1")) > 1
-        if slab:
-            from .slab import SlabContext
-            self._ctx = SlabContext(_lib.QG, nx, self.kk, self.ll, self.filtr, dt, peers=(slab if slab is not True else None),
-                                    nchunks=nchunks, device=(device if slab is not True else None), budgets=budgets,
-                                    U=U, nu=nu, nu4=nu4, mu=mu, beta=beta, passive_scalar=passive_scalar, nu4c=nu4c,
-                                    nuc=nuc, muc=muc)
-        else:
-            self._ctx = _lib.Context(_lib.QG, nx, self.kk, self.ll, self.filtr, dt, U=U, nu=nu, nu4=nu4, mu=mu,
-                                     beta=beta, budgets=budgets, device=device, passive_scalar=passive_scalar,
-                                     nu4c=nu4c, nuc=nuc, muc=muc)
+            slab = int(os.environ.get("WORLD_SIZE", "1")) > 1 and _lib.has_fused_plan(nx)
+        phys = dict(U=U, nu=nu, nu4=nu4, mu=mu, beta=beta, passive_scalar=passive_scalar, nu4c=nu4c, nuc=nuc, muc=muc)
         self._cache, self._user = {}, {}
+        self._ctx = self._create_context(phys, budgets, device, slab, nchunks)
         self.t, self.tc = 0, 0
         initialize_save_snapshots(self, self.path)      # ref: niwqg/QGModel.py:133-134; raises if no writer exists
         save_setup(self)
         self.cflmax = .5
         self.Ke = 0.0
         self._initialize_diagnostics()
+
+    def _create_context(self, phys, budgets, device, slab, nchunks):
+        if slab:
+            from .slab import SlabContext
+            return SlabContext(_lib.QG, self.nx, self.kk, self.ll, self.filtr, self.dt, peers=(slab if slab is not True else None),
+                               nchunks=nchunks, device=(device if slab is not True else None), budgets=budgets, **phys)
+        return _lib.Context(_lib.QG, self.nx, self.kk, self.ll, self.filtr, self.dt, budgets=budgets, device=device, **phys)
 
     def _initialize_logger(self):
         self.logger = logging.getLogger(__name__)

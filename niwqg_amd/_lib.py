@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # NIWQG_AMD_LIB: another build of the same sources (A/B experiments with compile-time knobs, tools/); default: the in-tree library
 LIB_PATH = os.environ.get("NIWQG_AMD_LIB") or os.path.join(HERE, "libniwqg_amd.so")
 SRC = os.path.join(HERE, "csrc", "nq_lib.hip")
-HEADERS = [os.path.join(HERE, "csrc", h) for h in ("nq_fft.hpp", "nq_generic.hpp", "nq_step.hpp")] + [
+HEADERS = [os.path.join(HERE, "csrc", h) for h in ("nq_fft.hpp", "nq_generic.hpp", "nq_step.hpp", "nq_anysize.hpp")] + [
     os.path.join(os.path.dirname(HERE), "include", "niwqg_amd.h")]
 
 COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
@@ -36,7 +36,17 @@ EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "
            "nq_reduce_buffer", "nq_reduce_read", "nq_reduce_write", "nq_device_bytes", "nq_stream",
            "nq_comm_probe", "nq_comm_unique_id", "nq_comm_init", "nq_slab_attach_peers", "nq_slab_set_callbacks", "nq_slab_set_null_link", "nq_slab_config", "nq_slab_set_stage_buffers", "nq_slab_spectral", "nq_slab_spectral_read",
            "nq_slab_step", "nq_slab_put_rows", "nq_slab_commit", "nq_slab_get_rows", "nq_slab_diagnostics",
-           "nq_slab_local_max", "nq_slab_counters", "nq_slab_allreduce_ms", "nq_snapshot_begin", "nq_snapshot_end"]
+           "nq_slab_local_max", "nq_slab_counters", "nq_slab_allreduce_ms", "nq_snapshot_begin", "nq_snapshot_end",
+           "nq_any_create", "nq_any_destroy", "nq_any_last_error", "nq_any_sync", "nq_any_device_bytes", "nq_any_alloc", "nq_any_free",
+           "nq_any_upload", "nq_any_download", "nq_any_fft", "nq_any_ew", "nq_any_reduce", "nq_any_expand_half", "nq_any_take_cols",
+           "nq_any_set_elem", "nq_any_etdrk4", "nq_any_etdrk4_patch"]
+
+FUSED_SIZES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)       # grids the fused ETDRK4 kernels have a plan for (csrc: NQ_FOR_SIZES)
+
+
+def has_fused_plan(nx):
+    return nx in FUSED_SIZES
+
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
@@ -146,6 +156,28 @@ def lib():
     L.nq_slab_allreduce_ms.argtypes = [vp, dp]
     L.nq_snapshot_begin.argtypes = [vp, ctypes.c_int]
     L.nq_snapshot_end.argtypes = [vp, dp, dp]
+    # the any-size engine (include/niwqg_amd.h: nq_any_*)
+    ip = ctypes.POINTER(ctypes.c_int)
+    L.nq_any_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.nq_any_destroy.argtypes = [vp]
+    L.nq_any_last_error.argtypes = [vp]
+    L.nq_any_last_error.restype = ctypes.c_char_p
+    L.nq_any_sync.argtypes = [vp]
+    L.nq_any_device_bytes.argtypes = [vp]
+    L.nq_any_device_bytes.restype = ctypes.c_longlong
+    L.nq_any_alloc.argtypes = [vp, ctypes.c_longlong, ctypes.POINTER(vp)]
+    L.nq_any_free.argtypes = [vp, vp, ctypes.c_longlong]
+    L.nq_any_upload.argtypes = [vp, vp, dp, ctypes.c_longlong]
+    L.nq_any_download.argtypes = [vp, vp, dp, ctypes.c_longlong]
+    L.nq_any_fft.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.nq_any_ew.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_longlong, dp]
+    L.nq_any_reduce.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_longlong, dp]
+    L.nq_any_expand_half.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.nq_any_take_cols.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.nq_any_set_elem.argtypes = [vp, vp, ctypes.c_longlong, ctypes.c_double, ctypes.c_double]
+    L.nq_any_etdrk4.argtypes = [vp, ctypes.c_int, ctypes.POINTER(Params), dp, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp),
+                                ctypes.c_double, ctypes.c_int, ip, ip, ip]
+    L.nq_any_etdrk4_patch.argtypes = [vp, ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, ip, ip, dp]
     L.nq_device_bytes.argtypes = [vp]
     L.nq_device_bytes.restype = ctypes.c_longlong
     L.nq_stream.argtypes = [vp]

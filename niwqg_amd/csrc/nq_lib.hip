@@ -10,6 +10,7 @@
 
 #include "../../include/niwqg_amd.h"
 #include "nq_step.hpp"
+#include "nq_anysize.hpp"
 
 using namespace nq;
 
@@ -3628,6 +3629,307 @@ long long nq_field_doubles(const nq_ctx* c, int id) {
     case NQ_F_PHI: case NQ_F_PHIH: case NQ_F_PHIX: case NQ_F_PHIY: case NQ_F_PHIH_STAGE4: return 2 * n * n;
     default: return -1;
   }
+}
+
+}  // extern "C"
+
+// ==================================================================================================================
+// The any-size engine (include/niwqg_amd.h: nq_any_*; csrc/nq_anysize.hpp; niwqg_amd/_anysize.py)
+// ==================================================================================================================
+#define ANYCHK(e, call)                                                                                      \
+  do {                                                                                                       \
+    hipError_t e_ = (call);                                                                                  \
+    if (e_ != hipSuccess) {                                                                                  \
+      char b_[384];                                                                                          \
+      snprintf(b_, sizeof(b_), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);   \
+      g_last_error = b_;                                                                                     \
+      if (e) (e)->err = b_;                                                                                  \
+      return -5;                                                                                             \
+    }                                                                                                        \
+  } while (0)
+#define ANYFAIL(e, code, ...)                      \
+  do {                                             \
+    char b_[384];                                  \
+    snprintf(b_, sizeof(b_), __VA_ARGS__);         \
+    g_last_error = b_;                             \
+    if (e) (e)->err = b_;                          \
+    return (code);                                 \
+  } while (0)
+
+template <bool INV>
+static int any_rows_fft(nq_any* e, const nq_any::Plan& pl, int nlines, double scale) {
+  switch (pl.M) {
+#define CASE_(n, a, b) case n: { typedef XPlan<n> X; \
+      hipLaunchKernelGGL((k_x_c2c<n, INV>), dim3((nlines + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, e->stream, \
+                         (const cd*)e->tmp, e->tmp, pl.M, pl.M, nlines, scale, (const cd*)pl.tw, (const double*)nullptr, 0); } break;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+    default: ANYFAIL(e, -2, "any-size engine: no row plan of length %d", pl.M);
+  }
+  return 0;
+}
+static int any_tmp(nq_any* e, size_t elems) {
+  if (e->tmp_elems >= elems) return 0;
+  if (e->tmp) {
+    ANYCHK(e, hipStreamSynchronize(e->stream));
+    ANYCHK(e, hipFree(e->tmp));
+    e->tmp = nullptr;
+    e->tmp_elems = 0;
+  }
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&e->tmp), elems * sizeof(cd)));
+  e->tmp_elems = elems;
+  return 0;
+}
+// Bluestein plan for transforms of length n: chirp w[j] = exp(-i pi j^2 / n) (angle reduced exactly: j^2 mod 2n), the transform of
+// conj(w) laid out circularly on M >= 2n - 1 points, and the twiddle table of the M-point row engine
+static int any_plan(nq_any* e, int n, const nq_any::Plan** out) {
+  for (const nq_any::Plan& p : e->plans)
+    if (p.n == n) { *out = &p; return 0; }
+  if (n < 2 || n > 4096) ANYFAIL(e, -2, "any-size engine: transform length %d outside [2, 4096]", n);
+  nq_any::Plan pl;
+  pl.n = n;
+  pl.M = 64;
+  while (pl.M < 2 * n - 1) pl.M *= 2;
+  const int M = pl.M;
+  std::vector<double> w(2 * (size_t)n), b(2 * (size_t)M, 0.0), tw(2 * (size_t)M);
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int j = 0; j < n; ++j) {
+    const long long r = ((long long)j * j) % (2LL * n);
+    const long double a = pi * (long double)r / (long double)n;
+    w[2 * j] = (double)cosl(a);
+    w[2 * j + 1] = (double)(-sinl(a));
+    // conj(w[j]) at +j and -j (circular)
+    b[2 * j] = (double)cosl(a);
+    b[2 * j + 1] = (double)sinl(a);
+    if (j > 0) {
+      b[2 * (size_t)(M - j)] = (double)cosl(a);
+      b[2 * (size_t)(M - j) + 1] = (double)sinl(a);
+    }
+  }
+  for (int m = 0; m < M; ++m) {
+    const long double a = -2.0L * pi * (long double)m / (long double)M;
+    tw[2 * m] = (double)cosl(a);
+    tw[2 * m + 1] = (double)sinl(a);
+  }
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.chirp), sizeof(cd) * n));
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.bhat), sizeof(cd) * M));
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.tw), sizeof(cd) * M));
+  ANYCHK(e, hipMemcpy(pl.chirp, w.data(), sizeof(cd) * n, hipMemcpyHostToDevice));
+  ANYCHK(e, hipMemcpy(pl.tw, tw.data(), sizeof(cd) * M, hipMemcpyHostToDevice));
+  int rc = any_tmp(e, (size_t)M);
+  if (rc) return rc;
+  ANYCHK(e, hipMemcpy(e->tmp, b.data(), sizeof(cd) * M, hipMemcpyHostToDevice));
+  rc = any_rows_fft<false>(e, pl, 1, 1.0);
+  if (rc) return rc;
+  ANYCHK(e, hipMemcpyAsync(pl.bhat, e->tmp, sizeof(cd) * M, hipMemcpyDeviceToDevice, e->stream));
+  ANYCHK(e, hipStreamSynchronize(e->stream));
+  e->plans.push_back(pl);
+  *out = &e->plans.back();
+  return 0;
+}
+
+extern "C" {
+
+int nq_any_create(int device, nq_any** out) {
+  if (!out) return -1;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_any_create: no HIP device available");
+  if (device < 0 || device >= ndev) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_any_create: device %d out of range (%d devices)", device, ndev);
+  nq_any* e = new nq_any();
+  e->device = device;
+  e->plans.reserve(16);
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&e->part), sizeof(double) * 2 * 1024) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&e->red), sizeof(double) * 2) != hipSuccess) {
+    delete e;
+    NQ_FAIL((nq_ctx*)nullptr, -5, "nq_any_create: stream / scratch allocation failed");
+  }
+  *out = e;
+  return 0;
+}
+int nq_any_destroy(nq_any* e) {
+  if (!e) return -1;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  for (void* p : e->allocs) (void)hipFree(p);
+  for (nq_any::Plan& p : e->plans) { (void)hipFree(p.chirp); (void)hipFree(p.bhat); (void)hipFree(p.tw); }
+  if (e->tmp) (void)hipFree(e->tmp);
+  (void)hipFree(e->part);
+  (void)hipFree(e->red);
+  (void)hipStreamDestroy(e->stream);
+  delete e;
+  return 0;
+}
+const char* nq_any_last_error(const nq_any* e) { return e ? e->err.c_str() : g_last_error.c_str(); }
+int nq_any_sync(nq_any* e) {
+  if (!e) return -1;
+  ANYCHK(e, hipStreamSynchronize(e->stream));
+  ANYCHK(e, hipGetLastError());
+  return 0;
+}
+long long nq_any_device_bytes(const nq_any* e) { return e ? e->bytes + (long long)(e->tmp_elems * sizeof(cd)) : 0; }
+int nq_any_alloc(nq_any* e, long long elems, void** plane) {
+  if (!e || !plane || elems <= 0) return -1;
+  ANYCHK(e, hipSetDevice(e->device));
+  void* p = nullptr;
+  ANYCHK(e, hipMalloc(&p, (size_t)elems * sizeof(cd)));
+  ANYCHK(e, hipMemsetAsync(p, 0, (size_t)elems * sizeof(cd), e->stream));
+  e->allocs.push_back(p);
+  e->bytes += elems * (long long)sizeof(cd);
+  *plane = p;
+  return 0;
+}
+int nq_any_free(nq_any* e, void* plane, long long elems) {
+  if (!e || !plane) return -1;
+  for (size_t i = 0; i < e->allocs.size(); ++i)
+    if (e->allocs[i] == plane) {
+      ANYCHK(e, hipStreamSynchronize(e->stream));
+      ANYCHK(e, hipFree(plane));
+      e->allocs.erase(e->allocs.begin() + i);
+      e->bytes -= elems * (long long)sizeof(cd);
+      return 0;
+    }
+  ANYFAIL(e, -1, "nq_any_free: not a plane of this engine");
+}
+int nq_any_upload(nq_any* e, void* plane, const double* host_cplx, long long elems) {
+  if (!e || !plane || !host_cplx || elems <= 0) return -1;
+  ANYCHK(e, hipMemcpyAsync(plane, host_cplx, (size_t)elems * sizeof(cd), hipMemcpyHostToDevice, e->stream));
+  return nq_any_sync(e);
+}
+int nq_any_download(nq_any* e, const void* plane, double* host_cplx, long long elems) {
+  if (!e || !plane || !host_cplx || elems <= 0) return -1;
+  ANYCHK(e, hipMemcpyAsync(host_cplx, plane, (size_t)elems * sizeof(cd), hipMemcpyDeviceToHost, e->stream));
+  return nq_any_sync(e);
+}
+// dst <- 1-D transforms of src along `axis` (1: along the contiguous index, length cols; 0: length rows), numpy.fft conventions
+// (forward unnormalised, inverse scaled by 1/n); dst may be src
+int nq_any_fft(nq_any* e, void* dst, const void* src, int rows, int cols, int axis, int inverse) {
+  if (!e || !dst || !src || rows < 1 || cols < 1 || (axis != 0 && axis != 1)) return -1;
+  ANYCHK(e, hipSetDevice(e->device));
+  const int n = axis == 1 ? cols : rows, nlines = axis == 1 ? rows : cols;
+  const nq_any::Plan* pl = nullptr;
+  int rc = any_plan(e, n, &pl);
+  if (rc) return rc;
+  rc = any_tmp(e, (size_t)nlines * pl->M);
+  if (rc) return rc;
+  const dim3 gp((pl->M + 15) / 16, (nlines + 15) / 16), gu((n + 15) / 16, (nlines + 15) / 16);
+  hipLaunchKernelGGL((k_any_lines<true>), gp, dim3(256), 0, e->stream, reinterpret_cast<cd*>(const_cast<void*>(src)), e->tmp, rows, cols, axis, pl->M,
+                     (const cd*)pl->chirp, inverse ? 1 : 0, 1.0);
+  rc = any_rows_fft<false>(e, *pl, nlines, 1.0);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_any_mul_rows, dim3(2048), dim3(256), 0, e->stream, e->tmp, (const cd*)pl->bhat, nlines, pl->M);
+  rc = any_rows_fft<true>(e, *pl, nlines, 1.0 / (double)pl->M);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_any_lines<false>), gu, dim3(256), 0, e->stream, reinterpret_cast<cd*>(dst), e->tmp, rows, cols, axis, pl->M,
+                     (const cd*)pl->chirp, inverse ? 1 : 0, inverse ? 1.0 / (double)n : 1.0);
+  ANYCHK(e, hipGetLastError());
+  return 0;
+}
+// d <- op(a, b, c; scalars) element by element over `elems` complex values (NQ_EW_* in the header); operands the op does not use
+// may be NULL; d may alias an operand
+int nq_any_ew(nq_any* e, int op, void* d, const void* a, const void* b, const void* c, long long elems, const double* scalars6) {
+  if (!e || !d || !a || elems <= 0 || op < 0 || op > EW_MULADD) return -1;
+  const bool need_b = (op == EW_MUL || op == EW_MULCONJ || op == EW_AXPBY || op == EW_AXPBYPCZ || op == EW_MULADD);
+  const bool need_c = (op == EW_AXPBYPCZ || op == EW_MULADD);
+  if ((need_b && !b) || (need_c && !c)) ANYFAIL(e, -1, "nq_any_ew: op %d needs more operands", op);
+  EwScalars sc;
+  for (int i = 0; i < 6; ++i) sc.s[i] = scalars6 ? scalars6[i] : (i == 0 ? 1.0 : 0.0);
+  const size_t n = (size_t)elems;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_any_ew, dim3(grid), dim3(256), 0, e->stream, op, reinterpret_cast<cd*>(d), reinterpret_cast<const cd*>(a),
+                     reinterpret_cast<const cd*>(b), reinterpret_cast<const cd*>(c), n, sc);
+  return 0;
+}
+// out2 <- reduction over `elems` complex values (NQ_RD_*): deterministic (fixed grid, partials added in order)
+int nq_any_reduce(nq_any* e, int op, const void* a, const void* b, long long elems, double* out2) {
+  if (!e || !a || !out2 || elems <= 0 || op < 0 || op > RD_MAXABSRE) return -1;
+  if ((op == RD_DOT || op == RD_DOTC || op == RD_WSUMABS2) && !b) ANYFAIL(e, -1, "nq_any_reduce: op %d needs two operands", op);
+  const size_t n = (size_t)elems;
+  const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(k_any_reduce1, dim3(grid), dim3(256), 0, e->stream, op, reinterpret_cast<const cd*>(a), reinterpret_cast<const cd*>(b), n, e->part);
+  hipLaunchKernelGGL(k_any_reduce2, dim3(1), dim3(64), 0, e->stream, op, (const double*)e->part, grid, e->red);
+  ANYCHK(e, hipMemcpyAsync(out2, e->red, sizeof(double) * 2, hipMemcpyDeviceToHost, e->stream));
+  return nq_any_sync(e);
+}
+// (rows, n/2+1) half spectrum -> (rows, n) Hermitian extension; project: Hermitian part (in l) of the two self-mirrored columns first
+int nq_any_expand_half(nq_any* e, void* full, const void* half, int rows, int n, int project) {
+  if (!e || !full || !half || rows < 1 || n < 2 || (n & 1)) return -1;
+  hipLaunchKernelGGL(k_any_expand_half, dim3((n + 63) / 64, rows), dim3(64), 0, e->stream, reinterpret_cast<const cd*>(half), reinterpret_cast<cd*>(full), rows, n, project);
+  return 0;
+}
+// the first dcols columns of a (rows, scols) plane as a (rows, dcols) plane
+int nq_any_take_cols(nq_any* e, void* dst, const void* src, int rows, int scols, int dcols) {
+  if (!e || !dst || !src || rows < 1 || dcols < 1 || dcols > scols) return -1;
+  hipLaunchKernelGGL(k_any_take_cols, dim3((dcols + 63) / 64, rows), dim3(64), 0, e->stream, reinterpret_cast<const cd*>(src), reinterpret_cast<cd*>(dst), rows, scols, dcols);
+  return 0;
+}
+int nq_any_set_elem(nq_any* e, void* plane, long long index, double re, double im) {
+  if (!e || !plane || index < 0) return -1;
+  hipLaunchKernelGGL(k_any_set_elem, dim3(1), dim3(1), 0, e->stream, reinterpret_cast<cd*>(plane), (size_t)index, re, im);
+  return 0;
+}
+// ETDRK4 planes of the linear operator c(l, k) on the whole (n, cols) plane, no filter folded in (the any-size path multiplies by
+// `filtr` as the reference does): eq as k_etdrk4_coeffs (0 q Kernel family, 1 phi, 2 QGModel's q, 3 its passive scalar);
+// kk (cols values), ll (n values) host arrays; out6: E, Eh, Q, f0, fab, fc planes of this engine.
+// near_*: the entries within delta of the contour (at most cap), for the host to recompute (niwqg_amd/_etdrk4.py) and hand back
+int nq_any_etdrk4(nq_any* e, int eq, const nq_params* p, const double* kk, const double* ll, const double* contour32, int n, int cols,
+                  void* const* out6, double delta, int cap, int* near_count, int* near_l, int* near_k) {
+  if (!e || !p || !kk || !ll || !contour32 || !out6 || n < 2 || cols < 1 || eq < 0 || eq > 3) return -1;
+  ANYCHK(e, hipSetDevice(e->device));
+  double *dk = nullptr, *dl = nullptr;
+  cd* dc = nullptr;
+  int *cnt = nullptr, *lo = nullptr, *ko = nullptr;
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dk), sizeof(double) * cols));
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dl), sizeof(double) * n));
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dc), sizeof(cd) * 32));
+  ANYCHK(e, hipMemcpy(dk, kk, sizeof(double) * cols, hipMemcpyHostToDevice));
+  ANYCHK(e, hipMemcpy(dl, ll, sizeof(double) * n, hipMemcpyHostToDevice));
+  ANYCHK(e, hipMemcpy(dc, contour32, sizeof(cd) * 32, hipMemcpyHostToDevice));
+  cd* o[6];
+  for (int i = 0; i < 6; ++i) o[i] = reinterpret_cast<cd*>(out6[i]);
+  hipLaunchKernelGGL(k_etdrk4_coeffs, dim3((cols + 63) / 64, n), dim3(64), 0, e->stream, eq, n, cols, cols, 0, *p, (const double*)dk, (const double*)dl,
+                     (const double*)nullptr, (const cd*)dc, o[0], o[1], o[2], o[3], o[4], o[5]);
+  int found = 0;
+  if (near_count && near_l && near_k && cap > 0) {
+    ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&cnt), sizeof(int)));
+    ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&lo), sizeof(int) * cap));
+    ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&ko), sizeof(int) * cap));
+    ANYCHK(e, hipMemsetAsync(cnt, 0, sizeof(int), e->stream));
+    hipLaunchKernelGGL(k_coeff_flag, dim3((cols + 63) / 64, n), dim3(64), 0, e->stream, eq, n, cols, 0, *p, (const double*)dk, (const double*)dl, (const cd*)dc,
+                       delta * delta, cap, cnt, lo, ko);
+    ANYCHK(e, hipMemcpyAsync(&found, cnt, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    ANYCHK(e, hipStreamSynchronize(e->stream));
+    const int take = found < cap ? found : cap;
+    if (take > 0) {
+      ANYCHK(e, hipMemcpy(near_l, lo, sizeof(int) * take, hipMemcpyDeviceToHost));
+      ANYCHK(e, hipMemcpy(near_k, ko, sizeof(int) * take, hipMemcpyDeviceToHost));
+    }
+    *near_count = found;
+  }
+  ANYCHK(e, hipStreamSynchronize(e->stream));
+  (void)hipFree(dk); (void)hipFree(dl); (void)hipFree(dc);
+  if (cnt) { (void)hipFree(cnt); (void)hipFree(lo); (void)hipFree(ko); }
+  ANYCHK(e, hipGetLastError());
+  return 0;
+}
+// vals: count x 4 complex (Qh, f0, fab, fc) for the entries (l, k) of a (n, cols) plane set
+int nq_any_etdrk4_patch(nq_any* e, void* const* out6, int cols, int count, const int* l, const int* k, const double* vals) {
+  if (!e || !out6 || count < 0 || (count > 0 && (!l || !k || !vals))) return -1;
+  if (count == 0) return 0;
+  int *dl = nullptr, *dk = nullptr;
+  cd* dv = nullptr;
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dl), sizeof(int) * count));
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dk), sizeof(int) * count));
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dv), sizeof(cd) * 4 * count));
+  ANYCHK(e, hipMemcpy(dl, l, sizeof(int) * count, hipMemcpyHostToDevice));
+  ANYCHK(e, hipMemcpy(dk, k, sizeof(int) * count, hipMemcpyHostToDevice));
+  ANYCHK(e, hipMemcpy(dv, vals, sizeof(cd) * 4 * count, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_coeff_patch, dim3((count + 255) / 256), dim3(256), 0, e->stream, count, (const int*)dl, (const int*)dk, (const cd*)dv, cols, cols, 0,
+                     (const double*)nullptr, reinterpret_cast<cd*>(out6[2]), reinterpret_cast<cd*>(out6[3]), reinterpret_cast<cd*>(out6[4]), reinterpret_cast<cd*>(out6[5]));
+  ANYCHK(e, hipStreamSynchronize(e->stream));
+  (void)hipFree(dl); (void)hipFree(dk); (void)hipFree(dv);
+  return 0;
 }
 
 }  // extern "C"

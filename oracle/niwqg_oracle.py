@@ -705,6 +705,10 @@ class QGOracle:
         if self.passive_scalar:
             vals += [("C2", self.C2), ("cvar", self.cvar), ("gradC2", self.gradC2), ("Gamma_c", self.Gamma_c),
                      ("ep_c", self._calc_ep_c()), ("chi_c", self._calc_chi_c())]
+        else:
+            # the reference registers the scalar's entries whatever passive_scalar says (QGModel.py:690-722) and, without the
+            # scalar, evaluates them on C2 = gradC2 = cvar = Gamma_c = 0, c = ch = 0, lapc = [0.] (QGModel.py:734-737): zeros
+            vals += [("C2", 0.0), ("cvar", 0.0), ("gradC2", 0.0), ("Gamma_c", 0.0), ("ep_c", 0.0), ("chi_c", 0.0)]
         return vals
 
     def _increment_diagnostics(self):

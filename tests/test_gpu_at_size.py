@@ -424,7 +424,7 @@ def test_dealias_roundoff_growth_at_size_is_the_oracles_own(nx):
     band = np.zeros(nx, bool)
     band[np.r_[0:13, nx - 12:nx]] = True
     out = ~(band[:, None] & band[None, :])
-    a, b, d_dev, d_orc = [], [], [], []
+    a, b, d_dev, d_orc, peak = [], [], [], [], []
     for n in range(nsteps):
         m._step_forward()
         o._step_forward()
@@ -432,17 +432,22 @@ def test_dealias_roundoff_growth_at_size_is_the_oracles_own(nx):
         mq, oq = m.qh, o.qh
         a.append(float(np.abs(mq[out]).max()))
         b.append(float(np.abs(oq[out]).max()))
+        peak.append(float(np.abs(oq).max()))
         d_dev.append(rel(mq, oq))
         d_orc.append(rel(o2.qh, oq))
         print("%d^2 step %2d  outside the band: device %.6e oracle %.6e   device-oracle %.1e   oracle-oracle(perturbed 1e-16) %.1e"
               % (nx, n + 1, a[-1], b[-1], d_dev[-1], d_orc[-1]), flush=True)
         if not (np.isfinite(a[-1]) and np.isfinite(b[-1])) or max(a[-1], b[-1]) > 1e100:
             break
-    a, b, d_dev, d_orc = (np.array(v) for v in (a, b, d_dev, d_orc))
+    a, b, d_dev, d_orc, peak = (np.array(v) for v in (a, b, d_dev, d_orc, peak))
     ga, gb = a[1:] / a[:-1], b[1:] / b[:-1]
-    clean = d_dev[1:] < 1e-9
-    assert clean.sum() >= 3, d_dev
-    assert np.allclose(ga[clean], gb[clean], rtol=1e-6), (ga, gb)
+    clean = d_dev < 1e-9
+    assert clean.sum() >= 4, d_dev
+    # the maxima themselves to 1e-6 (plus a rounding floor: the spectrum's peak is 1e8 .. 1e12 times larger), hence their ratios
+    assert (np.abs(a - b)[clean] <= 1e-6 * b[clean] + 1e-15 * peak[clean]).all(), (a, b)
+    both = clean[1:] & clean[:-1] & (b[:-1] > 1e-11 * peak[:-1])
+    assert both.sum() >= 2, (b, peak)
+    assert np.allclose(ga[both], gb[both], rtol=1e-5), (ga, gb)
     # amplification per step, over the steps where the differences are above rounding and below saturation
     def rate(d):
         w = (d > 1e-14) & (d < 1e-2)
@@ -453,7 +458,8 @@ def test_dealias_roundoff_growth_at_size_is_the_oracles_own(nx):
     print("%d^2: per-step amplification of a rounding-level difference: oracle vs itself x%.2f, device vs oracle x%.2f" % (nx, r_o, r_d))
     assert r_o > 2.0, r_o
     assert 1 / 1.5 < r_d / r_o < 1.5, (r_d, r_o)
-    assert (d_dev <= 1e3 * d_orc + 1e-13).all(), (d_dev, d_orc)
+    live = np.isfinite(d_dev) & np.isfinite(d_orc) & (d_orc < 0.1)       # (once the two oracles differ by O(1) there is nothing left to compare)
+    assert (d_dev[live] <= 1e3 * d_orc[live] + 1e-13).all(), (d_dev, d_orc)
 
 
 def test_qg_passive_scalar_row_kernel_8192_on_a_full_spectrum_against_numpy():

@@ -392,6 +392,8 @@ def main():
     ap.add_argument("--rank-of", type=int, default=0, help="measure ONE rank of a P-rank slab decomposition alone on this GPU "
                     "(P = 2, 4, 8; no exchange, nq_slab_set_null_link): the per-rank compute term of the strong-scaling "
                     "arithmetic, next to the single-GPU step of the same run")
+    ap.add_argument("--rank-only", action="store_true", help="with --rank-of: skip the single-GPU step of the same run (so that a "
+                    "kernel trace of the run holds the slab instantiations only)")
     ap.add_argument("--replicas", action="store_true", help="with --gpus N > 1: N independent replicas instead of one "
                                                             "slab-decomposed simulation")
     args = ap.parse_args()
@@ -576,7 +578,9 @@ def main():
             extra["replicas_aggregate_steps_per_s"] = aggregate_throughput(grp, args.steps, time.perf_counter() - t1)[0]
             del m2
 
-    if sim is not None and args.rank_of:
+    if sim is not None and args.rank_of and args.rank_only:
+        extra.update(rank_of=args.rank_of, rank_compute_ms_per_step=dev_ms / args.steps)
+    elif sim is not None and args.rank_of:
         # the single-GPU step on the same box in the same run: what the rank's compute is held against (gate: <= 1.15 x step / P)
         sim.sync()
         m1 = build_model(phys_model, args.nx, local_rank, kind=args.model)

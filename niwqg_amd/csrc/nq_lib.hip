@@ -43,7 +43,7 @@ struct EqState {           // ETDRK4 state of one equation
   int cur = 0;
   cd *fn0 = nullptr, *fna = nullptr;
   cd* coef[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // E, Eh, Q, f0, fab, fc (filter folded in)
-};
+};                                                                       // (rows 0..N/2 only when nq_ctx::cmirror is set)
 
 struct nq_ctx {
   nq_params p;
@@ -54,6 +54,12 @@ struct nq_ctx {
   int Wh = 0, Ph = 0;    // valid local half-spectrum columns and their pitch (== WhG, N/2+8 when P == 1)
   bool own_stream = true;
   bool kernel_family = true;
+  // c(l, k), the filter and the contour patches depend on l through l^2 only: rows l and N - l of every ETDRK4 coefficient plane
+  // are bit-identical (unless the filter is not mirror-symmetric in l: the 2/3 mask).  cmirror = 1: the planes hold rows 0..N/2
+  // and the spectral kernels index them through crow() -- half the coefficient memory, and, with the B-sub-pass workgroups of
+  // mirrored residues launched back to back (pair_order), the second read of a line is served on chip.  NIWQG_AMD_COEF_MIRROR=0
+  // keeps all N rows (A/B measurements).
+  int cmirror = 0, crows = 0;
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -271,14 +277,16 @@ __global__ void k_coeff_flag(int eq, int N, int width, int k0, nq_params p, cons
   }
 }
 // v: n x 4 values (Qh, f0, fab, fc of the reference, no filter); k is a global column
+// mrows = N when the planes hold rows 0..N/2 only (row N - l shares the storage of row l: nq_ctx::cmirror), else 0
 __global__ void k_coeff_patch(int n, const int* __restrict__ li, const int* __restrict__ ki, const cd* __restrict__ v, int width,
-                              int pitch, int k0, const double* __restrict__ filt, cd* Q, cd* f0, cd* fab, cd* fc) {
+                              int pitch, int k0, const double* __restrict__ filt, cd* Q, cd* f0, cd* fab, cd* fc, int mrows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int k = ki[i] - k0;
   if (k < 0 || k >= width) return;
-  const size_t idx = (size_t)li[i] * pitch + k;
-  const double fl = filt ? filt[idx] : 1.0;
+  const double fl = filt ? filt[(size_t)li[i] * pitch + k] : 1.0;
+  const int lr = (mrows && li[i] > mrows / 2) ? mrows - li[i] : li[i];
+  const size_t idx = (size_t)lr * pitch + k;
   Q[idx] = cscale(v[4 * i], fl);
   f0[idx] = cscale(v[4 * i + 1], fl);
   fab[idx] = cscale(v[4 * i + 2], fl);
@@ -873,6 +881,7 @@ static YGeom geom_half(const nq_ctx* c) {
   g.pitch_s = c->Ph;
   g.S2 = c->S2;
   g.kernel_family = c->kernel_family ? 1 : 0;
+  g.cmirror = c->cmirror;
   return g;
 }
 static YGeom geom_full(const nq_ctx* c) {
@@ -882,6 +891,7 @@ static YGeom geom_full(const nq_ctx* c) {
   g.pitch_s = c->Wf;
   g.S2 = c->S2;
   g.kernel_family = 1;
+  g.cmirror = c->cmirror;
   return g;
 }
 
@@ -2022,19 +2032,30 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
       ALLOC(c, c->filt_f, full);
       HIPCHK(c, hipMemcpy2DAsync(c->filt_f, sizeof(double) * c->Wf, filtr + c->kf0, sizeof(double) * c->nk, sizeof(double) * c->Wf, N, hipMemcpyHostToDevice, c->stream));
     }
+    {
+      // is the filter mirror-symmetric in l on this rank's columns?  (the exponential filter and "none" are; the 2/3 mask is not)
+      const char* e = getenv("NIWQG_AMD_COEF_MIRROR");
+      bool sym = !(e && atoi(e) == 0) && N >= 4;
+      for (int l = 1; sym && l < N / 2; ++l)
+        for (int k = 0; k < c->nk; ++k)
+          if (filtr[(size_t)l * c->nk + k] != filtr[(size_t)(N - l) * c->nk + k]) { sym = false; break; }
+      c->cmirror = sym ? 1 : 0;
+      c->crows = sym ? N / 2 + 1 : N;
+    }
+    const size_t half_c = (size_t)c->crows * c->Ph, full_c = (size_t)c->crows * c->Wf;
     // equations
     for (int i = 0; i < 3; ++i) ALLOC(c, c->q.y[i], half);
     ALLOC(c, c->q.fn0, half);
     ALLOC(c, c->q.fna, half);
-    for (int i = 0; i < 6; ++i) ALLOC(c, c->q.coef[i], half);
-    dim3 blk(64), grdh((c->Wh + 63) / 64, N), grdf((c->Wf + 63) / 64, N);
+    for (int i = 0; i < 6; ++i) ALLOC(c, c->q.coef[i], half_c);
+    dim3 blk(64), grdh((c->Wh + 63) / 64, c->crows), grdf((c->Wf + 63) / 64, c->crows);
     if (c->Wh > 0)
       hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, c->kernel_family ? 0 : 2, N, c->Wh, c->Ph, c->kh0, c->p, c->kk, c->ll, c->filt_h, c->contour, c->q.coef[0], c->q.coef[1], c->q.coef[2], c->q.coef[3], c->q.coef[4], c->q.coef[5]);
     if (sg.passive) {
       for (int i = 0; i < 3; ++i) ALLOC(c, c->cq.y[i], half);
       ALLOC(c, c->cq.fn0, half);
       ALLOC(c, c->cq.fna, half);
-      for (int i = 0; i < 6; ++i) ALLOC(c, c->cq.coef[i], half);
+      for (int i = 0; i < 6; ++i) ALLOC(c, c->cq.coef[i], half_c);
       if (c->Wh > 0)
         hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, 3, N, c->Wh, c->Ph, c->kh0, c->p, c->kk, c->ll, c->filt_h, c->contour, c->cq.coef[0], c->cq.coef[1], c->cq.coef[2], c->cq.coef[3], c->cq.coef[4], c->cq.coef[5]);
     }
@@ -2043,7 +2064,7 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
       for (int i = 0; i < 3; ++i) ALLOC(c, c->q2.y[i], half);
       ALLOC(c, c->q2.fn0, half);
       ALLOC(c, c->q2.fna, half);
-      for (int i = 0; i < 6; ++i) ALLOC(c, c->coefu[i], half);
+      for (int i = 0; i < 6; ++i) ALLOC(c, c->coefu[i], half_c);
       if (c->Wh > 0)
         hipLaunchKernelGGL(k_etdrk4_coeffs, grdh, blk, 0, c->stream, 0, N, c->Wh, c->Ph, c->kh0, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, c->coefu[0], c->coefu[1], c->coefu[2], c->coefu[3], c->coefu[4], c->coefu[5]);
       std::vector<double> fm((size_t)N * c->Ph, 0.0);
@@ -2075,7 +2096,7 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
       for (int i = 0; i < 3; ++i) ALLOC(c, c->w.y[i], full);
       ALLOC(c, c->w.fn0, full);
       ALLOC(c, c->w.fna, full);
-      for (int i = 0; i < 6; ++i) ALLOC(c, c->w.coef[i], full);
+      for (int i = 0; i < 6; ++i) ALLOC(c, c->w.coef[i], full_c);
       hipLaunchKernelGGL(k_etdrk4_coeffs, grdf, blk, 0, c->stream, 1, N, c->Wf, c->Wf, c->kf0, c->p, c->kk, c->ll, c->filt_f, c->contour, c->w.coef[0], c->w.coef[1], c->w.coef[2], c->w.coef[3], c->w.coef[4], c->w.coef[5]);
     }
     c->bud = p->budgets != 0;
@@ -3342,11 +3363,11 @@ int nq_get_scalar(nq_ctx* c, int id, double* out) {
 }
 
 // overwrite the entries nq_coeff_patch recorded for public equation eq in one set of coefficient planes
-static void apply_coeff_patch(nq_ctx* c, int eq, int width, int pitch, int k0, const double* filt, cd* const* coef) {
+static void apply_coeff_patch(nq_ctx* c, int eq, int width, int pitch, int k0, const double* filt, cd* const* coef, bool mirrored) {
   const nq_ctx::CoefPatch& pt = c->patch[eq];
   if (pt.n == 0 || width == 0) return;
   hipLaunchKernelGGL(k_coeff_patch, dim3((pt.n + 255) / 256), dim3(256), 0, c->stream, pt.n, pt.l, pt.k, pt.v, width, pitch, k0, filt,
-                     coef[2], coef[3], coef[4], coef[5]);
+                     coef[2], coef[3], coef[4], coef[5], mirrored ? c->N : 0);
 }
 
 int nq_get_coeff(nq_ctx* c, int eq, int which, double* out) {
@@ -3365,7 +3386,7 @@ int nq_get_coeff(nq_ctx* c, int eq, int which, double* out) {
   for (int i = 0; i < 6; ++i) tmp[i] = reinterpret_cast<cd*>(blockp) + (size_t)i * cnt;
   const int e = eq == 2 ? 3 : (half ? (c->kernel_family ? 0 : 2) : 1);
   hipLaunchKernelGGL(k_etdrk4_coeffs, dim3((width + 63) / 64, N), dim3(64), 0, c->stream, e, N, width, pitch, 0, c->p, c->kk, c->ll, (const double*)nullptr, c->contour, tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5]);
-  apply_coeff_patch(c, eq, width, pitch, 0, nullptr, tmp);
+  apply_coeff_patch(c, eq, width, pitch, 0, nullptr, tmp, false);
   hipError_t er = hipMemcpy2DAsync(out, sizeof(cd) * width, tmp[which], sizeof(cd) * pitch, sizeof(cd) * width, N, hipMemcpyDeviceToHost, c->stream);
   int rc = nq_sync(c);
   (void)hipFree(blockp);
@@ -3428,12 +3449,12 @@ int nq_coeff_patch(nq_ctx* c, int eq, int n, const int* l, const int* k, const d
   HIPCHK(c, hipMemcpy(pt.v, vals, sizeof(cd) * 4 * (size_t)n, hipMemcpyHostToDevice));
   pt.n = n;
   if (eq == 0) {
-    apply_coeff_patch(c, 0, c->Wh, c->Ph, c->kh0, c->filt_h, c->q.coef);
-    if (c->dual) apply_coeff_patch(c, 0, c->Wh, c->Ph, c->kh0, nullptr, c->coefu);
+    apply_coeff_patch(c, 0, c->Wh, c->Ph, c->kh0, c->filt_h, c->q.coef, c->cmirror != 0);
+    if (c->dual) apply_coeff_patch(c, 0, c->Wh, c->Ph, c->kh0, nullptr, c->coefu, c->cmirror != 0);
   } else if (eq == 1) {
-    apply_coeff_patch(c, 1, c->Wf, c->Wf, c->kf0, c->filt_f, c->w.coef);
+    apply_coeff_patch(c, 1, c->Wf, c->Wf, c->kf0, c->filt_f, c->w.coef, c->cmirror != 0);
   } else {
-    apply_coeff_patch(c, 2, c->Wh, c->Ph, c->kh0, c->filt_h, c->cq.coef);
+    apply_coeff_patch(c, 2, c->Wh, c->Ph, c->kh0, c->filt_h, c->cq.coef, c->cmirror != 0);
   }
   return nq_sync(c);
 }
@@ -3926,7 +3947,7 @@ int nq_any_etdrk4_patch(nq_any* e, void* const* out6, int cols, int count, const
   ANYCHK(e, hipMemcpy(dk, k, sizeof(int) * count, hipMemcpyHostToDevice));
   ANYCHK(e, hipMemcpy(dv, vals, sizeof(cd) * 4 * count, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_coeff_patch, dim3((count + 255) / 256), dim3(256), 0, e->stream, count, (const int*)dl, (const int*)dk, (const cd*)dv, cols, cols, 0,
-                     (const double*)nullptr, reinterpret_cast<cd*>(out6[2]), reinterpret_cast<cd*>(out6[3]), reinterpret_cast<cd*>(out6[4]), reinterpret_cast<cd*>(out6[5]));
+                     (const double*)nullptr, reinterpret_cast<cd*>(out6[2]), reinterpret_cast<cd*>(out6[3]), reinterpret_cast<cd*>(out6[4]), reinterpret_cast<cd*>(out6[5]), 0);
   ANYCHK(e, hipStreamSynchronize(e->stream));
   (void)hipFree(dl); (void)hipFree(dk); (void)hipFree(dv);
   return 0;

@@ -87,7 +87,21 @@ struct YGeom {
   int pitch_s;       // row pitch of the local spectral planes (state, coefficients, filter)
   int S2;            // N = S1 * S2
   int kernel_family; // 1: Kernel family (c2c semantics of the reference), 0: QGModel (rfft semantics)
+  int cmirror;       // 1: the ETDRK4 coefficient planes hold rows l = 0..N/2 only (row N-l is bit-identical: c, the filter and the
+                     //    contour patches depend on l through l^2), indexed through crow(); 0: all N rows
 };
+// Row of a coefficient plane that holds the values of spectral row l.
+__device__ __forceinline__ int crow(const YGeom& g, int l, int N) { return (g.cmirror && l > N / 2) ? N - l : l; }
+// Order in which the B-sub-pass workgroups take the S2 residues l1 = l mod S2: 0, S2/2, then the pairs (m, S2 - m).  The rows of
+// residue S2 - m are the mirrors N - l of the rows of residue m, i.e. the SAME coefficient rows: launched back to back (consecutive
+// blockIdx.y: linear workgroup ids that differ by gridDim.x, a multiple of 8, hence the same XCD and its L2) the second read of a
+// coefficient line is served on chip instead of from HBM.
+__device__ __forceinline__ int pair_order(int y, int S2) {
+  if (S2 < 4) return y;
+  if (y < 2) return y == 0 ? 0 : S2 / 2;
+  const int m = y >> 1;
+  return (y & 1) ? S2 - m : m;
+}
 
 
 // Keeps hipcc from hoisting the next phase's global loads (and interleaving independent FFTs) across a
@@ -1154,24 +1168,25 @@ struct EtdArrays {
   const cd* fc;
 };
 
-__device__ __forceinline__ cd etd_update(const EtdArrays& a, size_t idx, cd Nl, int stage) {
+// idx: element of the state / tendency planes; ci: element of the coefficient planes (crow(): mirrored rows share one)
+__device__ __forceinline__ cd etd_update(const EtdArrays& a, size_t idx, size_t ci, cd Nl, int stage) {
   cd y;
   if (stage == 0) {
-    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], Nl));
+    y = cadd(cmul(a.Eh[ci], a.y_in[idx]), cmul(a.Q[ci], Nl));
     a.fn0[idx] = Nl;
   } else if (stage == 1) {
-    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], Nl));
+    y = cadd(cmul(a.Eh[ci], a.y_in[idx]), cmul(a.Q[ci], Nl));
     a.fna[idx] = Nl;
   } else if (stage == 2) {
     const cd n0 = a.fn0[idx];
     const cd comb = cmake(2.0 * Nl.x - n0.x, 2.0 * Nl.y - n0.y);
-    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], comb));
+    y = cadd(cmul(a.Eh[ci], a.y_in[idx]), cmul(a.Q[ci], comb));
     const cd na = a.fna[idx];
     a.fna[idx] = cadd(na, Nl);
   } else {
     const cd n0 = a.fn0[idx], nab = a.fna[idx];
-    y = cadd(cadd(cmul(a.E[idx], a.y_in[idx]), cmul(a.f0[idx], n0)),
-             cadd(cscale(cmul(a.fab[idx], nab), 2.0), cmul(a.fc[idx], Nl)));
+    y = cadd(cadd(cmul(a.E[ci], a.y_in[idx]), cmul(a.f0[ci], n0)),
+             cadd(cscale(cmul(a.fab[ci], nab), 2.0), cmul(a.fc[ci], Nl)));
   }
   a.y_out[idx] = y;
   return y;
@@ -1179,24 +1194,24 @@ __device__ __forceinline__ cd etd_update(const EtdArrays& a, size_t idx, cd Nl, 
 
 // Same update with an explicit filter factor (coefficient planes WITHOUT the filter folded in); used by the
 // dual-copy q equation where the two copies see different (mirrored) filter planes.
-__device__ __forceinline__ cd etd_update_f(const EtdArrays& a, size_t idx, cd Nl, int stage, double fl) {
+__device__ __forceinline__ cd etd_update_f(const EtdArrays& a, size_t idx, size_t ci, cd Nl, int stage, double fl) {
   cd y;
   if (stage == 0) {
-    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], Nl));
+    y = cadd(cmul(a.Eh[ci], a.y_in[idx]), cmul(a.Q[ci], Nl));
     a.fn0[idx] = Nl;
   } else if (stage == 1) {
-    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], Nl));
+    y = cadd(cmul(a.Eh[ci], a.y_in[idx]), cmul(a.Q[ci], Nl));
     a.fna[idx] = Nl;
   } else if (stage == 2) {
     const cd n0 = a.fn0[idx];
     const cd comb = cmake(2.0 * Nl.x - n0.x, 2.0 * Nl.y - n0.y);
-    y = cadd(cmul(a.Eh[idx], a.y_in[idx]), cmul(a.Q[idx], comb));
+    y = cadd(cmul(a.Eh[ci], a.y_in[idx]), cmul(a.Q[ci], comb));
     const cd na = a.fna[idx];
     a.fna[idx] = cadd(na, Nl);
   } else {
     const cd n0 = a.fn0[idx], nab = a.fna[idx];
-    y = cadd(cadd(cmul(a.E[idx], a.y_in[idx]), cmul(a.f0[idx], n0)),
-             cadd(cscale(cmul(a.fab[idx], nab), 2.0), cmul(a.fc[idx], Nl)));
+    y = cadd(cadd(cmul(a.E[ci], a.y_in[idx]), cmul(a.f0[ci], n0)),
+             cadd(cscale(cmul(a.fab[ci], nab), 2.0), cmul(a.fc[ci], Nl)));
   }
   y = cscale(y, fl);
   a.y_out[idx] = y;
@@ -1222,7 +1237,7 @@ k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __rest
   typedef YPlanT<S1, CLX> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CLX, j = threadIdx.x / CLX;
-  const int k = blockIdx.x * CLX + c, l1 = blockIdx.y;
+  const int k = blockIdx.x * CLX + c, l1 = pair_order(blockIdx.y, g.S2);
   const int kg = g.k0 + k, S2 = g.S2, kernel_family = g.kernel_family;
   const bool ok = k < g.width;
   const int N = S1 * S2;
@@ -1245,7 +1260,7 @@ k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __rest
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int l = l1 + S2 * (j + t * T);
-    const size_t idx = (size_t)l * g.pitch_s + k;
+    const size_t idx = (size_t)l * g.pitch_s + k, ci = (size_t)crow(g, l, N) * g.pitch_s + k;
     const double ly = ll[l];
     const bool pass_row = kernel_family && interior && l == N / 2;      // see DESIGN.md "Nyquist lines"
     if constexpr (!dual) {
@@ -1253,7 +1268,7 @@ k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __rest
       // N_q = -(ik F1 + il F2)
       cd Nl = cmake(kx * f1[t].y + lz * f2[t].y, -(kx * f1[t].x + lz * f2[t].x));
       if (kernel_family && l == 0 && kg == 0) Nl = cmake(0, 0);   // jach[0,0] = 0 (QGModel does not)
-      etd_update(ea, idx, Nl, stage);
+      etd_update(ea, idx, ci, Nl, stage);
     } else {
       const double lm = pass_row ? -ly : ly;
       cd Np = cmake(kx * f1[t].y + ly * f2[t].y, -(kx * f1[t].x + ly * f2[t].x));
@@ -1262,8 +1277,8 @@ k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __rest
         Np = cmake(0, 0);
         Nm = cmake(0, 0);
       }
-      etd_update_f(ea, idx, Np, stage, dq.filt_p[idx]);
-      if (interior) etd_update_f(dq.minus, idx, Nm, stage, dq.filt_m[idx]);
+      etd_update_f(ea, idx, ci, Np, stage, dq.filt_p[idx]);
+      if (interior) etd_update_f(dq.minus, idx, ci, Nm, stage, dq.filt_m[idx]);
     }
   }
   // The passenger (DESIGN.md "Nyquist lines"): on row l = N/2 the il term of N_q is ANTI-Hermitian in the reference's full
@@ -1275,7 +1290,7 @@ k_s_q(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, const double* __rest
     if (ep.y_out != nullptr && kernel_family && interior && l1 == 0 && j == 0) {
       constexpr int tp = P / 2;
       const double ly = ll[N / 2];
-      etd_update(ep, (size_t)k, cmake(ly * f2[tp].y, -ly * f2[tp].x), stage);      // -i l F[v q]
+      etd_update(ep, (size_t)k, (size_t)k, cmake(ly * f2[tp].y, -ly * f2[tp].x), stage);      // -i l F[v q]
     }
   }
 }
@@ -1321,7 +1336,7 @@ k_s_phi(MArr Hw, const cd* __restrict__ jpass, int jpitch, EtdArrays ea, int sta
   typedef YPlanT<S1, CLX> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CLX, j = threadIdx.x / CLX;
-  const int k = blockIdx.x * CLX + c, l1 = blockIdx.y;
+  const int k = blockIdx.x * CLX + c, l1 = pair_order(blockIdx.y, g.S2);
   const int kg = g.k0 + k, S2 = g.S2;
   const int N = S1 * S2;
   const bool bud = bw.part != nullptr;
@@ -1335,7 +1350,7 @@ k_s_phi(MArr Hw, const cd* __restrict__ jpass, int jpitch, EtdArrays ea, int sta
   for (int t = 0; t < P; ++t) a[t] = Hw.ys[(size_t)(l1 * S1 + j + t * T) * Hw.pitch + k];
   // [0,0]: the Jacobian part of the tendency is zeroed there (ref Kernel.py:468) -- add its domain sum back
   double jfix[2] = {0.0, 0.0};
-  if (jpass != nullptr && g.k0 == 0 && blockIdx.x == 0 && blockIdx.y == 0) {   // jpass == null: YBJModel keeps [0,0]
+  if (jpass != nullptr && g.k0 == 0 && blockIdx.x == 0 && l1 == 0) {   // jpass == null: YBJModel keeps [0,0]
     for (int yy = threadIdx.x; yy < N; yy += Y::THREADS) {
       const cd z = jpass[(size_t)yy * jpitch];
       jfix[0] += z.x;
@@ -1362,7 +1377,7 @@ k_s_phi(MArr Hw, const cd* __restrict__ jpass, int jpitch, EtdArrays ea, int sta
     }
     cd Nl = a[t];                                       // N_phi = -J - 0.5 i R
     if (l == 0 && kg == 0) Nl = cmake(Nl.x + jfix[0], Nl.y + jfix[1]);
-    y[t] = etd_update(ea, idx, Nl, stage);
+    y[t] = etd_update(ea, idx, (size_t)crow(g, l, N) * g.pitch_s + k, Nl, stage);
   }
   double s4[4] = {0.0, 0.0, 0.0, 0.0};
   phi_outputs<P, T>(y, a, b, l1, S2, j, kg, invM, kk, ll, bud, s4);
@@ -1436,7 +1451,7 @@ k_s_invert(MArr Ha, MArr Hb, const cd* __restrict__ qh, const double* __restrict
   typedef YPlanT<S1, CLX> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CLX, j = threadIdx.x / CLX;
-  const int k = blockIdx.x * CLX + c, l1 = blockIdx.y;
+  const int k = blockIdx.x * CLX + c, l1 = pair_order(blockIdx.y, g.S2);
   const int kg = g.k0 + k, S2 = g.S2, kernel_family = g.kernel_family;
   const bool ok = k < g.width;
   const int N = S1 * S2;
@@ -1619,15 +1634,15 @@ k_c_qg(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, MArr Hu, MArr Hp, M
     if (ok) {
 #pragma unroll
       for (int t = 0; t < P; ++t) {
-        const size_t idx = (size_t)(j + t * T) * g.pitch_s + k;
+        const size_t idx = (size_t)(j + t * T) * g.pitch_s + k, ci = (size_t)crow(g, j + t * T, N) * g.pitch_s + k;
         if (QB_EARLY && bud_part && q_bud) qb[t] = q_bud[idx];
         o2[t] = ea.y_in[idx];
         if (stage < 3) {
-          o1[t] = ea.Eh[idx];
-          o3[t] = ea.Q[idx];
+          o1[t] = ea.Eh[ci];
+          o3[t] = ea.Q[ci];
         } else {
-          o1[t] = ea.E[idx];
-          o3[t] = ea.f0[idx];
+          o1[t] = ea.E[ci];
+          o3[t] = ea.f0[ci];
         }
         if (stage >= 2) {
           o4[t] = ea.fn0[idx];
@@ -1661,7 +1676,8 @@ k_c_qg(MArr Huq, MArr Hvq, EtdArrays ea, int stage, YGeom g, MArr Hu, MArr Hp, M
           yy = cadd(cmul(o1[t], o2[t]), cmul(o3[t], comb));
           ea.fna[idx] = cadd(o5[t], Nl);
         } else {
-          yy = cadd(cadd(cmul(o1[t], o2[t]), cmul(o3[t], o4[t])), cadd(cscale(cmul(ea.fab[idx], o5[t]), 2.0), cmul(ea.fc[idx], Nl)));
+          const size_t ci = (size_t)crow(g, l, N) * g.pitch_s + k;
+          yy = cadd(cadd(cmul(o1[t], o2[t]), cmul(o3[t], o4[t])), cadd(cscale(cmul(ea.fab[ci], o5[t]), 2.0), cmul(ea.fc[ci], Nl)));
         }
         ea.y_out[idx] = yy;
       }

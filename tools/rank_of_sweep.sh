@@ -29,7 +29,7 @@ except Exception as e:
 PY
     done
   done
-  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_$nx" -o run --output-format csv -- python3 "$ROOT/bench.py" --nx $nx --rank-of 8 --chunks 2 --steps 10 --warmup 2 > "$OUT/prof_$nx.log" 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_$nx" -o run --output-format csv -- python3 "$ROOT/bench.py" --nx $nx --rank-of 8 --rank-only --chunks 2 --steps 10 --warmup 2 > "$OUT/prof_$nx.log" 2>&1 )
   cp "$(find "$OUT/prof_$nx" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_rank_of_8_${nx}_kernel_stats.csv" 2>/dev/null
   rm -rf "$OUT/prof_$nx"
 done

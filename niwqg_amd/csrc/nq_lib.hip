@@ -1415,7 +1415,9 @@ struct XTimer {                                  // optional HIP-event pair arou
   bool on;
   std::vector<hipEvent_t>& ev;
   size_t& used;
-  explicit XTimer(nq_ctx* c_, bool reduce = false) : c(c_), on(c_->xtime), ev(reduce ? c_->rev : c_->xev), used(reduce ? c_->rev_used : c_->xev_used) {
+  hipStream_t xs;
+  explicit XTimer(nq_ctx* c_, bool reduce = false, hipStream_t xs_ = nullptr)
+      : c(c_), on(c_->xtime), ev(reduce ? c_->rev : c_->xev), used(reduce ? c_->rev_used : c_->xev_used), xs(xs_ ? xs_ : c_->mstream) {
     if (!on) return;
     if (used + 2 > ev.size()) {
       // the pool only shrinks in nq_slab_counters(reset): a caller that leaves timing on for a long run() gets the first
@@ -1427,11 +1429,11 @@ struct XTimer {                                  // optional HIP-event pair arou
         ev.push_back(e);
       }
     }
-    (void)hipEventRecord(ev[used], c->mstream);
+    (void)hipEventRecord(ev[used], xs);
   }
   ~XTimer() {
     if (!on) return;
-    (void)hipEventRecord(ev[used + 1], c->mstream);
+    (void)hipEventRecord(ev[used + 1], xs);
     used += 2;
   }
 };
@@ -1439,10 +1441,23 @@ struct XTimer {                                  // optional HIP-event pair arou
 // Chunk i of nch of exchange group g, for every rank of grp.  to_y: x side -> y side (the producers' row kernels recorded
 // ev_prod[i]); else y side -> x side (the column kernels recorded ev_col).  Both buffers of a group are cut into P blocks of
 // Nloc rows; chunk i is the same row range inside every block.
+// An exchange that nothing can run under -- one chunk, and not group 1, whose transfer the q update hides -- gains nothing from the
+// second stream and pays two event hand-offs between the streams (~25-35 us per exchange on one GPU, 0.3-0.4 ms of a 2.2 ms rank
+// step at 4096^2 / P = 8: profiles/r04_rank_of_P_measurements.txt): it is issued on the compute stream itself.
+// NIWQG_AMD_SLAB_INLINE=0 keeps every exchange on the exchange stream.
+static bool inline_exchange(const nq_ctx* c, int g, int nch) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("NIWQG_AMD_SLAB_INLINE");
+    on = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return on && nch == 1 && g != 1 && c->link != LINK_CALLBACK;
+}
 static int issue_chunk(std::vector<nq_ctx*>& grp, int g, bool to_y, int i, int nch) {
   nq_ctx* c0 = grp[0];
   if (c0->G[g].elems == 0) return 0;
   const size_t blk = (size_t)c0->Nloc * c0->G[g].pitch, cblk = blk / nch, off = (size_t)i * cblk;
+  const bool inl = inline_exchange(c0, g, nch);
   for (nq_ctx* c : grp) {
     cd* send = to_y ? c->G[g].bx : c->G[g].by;
     cd* recv = to_y ? c->G[g].by : c->G[g].bx;
@@ -1458,34 +1473,36 @@ static int issue_chunk(std::vector<nq_ctx*>& grp, int g, bool to_y, int i, int n
       }
       continue;
     }
-    HIPCHK(c, hipStreamWaitEvent(c->mstream, mine, 0));
+    const hipStream_t xs = inl ? c->stream : c->mstream;       // the stream this exchange runs on
+    if (!inl) HIPCHK(c, hipStreamWaitEvent(xs, mine, 0));
     {
-      XTimer xt(c);
+      XTimer xt(c, false, xs);
       if (c->link == LINK_PEERS) {
-        for (nq_ctx* s : grp) HIPCHK(c, hipStreamWaitEvent(c->mstream, to_y ? s->ev_prod[i] : s->ev_col, 0));
+        for (nq_ctx* s : grp)
+          if (!(inl && s == c)) HIPCHK(c, hipStreamWaitEvent(xs, to_y ? s->ev_prod[i] : s->ev_col, 0));
         for (nq_ctx* s : grp) {
           const cd* src = (to_y ? s->G[g].bx : s->G[g].by) + (size_t)c->rank * blk + off;
-          HIPCHK(c, hipMemcpyAsync(recv + (size_t)s->rank * blk + off, src, cblk * sizeof(cd), hipMemcpyDeviceToDevice, c->mstream));
+          HIPCHK(c, hipMemcpyAsync(recv + (size_t)s->rank * blk + off, src, cblk * sizeof(cd), hipMemcpyDeviceToDevice, xs));
         }
       } else if (c->link == LINK_NULL) {         // one rank of P measured alone: only its own block crosses (device copy)
-        HIPCHK(c, hipMemcpyAsync(recv + (size_t)c->rank * blk + off, send + (size_t)c->rank * blk + off, cblk * sizeof(cd), hipMemcpyDeviceToDevice, c->mstream));
+        HIPCHK(c, hipMemcpyAsync(recv + (size_t)c->rank * blk + off, send + (size_t)c->rank * blk + off, cblk * sizeof(cd), hipMemcpyDeviceToDevice, xs));
       } else {                                   // RCCL: one grouped send/recv pair per peer, the own block by a device copy
         NCCLCHK(c, g_rccl.GroupStart());
         for (int p = 0; p < c->P; ++p) {
           if (p == c->rank) continue;
-          NCCLCHK(c, g_rccl.Send(send + (size_t)p * blk + off, 2 * cblk, kNcclDouble, p, c->comm, c->mstream));
-          NCCLCHK(c, g_rccl.Recv(recv + (size_t)p * blk + off, 2 * cblk, kNcclDouble, p, c->comm, c->mstream));
+          NCCLCHK(c, g_rccl.Send(send + (size_t)p * blk + off, 2 * cblk, kNcclDouble, p, c->comm, xs));
+          NCCLCHK(c, g_rccl.Recv(recv + (size_t)p * blk + off, 2 * cblk, kNcclDouble, p, c->comm, xs));
         }
         NCCLCHK(c, g_rccl.GroupEnd());
-        HIPCHK(c, hipMemcpyAsync(recv + (size_t)c->rank * blk + off, send + (size_t)c->rank * blk + off, cblk * sizeof(cd), hipMemcpyDeviceToDevice, c->mstream));
+        HIPCHK(c, hipMemcpyAsync(recv + (size_t)c->rank * blk + off, send + (size_t)c->rank * blk + off, cblk * sizeof(cd), hipMemcpyDeviceToDevice, xs));
       }
     }
     c->n_exch += 1;
     if (c->link != LINK_NULL) c->bytes_sent += (double)cblk * 16.0 * (c->P - 1);
     if (to_y) {
-      if (i == nch - 1) HIPCHK(c, hipEventRecord(c->ev_done, c->mstream));
+      if (i == nch - 1) HIPCHK(c, hipEventRecord(c->ev_done, xs));
     } else {
-      HIPCHK(c, hipEventRecord(c->ev_arr[g][i], c->mstream));
+      HIPCHK(c, hipEventRecord(c->ev_arr[g][i], xs));
       c->arr_pending[g] = true;
     }
   }

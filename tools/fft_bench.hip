@@ -142,14 +142,17 @@ void run(const cd* in, cd* out, const cd* tw, const std::vector<double>& twh, in
   CK(hipMalloc(&twx, st.size() * 8 + 16));
   CK(hipMemcpy(twx, st.data(), st.size() * 8, hipMemcpyHostToDevice));
   auto k = k_fft_loop<N, PP, WG, LDS_TW>;
-  CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X::LDS_BYTES));
+  // register twiddles need no table behind the exchange area: 64.5 KB per workgroup, so that TWO 512-thread workgroups fit a CU
+  // (with the table the 8-point plan asks for 84.7 KB and "wg/cu=2" silently runs one per CU: round 4)
+  const size_t lds_bytes = LDS_TW ? X::LDS_BYTES : (size_t)X::F::LDS_ELEMS * sizeof(cd) + 512;
+  CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
-  hipLaunchKernelGGL(k, dim3(nwg), dim3(X::THREADS), X::LDS_BYTES, 0, in, out, tw, twx, 2);
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(X::THREADS), lds_bytes, 0, in, out, tw, twx, 2);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(a));
-  hipLaunchKernelGGL(k, dim3(nwg), dim3(X::THREADS), X::LDS_BYTES, 0, in, out, tw, twx, iters);
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(X::THREADS), lds_bytes, 0, in, out, tw, twx, iters);
   CK(hipEventRecord(b));
   CK(hipEventSynchronize(b));
   float ms;
@@ -157,7 +160,7 @@ void run(const cd* in, cd* out, const cd* tw, const std::vector<double>& twh, in
   // nwg workgroups over 256 CUs: FFTs per CU = nwg/256*iters
   const double us_per_fft_cu = ms * 1e3 / ((double)nwg / 256.0 * iters);
   printf("N=%d P=%2d threads=%4d wg/cu=%d tw=%s lds=%6zu B: %8.3f ms, %.3f us per FFT per CU (%.1f GFLOP/s/CU nominal 5NlogN)\n", N, PP,
-         X::THREADS, WG, LDS_TW ? "lds" : "reg", X::LDS_BYTES, ms, us_per_fft_cu, 5.0 * N * log2((double)N) / us_per_fft_cu * 1e-3);
+         X::THREADS, WG, LDS_TW ? "lds" : "reg", lds_bytes, ms, us_per_fft_cu, 5.0 * N * log2((double)N) / us_per_fft_cu * 1e-3);
   CK(hipFree(twx));
 }
 

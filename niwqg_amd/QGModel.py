@@ -24,7 +24,7 @@ class Model(object):
             from . import _anysize
             if not _anysize.supported(nx):
                 raise RuntimeError("nx = %r: the fused kernels take powers of two in [64, 8192], the any-size path even nx in "
-                                   "[4, %d]" % (nx, _anysize.NX_MAX))
+                                   "[4, %d] and 16384" % (nx, _anysize.NX_MAX))
             cls = _anysize.specialise(cls, _anysize.QGFamily)
         return object.__new__(cls)
 

@@ -1,7 +1,7 @@
 """Grids without a fused plan: the reference's own sequence of whole-plane operations, on the device.
 
 The reference takes any ``nx`` (ref: niwqg/Kernel.py:100-103, numpy.fft transforms any length, :562-566; QGModel.py:93-96,
-:551-552).  The fused ETDRK4 kernels exist for powers of two in [64, 8192].  For every other EVEN ``nx`` in [4, 4096] the model
+:551-552).  The fused ETDRK4 kernels exist for powers of two in [64, 8192].  For every other EVEN ``nx`` in [4, 8192], and for 16384, the model
 classes are specialised with the mix-ins below (``Kernel.Kernel.__new__`` / ``QGModel.Model.__new__`` pick them): state and
 constants live on the device as ``Plane`` objects and every operation of the reference's time step -- whole-plane transforms of
 any length (Bluestein on the power-of-two row engine), products, the ETDRK4 updates, domain means -- is one call into the
@@ -23,12 +23,13 @@ from . import _etdrk4, _lib
  EW_MULADD) = range(12)
 RD_SUM, RD_SUMABS2, RD_DOT, RD_DOTC, RD_MAXABS, RD_WSUMABS2, RD_MAXABSRE = range(7)
 
-NX_MAX = 4096
+NX_MAX = 8192
 
 
 def supported(nx):
-    """even grid sizes the any-size engine takes (the Bluestein work rows are 2 nx - 1 rounded up to a power of two <= 8192)"""
-    return isinstance(nx, (int, np.integer)) and 4 <= nx <= NX_MAX and nx % 2 == 0
+    """even grid sizes the any-size engine takes: every even nx up to 8192 (Bluestein work rows of 2 nx - 1 points rounded up to a
+    power of two <= 16384, the longest as a four-step 128 x 128 transform) and 16384 itself (four-step, no chirp)"""
+    return isinstance(nx, (int, np.integer)) and nx % 2 == 0 and (4 <= nx <= NX_MAX or nx == 16384)
 
 
 class Engine(object):

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) k_any_lines(cd* __restrict__ plane, cd* _
         if (j < n) {
           v = plane[(size_t)line * cols + j];
           if (conj_io) v = cconj(v);
-          v = cmul(v, chirp[j]);
+          if (chirp) v = cmul(v, chirp[j]);
         }
         tmp[(size_t)line * M + j] = v;
       }
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) k_any_lines(cd* __restrict__ plane, cd* _
       if (line < nlines && j < n) {
         v = plane[(size_t)j * cols + line];
         if (conj_io) v = cconj(v);
-        v = cmul(v, chirp[j]);
+        if (chirp) v = cmul(v, chirp[j]);
       }
       tile[ty][tx] = v;
       __syncthreads();
@@ -139,14 +139,20 @@ __global__ void __launch_bounds__(256) k_any_lines(cd* __restrict__ plane, cd* _
     if (axis == 1) {
       const int line = l0 + ty, j = j0 + tx;
       if (line < nlines && j < n) {
-        cd v = cscale(cmul(tmp[(size_t)line * M + j], chirp[j]), scale);
+        cd v = tmp[(size_t)line * M + j];
+        if (chirp) v = cmul(v, chirp[j]);
+        v = cscale(v, scale);
         if (conj_io) v = cconj(v);
         plane[(size_t)line * cols + j] = v;
       }
     } else {
       const int ji = j0 + tx, li = l0 + ty;
       cd v = cmake(0, 0);
-      if (li < nlines && ji < n) v = cscale(cmul(tmp[(size_t)li * M + ji], chirp[ji]), scale);
+      if (li < nlines && ji < n) {
+        v = tmp[(size_t)li * M + ji];
+        if (chirp) v = cmul(v, chirp[ji]);
+        v = cscale(v, scale);
+      }
       tile[ty][tx] = v;
       __syncthreads();
       const int j = j0 + ty, line = l0 + tx;
@@ -189,6 +195,33 @@ __global__ void k_any_take_cols(const cd* __restrict__ src, cd* __restrict__ dst
 }
 __global__ void k_any_set_elem(cd* p, size_t idx, double re, double im) { p[idx] = cmake(re, im); }
 
+// Work rows longer than the row engine's longest plan (M = 16384 = 128 x 128): the four-step transform on the rows of tmp, every
+// step a batched [R][C] -> [C][R] transpose per line through LDS (16 x 16 tiles) or a pass of the 128-point row engine:
+//   x[a + A b]  --transpose-->  [a][b]  --FFT_B over b-->  Y[a][kb]  --x w_M^(a kb), transpose-->  [kb][a]  --FFT_A over a-->  Z[kb][ka]
+//   --transpose-->  X[kb + B ka]
+// tw: exp(-2 pi i m / M), m < M (a kb < M for a < A, kb < B); inv conjugates it.
+__global__ void __launch_bounds__(256) k_any_btranspose(const cd* __restrict__ src, cd* __restrict__ dst, int R, int C,
+                                                        const cd* __restrict__ tw, int use_tw, int inv) {
+  __shared__ cd tile[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
+  const size_t base = (size_t)blockIdx.z * R * C;
+  const int r = r0 + ty, c = c0 + tx;
+  cd v = cmake(0, 0);
+  if (r < R && c < C) {
+    v = src[base + (size_t)r * C + c];
+    if (use_tw) {
+      cd w = tw[r * c];
+      if (inv) w.y = -w.y;
+      v = cmul(v, w);
+    }
+  }
+  tile[ty][tx] = v;
+  __syncthreads();
+  const int ro = r0 + tx, co = c0 + ty;
+  if (ro < R && co < C) dst[base + (size_t)co * R + ro] = tile[tx][ty];
+}
+
 }  // namespace nq
 
 struct nq_any {
@@ -200,11 +233,13 @@ struct nq_any {
   // Bluestein plans by transform length n
   struct Plan {
     int n = 0, M = 0;
+    bool direct = false;                 // n itself is a power of two the row engine (or its four-step form) takes: no chirp
     nq::cd *chirp = nullptr, *bhat = nullptr, *tw = nullptr;
+    nq::cd* tw_small = nullptr;          // M = 16384: the twiddles of the 128-point passes of the four-step transform
   };
   std::vector<Plan> plans;
-  nq::cd* tmp = nullptr;
-  size_t tmp_elems = 0;
+  nq::cd *tmp = nullptr, *tmp2 = nullptr;      // work rows [line][M]; tmp2 only for the four-step transform
+  size_t tmp_elems = 0, tmp2_elems = 0;
   double *part = nullptr, *red = nullptr;
   double* red_host = nullptr;
 };

@@ -3696,6 +3696,23 @@ long long nq_field_doubles(const nq_ctx* c, int id) {
 
 template <bool INV>
 static int any_rows_fft(nq_any* e, const nq_any::Plan& pl, int nlines, double scale) {
+  if (pl.M == 16384) {
+    // four-step transform of rows of 128 x 128 points (csrc/nq_anysize.hpp: k_any_btranspose); result back in e->tmp
+    const int A = 128, B = 128;
+    typedef XPlan<128> X;
+    const dim3 tg(A / 16, B / 16, nlines), tb(256);
+    const int rows128 = nlines * 128;
+    hipLaunchKernelGGL(k_any_btranspose, tg, tb, 0, e->stream, (const cd*)e->tmp, e->tmp2, B, A, (const cd*)nullptr, 0, 0);
+    hipLaunchKernelGGL((k_x_c2c<128, INV>), dim3((rows128 + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, e->stream, (const cd*)e->tmp2, e->tmp2, 128, 128,
+                       rows128, 1.0, (const cd*)pl.tw_small, (const double*)nullptr, 0);
+    hipLaunchKernelGGL(k_any_btranspose, tg, tb, 0, e->stream, (const cd*)e->tmp2, e->tmp, A, B, (const cd*)pl.tw, 1, INV ? 1 : 0);
+    hipLaunchKernelGGL((k_x_c2c<128, INV>), dim3((rows128 + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, e->stream, (const cd*)e->tmp, e->tmp, 128, 128,
+                       rows128, scale, (const cd*)pl.tw_small, (const double*)nullptr, 0);
+    hipLaunchKernelGGL(k_any_btranspose, tg, tb, 0, e->stream, (const cd*)e->tmp, e->tmp2, B, A, (const cd*)nullptr, 0, 0);
+    std::swap(e->tmp, e->tmp2);
+    std::swap(e->tmp_elems, e->tmp2_elems);
+    return 0;
+  }
   switch (pl.M) {
 #define CASE_(n, a, b) case n: { typedef XPlan<n> X; \
       hipLaunchKernelGGL((k_x_c2c<n, INV>), dim3((nlines + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, e->stream, \
@@ -3706,61 +3723,83 @@ static int any_rows_fft(nq_any* e, const nq_any::Plan& pl, int nlines, double sc
   }
   return 0;
 }
-static int any_tmp(nq_any* e, size_t elems) {
-  if (e->tmp_elems >= elems) return 0;
-  if (e->tmp) {
+static int any_buf(nq_any* e, cd** buf, size_t* have, size_t elems) {
+  if (*have >= elems) return 0;
+  if (*buf) {
     ANYCHK(e, hipStreamSynchronize(e->stream));
-    ANYCHK(e, hipFree(e->tmp));
-    e->tmp = nullptr;
-    e->tmp_elems = 0;
+    ANYCHK(e, hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
   }
-  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&e->tmp), elems * sizeof(cd)));
-  e->tmp_elems = elems;
+  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(buf), elems * sizeof(cd)));
+  *have = elems;
   return 0;
+}
+static int any_tmp(nq_any* e, size_t elems, bool four_step = false) {
+  int rc = any_buf(e, &e->tmp, &e->tmp_elems, elems);
+  if (rc == 0 && four_step) rc = any_buf(e, &e->tmp2, &e->tmp2_elems, elems);
+  return rc;
 }
 // Bluestein plan for transforms of length n: chirp w[j] = exp(-i pi j^2 / n) (angle reduced exactly: j^2 mod 2n), the transform of
 // conj(w) laid out circularly on M >= 2n - 1 points, and the twiddle table of the M-point row engine
 static int any_plan(nq_any* e, int n, const nq_any::Plan** out) {
   for (const nq_any::Plan& p : e->plans)
     if (p.n == n) { *out = &p; return 0; }
-  if (n < 2 || n > 4096) ANYFAIL(e, -2, "any-size engine: transform length %d outside [2, 4096]", n);
+  const bool pow2 = n >= 64 && (n & (n - 1)) == 0;
+  if (n < 2 || (pow2 ? n > 16384 : n > 8192)) ANYFAIL(e, -2, "any-size engine: transform length %d (any n in [2, 8192], or 16384)", n);
   nq_any::Plan pl;
   pl.n = n;
+  pl.direct = pow2;
   pl.M = 64;
-  while (pl.M < 2 * n - 1) pl.M *= 2;
+  if (pow2) pl.M = n;
+  else
+    while (pl.M < 2 * n - 1) pl.M *= 2;
   const int M = pl.M;
-  std::vector<double> w(2 * (size_t)n), b(2 * (size_t)M, 0.0), tw(2 * (size_t)M);
   const long double pi = 3.14159265358979323846264338327950288L;
-  for (int j = 0; j < n; ++j) {
-    const long long r = ((long long)j * j) % (2LL * n);
-    const long double a = pi * (long double)r / (long double)n;
-    w[2 * j] = (double)cosl(a);
-    w[2 * j + 1] = (double)(-sinl(a));
-    // conj(w[j]) at +j and -j (circular)
-    b[2 * j] = (double)cosl(a);
-    b[2 * j + 1] = (double)sinl(a);
-    if (j > 0) {
-      b[2 * (size_t)(M - j)] = (double)cosl(a);
-      b[2 * (size_t)(M - j) + 1] = (double)sinl(a);
-    }
-  }
+  std::vector<double> tw(2 * (size_t)M);
   for (int m = 0; m < M; ++m) {
     const long double a = -2.0L * pi * (long double)m / (long double)M;
     tw[2 * m] = (double)cosl(a);
     tw[2 * m + 1] = (double)sinl(a);
   }
-  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.chirp), sizeof(cd) * n));
-  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.bhat), sizeof(cd) * M));
   ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.tw), sizeof(cd) * M));
-  ANYCHK(e, hipMemcpy(pl.chirp, w.data(), sizeof(cd) * n, hipMemcpyHostToDevice));
   ANYCHK(e, hipMemcpy(pl.tw, tw.data(), sizeof(cd) * M, hipMemcpyHostToDevice));
-  int rc = any_tmp(e, (size_t)M);
-  if (rc) return rc;
-  ANYCHK(e, hipMemcpy(e->tmp, b.data(), sizeof(cd) * M, hipMemcpyHostToDevice));
-  rc = any_rows_fft<false>(e, pl, 1, 1.0);
-  if (rc) return rc;
-  ANYCHK(e, hipMemcpyAsync(pl.bhat, e->tmp, sizeof(cd) * M, hipMemcpyDeviceToDevice, e->stream));
-  ANYCHK(e, hipStreamSynchronize(e->stream));
+  if (M == 16384) {
+    std::vector<double> ts(2 * 128);
+    for (int m = 0; m < 128; ++m) {
+      const long double a = -2.0L * pi * (long double)m / 128.0L;
+      ts[2 * m] = (double)cosl(a);
+      ts[2 * m + 1] = (double)sinl(a);
+    }
+    ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.tw_small), sizeof(cd) * 128));
+    ANYCHK(e, hipMemcpy(pl.tw_small, ts.data(), sizeof(cd) * 128, hipMemcpyHostToDevice));
+  }
+  if (!pl.direct) {
+    std::vector<double> w(2 * (size_t)n), b(2 * (size_t)M, 0.0);
+    for (int j = 0; j < n; ++j) {
+      const long long r = ((long long)j * j) % (2LL * n);
+      const long double a = pi * (long double)r / (long double)n;
+      w[2 * j] = (double)cosl(a);
+      w[2 * j + 1] = (double)(-sinl(a));
+      // conj(w[j]) at +j and -j (circular)
+      b[2 * j] = (double)cosl(a);
+      b[2 * j + 1] = (double)sinl(a);
+      if (j > 0) {
+        b[2 * (size_t)(M - j)] = (double)cosl(a);
+        b[2 * (size_t)(M - j) + 1] = (double)sinl(a);
+      }
+    }
+    ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.chirp), sizeof(cd) * n));
+    ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.bhat), sizeof(cd) * M));
+    ANYCHK(e, hipMemcpy(pl.chirp, w.data(), sizeof(cd) * n, hipMemcpyHostToDevice));
+    int rc = any_tmp(e, (size_t)M, M == 16384);
+    if (rc) return rc;
+    ANYCHK(e, hipMemcpy(e->tmp, b.data(), sizeof(cd) * M, hipMemcpyHostToDevice));
+    rc = any_rows_fft<false>(e, pl, 1, 1.0);
+    if (rc) return rc;
+    ANYCHK(e, hipMemcpyAsync(pl.bhat, e->tmp, sizeof(cd) * M, hipMemcpyDeviceToDevice, e->stream));
+    ANYCHK(e, hipStreamSynchronize(e->stream));
+  }
   e->plans.push_back(pl);
   *out = &e->plans.back();
   return 0;
@@ -3791,8 +3830,14 @@ int nq_any_destroy(nq_any* e) {
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
   for (void* p : e->allocs) (void)hipFree(p);
-  for (nq_any::Plan& p : e->plans) { (void)hipFree(p.chirp); (void)hipFree(p.bhat); (void)hipFree(p.tw); }
+  for (nq_any::Plan& p : e->plans) {
+    if (p.chirp) (void)hipFree(p.chirp);
+    if (p.bhat) (void)hipFree(p.bhat);
+    if (p.tw_small) (void)hipFree(p.tw_small);
+    (void)hipFree(p.tw);
+  }
   if (e->tmp) (void)hipFree(e->tmp);
+  if (e->tmp2) (void)hipFree(e->tmp2);
   (void)hipFree(e->part);
   (void)hipFree(e->red);
   (void)hipStreamDestroy(e->stream);
@@ -3806,7 +3851,7 @@ int nq_any_sync(nq_any* e) {
   ANYCHK(e, hipGetLastError());
   return 0;
 }
-long long nq_any_device_bytes(const nq_any* e) { return e ? e->bytes + (long long)(e->tmp_elems * sizeof(cd)) : 0; }
+long long nq_any_device_bytes(const nq_any* e) { return e ? e->bytes + (long long)((e->tmp_elems + e->tmp2_elems) * sizeof(cd)) : 0; }
 int nq_any_alloc(nq_any* e, long long elems, void** plane) {
   if (!e || !plane || elems <= 0) return -1;
   ANYCHK(e, hipSetDevice(e->device));
@@ -3849,10 +3894,19 @@ int nq_any_fft(nq_any* e, void* dst, const void* src, int rows, int cols, int ax
   const nq_any::Plan* pl = nullptr;
   int rc = any_plan(e, n, &pl);
   if (rc) return rc;
-  rc = any_tmp(e, (size_t)nlines * pl->M);
+  rc = any_tmp(e, (size_t)nlines * pl->M, pl->M == 16384);
   if (rc) return rc;
   const dim3 gp((pl->M + 15) / 16, (nlines + 15) / 16), gu((n + 15) / 16, (nlines + 15) / 16);
-  hipLaunchKernelGGL((k_any_lines<true>), gp, dim3(256), 0, e->stream, reinterpret_cast<cd*>(const_cast<void*>(src)), e->tmp, rows, cols, axis, pl->M,
+  cd* srcp = reinterpret_cast<cd*>(const_cast<void*>(src));
+  if (pl->direct) {          // a power of two the row engine takes (four-step for 16384): no chirp, the inverse by its own kernel
+    hipLaunchKernelGGL((k_any_lines<true>), gp, dim3(256), 0, e->stream, srcp, e->tmp, rows, cols, axis, pl->M, (const cd*)nullptr, 0, 1.0);
+    rc = inverse ? any_rows_fft<true>(e, *pl, nlines, 1.0 / (double)n) : any_rows_fft<false>(e, *pl, nlines, 1.0);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_any_lines<false>), gu, dim3(256), 0, e->stream, reinterpret_cast<cd*>(dst), e->tmp, rows, cols, axis, pl->M, (const cd*)nullptr, 0, 1.0);
+    ANYCHK(e, hipGetLastError());
+    return 0;
+  }
+  hipLaunchKernelGGL((k_any_lines<true>), gp, dim3(256), 0, e->stream, srcp, e->tmp, rows, cols, axis, pl->M,
                      (const cd*)pl->chirp, inverse ? 1 : 0, 1.0);
   rc = any_rows_fft<false>(e, *pl, nlines, 1.0);
   if (rc) return rc;

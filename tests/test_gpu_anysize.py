@@ -115,9 +115,57 @@ def test_the_references_own_assertions_on_a_96_grid():
     assert np.allclose(m.qh, m.fft(qi) * np.exp(-m.nu4 * m.wv4 * m.tmax), rtol=1e-12, atol=1e-12 * nx * nx)
 
 
+BIG = bool(__import__("os").environ.get("NQ_ANYSIZE_BIG"))       # the 16384^2 cases: two minutes and 30 GB of host memory (round-4 log in profiles/)
+
+
+@pytest.mark.parametrize("nx", [5000, 6144] + ([16384] if BIG else []))
+def test_fft_seam_with_four_step_work_rows_against_pocketfft(nx):
+    """Transform lengths whose work rows are 16384 points long -- Bluestein for 4096 < n <= 8192 (5000 = 2^3 5^4, 6144 = 3 2^11) and
+    16384 itself without a chirp -- run as a four-step 128 x 128 transform on the 128-point row engine (csrc/nq_anysize.hpp)."""
+    import scipy.fft
+    import os
+    nw = max(1, min(16, (os.cpu_count() or 2) - 1))
+    rng = np.random.default_rng(nx)
+    m = models().QGModel.Model(nx=nx)
+    assert getattr(m, "_any_size", False)
+    r = rng.standard_normal((nx, nx))
+    h = m.fft(r)
+    ref = scipy.fft.rfft2(r, workers=nw)
+    e1 = rel(h, ref)
+    e2 = rel(m.ifft(ref), r)
+    print("nx %d: rfft2 %.1e  irfft2 %.1e" % (nx, e1, e2))
+    assert max(e1, e2) < 5e-15
+
+
+@pytest.mark.skipif(not BIG, reason="NQ_ANYSIZE_BIG=1 runs the 16384^2 cases")
+def test_qgmodel_16384_through_resolution_independence():
+    """QGModel at 16384^2 on the any-size path (the reference cannot construct this size; a fused plan does not exist): a
+    band-limited state stepped 5 times with the size's own dt and hyperviscosity against the reference-pinned oracle at 128^2
+    with the same coefficients -- the pseudo-spectral step is exact at any resolution that holds the band."""
+    nx, nsteps = 16384, 5
+    kw = dict(L=L, nx=128, tmax=1e30, dt=0.05 * TE * 128 / nx, twrite=10 ** 9, tdiags=10 ** 9, use_filter=True, U=-U0,
+              nu4=5e11 * (128.0 / nx) ** 4, nu=20.0, mu=1e-8, beta=2e-11)
+    o = O.QGOracle(**kw)
+    q0, _ = T._random_band_limited_state(o.grid.x, o.grid.y, 777, False)
+    o.set_q(q0)
+    for _ in range(nsteps):
+        o._step_forward()
+    m = models().QGModel.Model(**dict(kw, nx=nx))
+    q1, _ = T._random_band_limited_state(m.x, m.y, 777, False)
+    m.set_q(q1)
+    del q1
+    T.steps(m, nsteps)
+    ref = T._low_modes_half(o.qh, o.kk, o.ll, o.grid.x.ravel()[0], o.grid.y.ravel()[0], 128)
+    got = T._low_modes_half(m.qh, np.asarray(m.kk).ravel(), np.asarray(m.ll).ravel(), m.x.ravel()[0], m.y.ravel()[0], nx)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    print("QGModel 16384^2, %d steps, low modes against the oracle: %.1e" % (nsteps, err))
+    assert err < 1e-10
+    assert abs(m.Ke - o.Ke) <= 1e-9 * abs(o.Ke)
+
+
 def test_grids_nobody_can_run_fail_loudly():
     M = models()
-    for nx in (97, 5, 16384, 4098, 2):
+    for nx in (97, 5, 8194, 32768, 2):
         with pytest.raises(RuntimeError):
             M.CoupledModel.Model(nx=nx)
         with pytest.raises(RuntimeError):

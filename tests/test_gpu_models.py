@@ -301,7 +301,7 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(RuntimeError):
         models().CoupledModel.Model(nx=97)          # (even grids without a fused plan run on the any-size path: test_gpu_anysize.py)
     with pytest.raises(RuntimeError):
-        models().CoupledModel.Model(nx=16384)
+        models().CoupledModel.Model(nx=32768)
 
 
 # ---- larger sizes ------------------------------------------------------------------------------------
@@ -766,7 +766,7 @@ def test_malformed_and_degenerate_inputs(slab):
     with pytest.raises(ValueError):
         q.ifft(np.zeros((64, 64), complex))         # irfft2 takes the (ny, nx/2+1) half spectrum
     if not slab:
-        for nx in (97, 33, 16384):               # (even grids without a fused plan run on the any-size path since round 4)
+        for nx in (97, 33, 32768):               # (even grids without a fused plan run on the any-size path since round 4)
             with pytest.raises(RuntimeError):
                 M.CoupledModel.Model(**notebook_kwargs(nx, True))
         a = M.CoupledModel.Model(**notebook_kwargs(96, True))

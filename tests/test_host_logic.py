@@ -293,3 +293,34 @@ def test_constructor_signatures_are_the_references():
         got = [(k, v.default) for k, v in inspect.signature(cls.__init__).parameters.items() if k != "self"]
         assert got[:len(want)] == want, cls
         assert set(k for k, _ in got[len(want):]) <= {"device", "budgets", "exact_qh", "slab", "nchunks"}, got[len(want):]
+
+
+def test_any_size_path_host_logic(built):
+    """Grids without a fused plan (niwqg_amd/_anysize.py): which sizes it takes, the loud refusals (before any device is touched),
+    the class specialisation (same name and module, isinstance against the public class holds), and the op / reduction codes of the
+    ctypes layer against the header."""
+    import niwqg_amd
+    from niwqg_amd import _anysize, _lib
+    assert all(_lib.has_fused_plan(n) for n in (64, 128, 4096, 8192)) and not any(_lib.has_fused_plan(n) for n in (32, 96, 16384))
+    assert all(_anysize.supported(n) for n in (4, 6, 16, 32, 96, 100, 1000, 3072, 4098, 5000, 6144, 8190, 16384))
+    assert not any(_anysize.supported(n) for n in (2, 3, 97, 8194, 12288, 32768, 96.0))
+    for nx in (97, 2, 8194, 32768):
+        with pytest.raises(RuntimeError, match="any-size"):
+            niwqg_amd.CoupledModel.Model(nx=nx)
+        with pytest.raises(RuntimeError, match="any-size"):
+            niwqg_amd.QGModel.Model(nx=nx)
+    for pub, mix in ((niwqg_amd.CoupledModel.Model, _anysize.KernelFamily), (niwqg_amd.YBJModel.Model, _anysize.KernelFamily),
+                     (niwqg_amd.QGModel.Model, _anysize.QGFamily)):
+        cls = _anysize.specialise(pub, mix)
+        assert cls is _anysize.specialise(pub, mix) and issubclass(cls, pub) and issubclass(cls, mix)
+        assert cls.__name__ == pub.__name__ and cls.__module__ == pub.__module__ and cls.__mro__[1] is mix
+    header = open(os.path.join(ROOT, "include", "niwqg_amd.h")).read()
+    ids = {name: int(val) for name, val in re.findall(r"\b(NQ_[A-Z0-9_]+)\s*=\s*(\d+)", header)}
+    for name in ("COPY", "MUL", "MULCONJ", "AXPBY", "AXPBYPCZ", "REAL", "ABS2", "SCALE", "CONJ", "ADDS", "IMAG", "MULADD"):
+        assert ids["NQ_EW_" + name] == getattr(_anysize, "EW_" + name), name
+    for name in ("SUM", "SUMABS2", "DOT", "DOTC", "MAXABS", "WSUMABS2", "MAXABSRE"):
+        assert ids["NQ_RD_" + name] == getattr(_anysize, "RD_" + name), name
+    assert ids["NQ_S_MAX_PHI"] == _lib.S_MAX_PHI
+    src = open(os.path.join(ROOT, "niwqg_amd", "csrc", "nq_anysize.hpp")).read()
+    for name, val in re.findall(r"\b(EW_[A-Z0-9]+|RD_[A-Z0-9]+) = (\d+)", src):
+        assert ids["NQ_" + name] == int(val), name

@@ -345,6 +345,42 @@ def bench_ensemble(args, grp, rank, world, local_rank):
     grp.close()
 
 
+def bench_any_size(args, m, grp, rank, world):
+    """Grids without a fused plan (niwqg_amd/_anysize.py: the reference's whole-plane sequence on the device, Bluestein / four-step
+    transforms): wall-clock steps/s of `_step_etdrk4`, the whole step against the canonical bytes.  No per-kernel table: a step is
+    hundreds to thousands of small library calls."""
+    import torch
+    from niwqg_amd.distributed import aggregate_throughput
+    for _ in range(max(1, min(args.warmup, 3))):
+        m._step_etdrk4()
+    m._ctx.sync()
+    grp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m._step_etdrk4()
+    m._ctx.sync()
+    grp.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    sps, wall = aggregate_throughput(grp, args.steps, wall)
+    if rank == 0:
+        npts = float(args.nx) ** 2
+        step_bytes = CANONICAL_B_PER_PT_STEP[args.model] * npts
+        gbs = step_bytes * sps / world / 1e9
+        print(json.dumps({
+            "metric": "time-steps/sec, %sModel %d^2 fp64, ANY-SIZE path (no fused plan for this grid)" % (
+                {"coupled": "Coupled", "uncoupled": "UnCoupled", "qg": "QG", "ybj": "YBJ"}[args.model], args.nx),
+            "value": sps, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%sModel %d^2 fp64, ETDRK4, the reference's whole-plane sequence on the device" % (args.model, args.nx),
+                       "parallelism": "single GPU" if world == 1 else "replicas x%d" % world, "device_bytes": m._ctx.device_bytes()},
+            "roofline": {"bound": "hbm", "kernel": "whole step (canonical bytes of SURVEY 8d)", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None}}))
+    grp.close()
+
+
 def _lib_copy(ctx):
     """nq_stream_copy_gbs on a context view that does not wrap it (a slab rank)"""
     import ctypes
@@ -466,6 +502,8 @@ def main():
         ctx = m._ctx
         if world > 1:
             mode = "replicas x%d (one full problem per GPU)" % world
+        if getattr(m, "_any_size", False):
+            return bench_any_size(args, m, grp, rank, world)
 
     def advance(n):
         if sim is not None:

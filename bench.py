@@ -173,12 +173,14 @@ class _SlabCtxView(object):
             setattr(self, name, getattr(_lib.Context, name).__get__(self))
 
 
-def build_slab(model, nx, grp, local_rank, nchunks=2, kind=None, rank_of=0):
+def build_slab(model, nx, grp, local_rank, nchunks=2, kind=None, rank_of=0, peers=0):
     """One slab-decomposed simulation over all ranks of `grp` (niwqg_amd.slab).  Two stages so that the ranks can agree
     that every one of them got its memory BEFORE the first collective: allocate() then initialise().
     rank_of = P > 0: rank 0 of a P-rank decomposition ALONE on this GPU, with the library's null link (nq_slab_set_null_link):
-    every launch, stream, event and row chunk of a real rank, nothing on the wire -- the compute term of DESIGN.md section 9."""
-    nranks, myrank = (rank_of, 0) if rank_of else (grp.world, grp.rank)
+    every launch, stream, event and row chunk of a real rank, nothing on the wire -- the compute term of DESIGN.md section 9.
+    peers = P > 1: ALL P ranks in this one process, rank r on device r (modulo the devices there are): the blocks cross by peer
+    copies over xGMI (SDMA, no CUs) instead of RCCL's send/recv kernels -- the A/B for the first real multi-GPU run."""
+    nranks, myrank = (rank_of, 0) if rank_of else ((peers, None) if peers else (grp.world, grp.rank))
     from niwqg_amd import _lib, slab
     kw = c3_kwargs(nx, model)
     dk = 2 * np.pi / L
@@ -200,32 +202,42 @@ def build_slab(model, nx, grp, local_rank, nchunks=2, kind=None, rank_of=0):
         phys.update(f=kw["f"], kappa2=kappa2, nuw=kw["nuw"], nu4w=kw["nu4w"], muw=kw["muw"])
 
     def allocate():
-        ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], nranks, device=local_rank, only_rank=myrank,
-                                budgets=budgets, torch_buffers=not rank_of, **phys)
+        dev = local_rank
+        if peers:
+            import torch
+            ndev = max(torch.cuda.device_count(), 1)
+            dev = [r % ndev for r in range(peers)]
+        ranks = slab.make_ranks(mid, nx, kk, ll, filtr, kw["dt"], nranks, device=dev, only_rank=myrank,
+                                budgets=budgets, torch_buffers=not (rank_of or peers), **phys)
         return ranks
 
     def initialise(ranks):
         # RCCL issued by the library itself (grouped send/recv per row chunk); with gloo the library calls back into
         # Python at every exchange
-        sim = slab.SlabSimulation(ranks, "null", nchunks=nchunks) if rank_of else slab.connect(ranks, grp.dist, nchunks)
+        if rank_of:
+            sim = slab.SlabSimulation(ranks, "null", nchunks=nchunks)
+        elif peers:
+            sim = slab.SlabSimulation(ranks, "peers", nchunks=nchunks)
+        else:
+            sim = slab.connect(ranks, grp.dist, nchunks)
 
-        nloc, r0 = ranks[0].nloc, ranks[0].rank * ranks[0].nloc
+        nloc = ranks[0].nloc
         cell = (np.arange(nx) + 0.5) / nx * L
+        noise = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx)) if (model == "qg" and nx == 2048) else None
 
-        class Rows(object):       # what SlabSimulation.set_q indexes: global row range -> the local rows
-            def __init__(self, a):
-                self.a = a
+        class Rows(object):       # what SlabSimulation.set_q indexes: a global row range -> those rows, formed on demand
+            def __init__(self, make):
+                self.make = make
 
             def __getitem__(self, sl):
-                assert sl.start == r0 and sl.stop == r0 + nloc
-                return self.a
-        if model == "qg" and nx == 2048:                         # BASELINE config 2: seeded white noise, row by row
-            q = 1e-5 * np.random.default_rng(0).standard_normal((nx, nx))[r0:r0 + nloc]
+                assert (sl.stop - sl.start) == nloc and sl.start % nloc == 0
+                return self.make(sl.start, sl.stop)
+        if noise is not None:                                    # BASELINE config 2: seeded white noise, row by row
+            sim.set_q(Rows(lambda a, b: noise[a:b]))
         else:
-            q = lamb_dipole_rows(cell, cell[r0:r0 + nloc], nx)
-        sim.set_q(Rows(q))
+            sim.set_q(Rows(lambda a, b: lamb_dipole_rows(cell, cell[a:b], nx)))
         if model != "qg":
-            sim.set_phi(Rows((np.ones((nloc, nx)) + 1j) * (2 * U0) / np.sqrt(2)))
+            sim.set_phi(Rows(lambda a, b: (np.ones((b - a, nx)) + 1j) * (2 * U0) / np.sqrt(2)))
         sim.sync()
         return sim, _SlabCtxView(ranks[0])
 
@@ -428,6 +440,9 @@ def main():
     ap.add_argument("--rank-of", type=int, default=0, help="measure ONE rank of a P-rank slab decomposition alone on this GPU "
                     "(P = 2, 4, 8; no exchange, nq_slab_set_null_link): the per-rank compute term of the strong-scaling "
                     "arithmetic, next to the single-GPU step of the same run")
+    ap.add_argument("--link", default="rccl", choices=["rccl", "peers"], help="with --gpus N > 1: 'rccl' = one process per GPU, grouped "
+                    "ncclSend/ncclRecv issued by the library (the driver's launch); 'peers' = ONE process, rank r on device r, the "
+                    "blocks cross by peer copies (SDMA over xGMI, no CUs): no torchrun, no RCCL")
     ap.add_argument("--rank-only", action="store_true", help="with --rank-of: skip the single-GPU step of the same run (so that a "
                     "kernel trace of the run holds the slab instantiations only)")
     ap.add_argument("--replicas", action="store_true", help="with --gpus N > 1: N independent replicas instead of one "
@@ -435,7 +450,10 @@ def main():
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
-    if env_world is None and args.gpus > 1:
+    peers_n = args.gpus if (args.link == "peers" and args.gpus > 1) else 0
+    if peers_n and env_world is not None:
+        sys.exit("bench.py: --link peers runs all ranks in ONE process: start it without a launcher")
+    if env_world is None and args.gpus > 1 and not peers_n:
         sys.exit(relaunch_as_ranks(args.gpus))
     if env_world is not None and int(env_world) != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s: launch with torch.distributed.run --nproc-per-node %d, or "
@@ -479,11 +497,11 @@ def main():
     sim = None
     if args.rank_of and world > 1:
         sys.exit("bench.py: --rank-of measures one rank alone: run it with --gpus 1")
-    if args.rank_of or ((world > 1 or (args.force_slab and grp.dist is not None)) and not args.replicas):
+    if args.rank_of or peers_n or ((world > 1 or (args.force_slab and grp.dist is not None)) and not args.replicas):
         # ONE simulation, slab-decomposed over the ranks.  Allocation is the only step allowed to fail
         # softly: the ranks agree on it BEFORE the first collective; from then on any error is fatal (a rank that
         # dropped out of a collective sequence cannot be recovered from inside the job).
-        allocate, initialise = build_slab(phys_model, args.nx, grp, local_rank, args.chunks, kind=args.model, rank_of=args.rank_of)
+        allocate, initialise = build_slab(phys_model, args.nx, grp, local_rank, args.chunks, kind=args.model, rank_of=args.rank_of, peers=peers_n)
         err, ranks = None, None
         try:
             ranks = allocate()
@@ -496,7 +514,7 @@ def main():
             grp.close()
             sys.exit(3)
         sim, ctx = initialise(ranks)
-        mode = "slab x%d: %s" % (args.rank_of or world, sim.describe())
+        mode = "slab x%d: %s" % (args.rank_of or peers_n or world, sim.describe())
     if sim is None:
         m = build_model(phys_model, args.nx, local_rank, kind=args.model)
         ctx = m._ctx
@@ -526,11 +544,11 @@ def main():
     def barrier():
         # the library's streams first (nq_sync drains the compute AND the exchange stream): torch's communicator must never
         # start a collective while the library's own still has sends / receives queued on the same device
-        ctx.sync()
+        (sim.sync if sim is not None else ctx.sync)()       # (every rank this process drives: all of them with --link peers)
         torch.cuda.synchronize()
         grp.barrier()
         torch.cuda.synchronize()
-        ctx.sync()
+        (sim.sync if sim is not None else ctx.sync)()
 
     NBLK = 5 if args.steps >= 5 else 1
     blocks = [args.steps // NBLK + (1 if i < args.steps % NBLK else 0) for i in range(NBLK)]
@@ -637,7 +655,7 @@ def main():
 
     if rank == 0:
         npts = float(args.nx) ** 2
-        share = (args.rank_of or world) if sim is not None else 1     # a slab rank's launch covers 1/P of the grid
+        share = (args.rank_of or peers_n or world) if sim is not None else 1     # a slab rank's launch covers 1/P of the grid
         table = KERNEL_B_PER_PT[args.model]
         cands = [k for k in classes if k in table and classes[k][0] > 0]
         dom = max(cands, key=lambda k: classes[k][1])
@@ -659,7 +677,7 @@ def main():
             "metric": ("rank-compute steps/sec of ONE rank of %d alone (no exchange; NOT a simulation rate), " % args.rank_of if args.rank_of else "")
                       + "time-steps/sec, %sModel %d^2 fp64 (achieved HBM GB/s in roofline)" % (
                 {"coupled": "Coupled", "uncoupled": "UnCoupled", "qg": "QG", "ybj": "YBJ"}[args.model], args.nx),
-            "value": sps, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": sps, "unit": "steps/s", "n_gpus": peers_n or world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * s_per_step, "higher_is_better": True,
             "scaling": "strong" if sim is not None else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%sModel %s %d^2 fp64, ETDRK4, filter %s, budgets %s"
@@ -698,7 +716,7 @@ def main():
                          "step_frac_of_copy": (step_bytes / s_per_step / 1e9 / (copy_gbs * share)) if copy_gbs else None,
                          "step_real_frac_of_copy": (real_bytes / s_per_step / 1e9 / (copy_gbs * share)) if copy_gbs else None},
         }
-        if world == 1 and not args.no_cpu_baseline and not args.rank_of:
+        if world == 1 and not args.no_cpu_baseline and not args.rank_of and not peers_n:
             out["cpu_baseline"] = cpu_baseline(phys_model, args.nx, nx_sample=args.cpu_baseline_nx or None)
         print(json.dumps(out))
     watchdog("shutdown")

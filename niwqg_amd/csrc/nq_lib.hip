@@ -1310,6 +1310,26 @@ static void do_step(nq_ctx* c) {      // P == 1
 // ==================================================================================================================
 enum { LINK_NONE = 0, LINK_PEERS = 1, LINK_RCCL = 2, LINK_CALLBACK = 3, LINK_NULL = 4 };
 
+// Iterating the contexts of a group makes each context's device current before its loop body runs: with peers on DIFFERENT
+// devices of one process (nq_slab_attach_peers, round 4) every launch, event record and copy has to be issued with the owner's
+// device current.  On one device it is a thread-local no-op.
+struct EachCtx {
+  std::vector<nq_ctx*>& g;
+  struct It {
+    nq_ctx** p;
+    nq_ctx* operator*() const {
+      (void)hipSetDevice((*p)->device);
+      return *p;
+    }
+    It& operator++() { ++p; return *this; }
+    bool operator!=(const It& o) const { return p != o.p; }
+  };
+  It begin() const { return It{g.data()}; }
+  It end() const { return It{g.data() + g.size()}; }
+};
+static inline EachCtx each(std::vector<nq_ctx*>& g) { return EachCtx{g}; }
+
+
 // RCCL, taken from the process at run time (torch ships its own librccl and has usually loaded it already)
 struct NcclId { char internal[128]; };
 struct RcclApi {
@@ -1458,7 +1478,7 @@ static int issue_chunk(std::vector<nq_ctx*>& grp, int g, bool to_y, int i, int n
   if (c0->G[g].elems == 0) return 0;
   const size_t blk = (size_t)c0->Nloc * c0->G[g].pitch, cblk = blk / nch, off = (size_t)i * cblk;
   const bool inl = inline_exchange(c0, g, nch);
-  for (nq_ctx* c : grp) {
+  for (nq_ctx* c : each(grp)) {
     cd* send = to_y ? c->G[g].bx : c->G[g].by;
     cd* recv = to_y ? c->G[g].by : c->G[g].bx;
     hipEvent_t mine = to_y ? c->ev_prod[i] : c->ev_col;
@@ -1529,16 +1549,16 @@ static void set_window(nq_ctx* c, int i, int nch) {
 // whole group g at once, complete on the compute streams when this returns to the caller's next launch
 static int exchange_now(std::vector<nq_ctx*>& grp, int g, bool to_y) {
   if (grp.size() == 1 && grp[0]->P == 1 && grp[0]->G[g].bx == grp[0]->G[g].by) return 0;      // one rank, one buffer
-  for (nq_ctx* c : grp) HIPCHK(c, hipEventRecord(to_y ? c->ev_prod[0] : c->ev_col, c->stream));
+  for (nq_ctx* c : each(grp)) HIPCHK(c, hipEventRecord(to_y ? c->ev_prod[0] : c->ev_col, c->stream));
   const int sent = effective_chunks(grp[0]);
   if (to_y) {
     SLABTRY(issue_chunk(grp, g, true, 0, 1));
-    for (nq_ctx* c : grp)
+    for (nq_ctx* c : each(grp))
       if (c->link != LINK_CALLBACK) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
   } else {
     // arrival events are per chunk of the step's chunking: send it that way so that later waits find every event recorded
     for (int i = 0; i < sent; ++i) SLABTRY(issue_chunk(grp, g, false, i, sent));
-    for (nq_ctx* c : grp)
+    for (nq_ctx* c : each(grp))
       for (int i = 0; i < sent; ++i) SLABTRY(wait_arrival(c, g, i, sent));
   }
   return 0;
@@ -1569,7 +1589,7 @@ static int slab_allreduce(std::vector<nq_ctx*>& grp, int which) {
   int n = 0;
   if (!red_ptr(c0, which, &n)) NQ_FAIL(c0, -1, "slab_allreduce: which = %d", which);
   if (c0->link == LINK_CALLBACK) {
-    for (nq_ctx* c : grp) {
+    for (nq_ctx* c : each(grp)) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (!c->rcb) NQ_FAIL(c, -4, "no all-reduce callback");
       const int rc = c->rcb(c->cb_user, which);
@@ -1583,18 +1603,20 @@ static int slab_allreduce(std::vector<nq_ctx*>& grp, int which) {
     PeerBufs pb;
     for (size_t r = 0; r < grp.size(); ++r) {
       pb.p[r] = red_ptr(grp[r], which, &n);
+      HIPCHK(grp[r], hipSetDevice(grp[r]->device));
       HIPCHK(grp[r], hipEventRecord(grp[r]->ev_red, grp[r]->stream));
-      HIPCHK(c0, hipStreamWaitEvent(c0->mstream, grp[r]->ev_red, 0));
     }
+    HIPCHK(c0, hipSetDevice(c0->device));       // the reduction runs on rank 0's device and reads / writes the peers' sums in place
+    for (size_t r = 0; r < grp.size(); ++r) HIPCHK(c0, hipStreamWaitEvent(c0->mstream, grp[r]->ev_red, 0));
     {
       XTimer xt(c0, true);
       hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(64), 0, c0->mstream, pb, (int)grp.size(), n);
     }
     HIPCHK(c0, hipEventRecord(c0->ev_done, c0->mstream));
-    for (nq_ctx* c : grp) HIPCHK(c, hipStreamWaitEvent(c->stream, c0->ev_done, 0));
+    for (nq_ctx* c : each(grp)) HIPCHK(c, hipStreamWaitEvent(c->stream, c0->ev_done, 0));
     return 0;
   }
-  for (nq_ctx* c : grp) {                        // RCCL
+  for (nq_ctx* c : each(grp)) {                        // RCCL
     double* p = red_ptr(c, which, &n);
     HIPCHK(c, hipEventRecord(c->ev_red, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->mstream, c->ev_red, 0));
@@ -1632,7 +1654,7 @@ static int slab_step_ybj(std::vector<nq_ctx*>& grp) {
   const int nch = effective_chunks(c0);
   for (int s = 0; s < 4; ++s) {
     for (int i = 0; i < nch; ++i) {
-      for (nq_ctx* c : grp) {
+      for (nq_ctx* c : each(grp)) {
         SLABTRY(wait_arrival(c, 3, i, nch));
         SLABTRY(wait_arrival(c, 1, i, nch));
         SLABTRY(wait_arrival(c, 4, i, nch));
@@ -1642,7 +1664,7 @@ static int slab_step_ybj(std::vector<nq_ctx*>& grp) {
       }
       SLABTRY(issue_chunk(grp, 0, true, i, nch));
     }
-    for (nq_ctx* c : grp) {
+    for (nq_ctx* c : each(grp)) {
       set_window(c, 0, 1);
       if (c->link != LINK_CALLBACK) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
       launch_A_m(c, false, {&c->mW});
@@ -1661,7 +1683,7 @@ static int slab_step_ybj(std::vector<nq_ctx*>& grp) {
     }
     for (int i = 0; i < nch; ++i) SLABTRY(issue_chunk(grp, s < 3 ? 4 : 1, false, i, nch));
   }
-  for (nq_ctx* c : grp) c->n_steps += 1;
+  for (nq_ctx* c : each(grp)) c->n_steps += 1;
   return 0;
 }
 
@@ -1672,14 +1694,14 @@ static int slab_step_once(std::vector<nq_ctx*>& grp) {
   const int nch = effective_chunks(c0);
   for (int s = 0; s < 4; ++s) {
     if (s == 3 && c0->uv4_now)
-      for (nq_ctx* c : grp) {                   // the fourth stage's u, v have just arrived on the x side (group 3)
+      for (nq_ctx* c : each(grp)) {                   // the fourth stage's u, v have just arrived on the x side (group 3)
         for (int i = 0; i < nch; ++i) SLABTRY(wait_arrival(c, 3, i, nch));
         set_window(c, 0, 1);
         SLABTRY(stage4_uv_max(c));
       }
     // rows: nonlinear products, chunk by chunk; chunk i leaves as soon as it is done
     for (int i = 0; i < nch; ++i) {
-      for (nq_ctx* c : grp) {
+      for (nq_ctx* c : each(grp)) {
         SLABTRY(wait_arrival(c, 3, i, nch));
         if (waves) SLABTRY(wait_arrival(c, 1, i, nch));
         set_window(c, i, nch);
@@ -1688,19 +1710,19 @@ static int slab_step_once(std::vector<nq_ctx*>& grp) {
       }
       SLABTRY(issue_chunk(grp, 0, true, i, nch));
     }
-    for (nq_ctx* c : grp) {
+    for (nq_ctx* c : each(grp)) {
       set_window(c, 0, 1);
       if (c->link != LINK_CALLBACK) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
     }
     if (coupled) {
-      for (nq_ctx* c : grp) {
+      for (nq_ctx* c : each(grp)) {
         phase_update_phi(c, s);
         HIPCHK(c, hipEventRecord(c->ev_col, c->stream));
       }
       for (int i = 0; i < nch; ++i) SLABTRY(issue_chunk(grp, 1, false, i, nch));
-      for (nq_ctx* c : grp) phase_update_q(c, s);                    // under the transfer of group 1
+      for (nq_ctx* c : each(grp)) phase_update_q(c, s);                    // under the transfer of group 1
       for (int i = 0; i < nch; ++i) {
-        for (nq_ctx* c : grp) {
+        for (nq_ctx* c : each(grp)) {
           SLABTRY(wait_arrival(c, 1, i, nch));
           set_window(c, i, nch);
           phase_wavepv(c);
@@ -1708,7 +1730,7 @@ static int slab_step_once(std::vector<nq_ctx*>& grp) {
         }
         SLABTRY(issue_chunk(grp, 2, true, i, nch));
       }
-      for (nq_ctx* c : grp) {
+      for (nq_ctx* c : each(grp)) {
         set_window(c, 0, 1);
         if (c->link != LINK_CALLBACK) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
         phase_invert(c, s);
@@ -1716,7 +1738,7 @@ static int slab_step_once(std::vector<nq_ctx*>& grp) {
       }
       for (int i = 0; i < nch; ++i) SLABTRY(issue_chunk(grp, 3, false, i, nch));
     } else {
-      for (nq_ctx* c : grp) {
+      for (nq_ctx* c : each(grp)) {
         phase_update(c, s);                                            // includes the (spectral) inversion
         HIPCHK(c, hipEventRecord(c->ev_col, c->stream));
       }
@@ -1726,16 +1748,16 @@ static int slab_step_once(std::vector<nq_ctx*>& grp) {
     }
   }
   if (c0->bud) {
-    for (nq_ctx* c : grp) phase_budget_sums(c);
+    for (nq_ctx* c : each(grp)) phase_budget_sums(c);
     SLABTRY(slab_allreduce(grp, 0));
-    for (nq_ctx* c : grp) phase_budget_finish(c);
+    for (nq_ctx* c : each(grp)) phase_budget_finish(c);
   }
-  for (nq_ctx* c : grp) c->n_steps += 1;
+  for (nq_ctx* c : each(grp)) c->n_steps += 1;
   return 0;
 }
 // every arrival of the last step has to be on the compute stream before anybody else (a read, a set_q, a sync) touches the x side
 static int slab_settle(std::vector<nq_ctx*>& grp) {
-  for (nq_ctx* c : grp) {
+  for (nq_ctx* c : each(grp)) {
     const int sent = effective_chunks(c);
     for (int g = 0; g < 5; ++g)
       if (c->arr_pending[g]) {
@@ -2631,9 +2653,22 @@ int nq_slab_attach_peers(nq_ctx* const* ctxs, int nranks) {
   std::vector<nq_ctx*> all(ctxs, ctxs + nranks);
   for (int r = 0; r < nranks; ++r) {
     nq_ctx* c = all[r];
-    if (!c || c->P != nranks || c->rank != r || c->device != all[0]->device || c->link != LINK_NONE)
-      NQ_FAIL(c, -1, "nq_slab_attach_peers: context %d is not rank %d of %d on the common device (or already linked)", r, r, nranks);
+    if (!c || c->P != nranks || c->rank != r || c->link != LINK_NONE)
+      NQ_FAIL(c, -1, "nq_slab_attach_peers: context %d is not rank %d of %d (or already linked)", r, r, nranks);
   }
+  // peers on different devices of this process: the blocks then cross by peer copies (SDMA over xGMI, no CU involved) and the
+  // all-reduce kernel reads the peers' buffers directly -- both need peer access, enabled here in both directions
+  for (nq_ctx* a : all)
+    for (nq_ctx* b : all) {
+      if (a->device == b->device) continue;
+      int can = 0;
+      HIPCHK(a, hipDeviceCanAccessPeer(&can, a->device, b->device));
+      if (!can) NQ_FAIL(a, -3, "nq_slab_attach_peers: device %d cannot access device %d", a->device, b->device);
+      HIPCHK(a, hipSetDevice(a->device));
+      const hipError_t e = hipDeviceEnablePeerAccess(b->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) NQ_FAIL(a, -5, "hipDeviceEnablePeerAccess(%d -> %d): %s", a->device, b->device, hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
   for (nq_ctx* c : all) {
     c->peers = all;
     c->link = LINK_PEERS;
@@ -2685,7 +2720,7 @@ int nq_slab_config(nq_ctx* c, int nchunks) {
   std::vector<nq_ctx*> grp = c->link == LINK_PEERS ? c->peers : std::vector<nq_ctx*>(1, c);
   int rc = slab_settle(grp);
   if (rc) return rc;
-  for (nq_ctx* x : grp) x->nchunk = nchunks;
+  for (nq_ctx* x : each(grp)) x->nchunk = nchunks;
   return 0;
 }
 int nq_slab_step(nq_ctx* c, int nsteps) {
@@ -2693,21 +2728,21 @@ int nq_slab_step(nq_ctx* c, int nsteps) {
   if (nsteps < 0) NQ_FAIL(c, -1, "nq_slab_step: nsteps < 0");
   std::vector<nq_ctx*> grp;
   SLABTRY(slab_group(c, &grp));
-  for (nq_ctx* x : grp) HIPCHK(x, hipSetDevice(x->device));
+  for (nq_ctx* x : each(grp)) HIPCHK(x, hipSetDevice(x->device));
   c->n_calls += 1;
   for (int i = 0; i < nsteps; ++i) {
     const bool now = c->want_uv4 && i == nsteps - 1 && c->kernel_family && !c->ybj;
-    for (nq_ctx* x : grp) x->uv4_now = now;
+    for (nq_ctx* x : each(grp)) x->uv4_now = now;
     SLABTRY(slab_step_once(grp));
   }
   if (nsteps > 0)
-    for (nq_ctx* x : grp) {
+    for (nq_ctx* x : each(grp)) {
       x->stepped = true;
       x->have_uv4 = x->uv4_now;
       x->want_uv4 = x->uv4_now = false;
     }
   SLABTRY(slab_settle(grp));
-  for (nq_ctx* x : grp) HIPCHK(x, hipGetLastError());
+  for (nq_ctx* x : each(grp)) HIPCHK(x, hipGetLastError());
   return 0;
 }
 
@@ -2749,12 +2784,12 @@ int nq_slab_commit(nq_ctx* c, int which) {
   if (!c) return -1;
   std::vector<nq_ctx*> grp;
   SLABTRY(slab_group(c, &grp));
-  for (nq_ctx* x : grp) HIPCHK(x, hipSetDevice(x->device));
+  for (nq_ctx* x : each(grp)) HIPCHK(x, hipSetDevice(x->device));
   SLABTRY(slab_settle(grp));
   nq_ctx* c0 = grp[0];
   if (which == 0) {
     SLABTRY(exchange_now(grp, 0, true));
-    for (nq_ctx* x : grp) {
+    for (nq_ctx* x : each(grp)) {
       launch_A_m(x, false, {&x->mUq});
       if (x->Wh > 0) launch_B_p(x, false, x->mUq.ys, x->mUq.pitch, x->q.y[x->q.cur], x->Ph, x->Wh, 1.0);
       if (x->dual)      // q is real: both copies of the dual-copy equation start from the same half spectrum
@@ -2762,10 +2797,10 @@ int nq_slab_commit(nq_ctx* c, int which) {
       SLABTRY(reset_passenger(x));
     }
     if (c0->p.model == NQ_MODEL_COUPLED) {
-      for (nq_ctx* x : grp) phase_wavepv(x);
+      for (nq_ctx* x : each(grp)) phase_wavepv(x);
       SLABTRY(exchange_now(grp, 2, true));
     }
-    for (nq_ctx* x : grp) {
+    for (nq_ctx* x : each(grp)) {
       phase_invert_y(x, x->q.y[x->q.cur], true, x->part0Q, nullptr, x->passive ? x->cq.y[x->cq.cur] : nullptr);
       if (x->bud && x->kernel_family)
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->part0Q, x->nwq, 3, 3, x->carryQ);
@@ -2776,7 +2811,7 @@ int nq_slab_commit(nq_ctx* c, int which) {
   } else if (which == 1) {
     if (!c0->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
     SLABTRY(exchange_now(grp, 0, true));
-    for (nq_ctx* x : grp) {
+    for (nq_ctx* x : each(grp)) {
       launch_A_m(x, false, {&x->mW});
       launch_B_p(x, false, x->mW.ys, x->mW.pitch, x->w.y[x->w.cur], x->Wf, x->Wf, 1.0);
       launch_emit_phi(x, x->w.y[x->w.cur]);
@@ -2786,21 +2821,21 @@ int nq_slab_commit(nq_ctx* c, int which) {
     }
     SLABTRY(exchange_now(grp, 1, false));
     if (c0->bud) SLABTRY(slab_allreduce(grp, 1));
-    for (nq_ctx* x : grp) SLABTRY(nq_refresh_grad_phi(x));
+    for (nq_ctx* x : each(grp)) SLABTRY(nq_refresh_grad_phi(x));
   } else if (which == 2 || which == 3) {        // Kernel._invert on the current state (CoupledModel.py:75-97 / UnCoupledModel.py:54-64)
     if (which == 3) {                           // QGModel.set_c (QGModel.py:476-480): the scalar's spectrum first
       if (!c0->passive) NQ_FAIL(c, -4, "nq_slab_commit: this context has no passive scalar");
       SLABTRY(exchange_now(grp, 0, true));
-      for (nq_ctx* x : grp) {
+      for (nq_ctx* x : each(grp)) {
         launch_A_m(x, false, {&x->mUq});
         if (x->Wh > 0) launch_B_p(x, false, x->mUq.ys, x->mUq.pitch, x->cq.y[x->cq.cur], x->Ph, x->Wh, 1.0);
       }
     }
     if (c0->p.model == NQ_MODEL_COUPLED) {
-      for (nq_ctx* x : grp) phase_wavepv(x);
+      for (nq_ctx* x : each(grp)) phase_wavepv(x);
       SLABTRY(exchange_now(grp, 2, true));
     }
-    for (nq_ctx* x : grp) {
+    for (nq_ctx* x : each(grp)) {
       phase_invert_y(x, x->q.y[x->q.cur], true, x->part0Q, nullptr, x->passive ? x->cq.y[x->cq.cur] : nullptr);
       if (x->bud && x->kernel_family)
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->part0Q, x->nwq, 3, 3, x->carryQ);
@@ -2809,7 +2844,7 @@ int nq_slab_commit(nq_ctx* c, int which) {
     if (c0->bud && c0->kernel_family) SLABTRY(slab_allreduce(grp, 2));
   } else NQ_FAIL(c, -1, "nq_slab_commit: which = %d", which);
   SLABTRY(slab_settle(grp));
-  for (nq_ctx* x : grp) {
+  for (nq_ctx* x : each(grp)) {
     HIPCHK(x, hipGetLastError());
     SLABTRY(nq_sync(x));
   }
@@ -2866,7 +2901,7 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
   const int N = c0->N, NB = 1024;
   const double M = (double)N * N;
   const bool waves = c0->kernel_family, coupled = c0->p.model == NQ_MODEL_COUPLED;
-  for (nq_ctx* x : grp) {
+  for (nq_ctx* x : each(grp)) {
     HIPCHK(x, hipSetDevice(x->device));
     const int nxb = xdiag_blocks(x), nww = (x->Wf / x->CLy) * x->S2;
     if (!x->diag_part) {
@@ -2907,6 +2942,7 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
   }
   SLABTRY(slab_allreduce(grp, 4));
   double h[16];
+  HIPCHK(c0, hipSetDevice(c0->device));
   HIPCHK(c0, hipMemcpyAsync(h, c0->diag_out, sizeof(double) * 16, hipMemcpyDeviceToHost, c0->stream));
   SLABTRY(nq_sync(c0));
   for (int i = 0; i < 15; ++i) out[i] = h[i];
@@ -2915,7 +2951,7 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
   out[15] = qbar;
   if (!waves && c0->passive) {
     // as in nq_diagnostics: [16..19] the |c-hat|^2 sums, [20] the Gamma_c projection with the u, v of the fourth stage
-    for (nq_ctx* x : grp) {
+    for (nq_ctx* x : each(grp)) {
       const cd* ch = x->cq.y[x->cq.cur];
       if (x->Wh > 0) {
         hipLaunchKernelGGL(k_diag_c, dim3(NB), dim3(256), 0, x->stream, ch, N, x->Wh, x->Ph, x->kh0, x->kk, x->ll, x->diag_part);
@@ -2925,9 +2961,9 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
       phase_invert_y(x, qh4, false, x->part0Q, nullptr, ch);
     }
     SLABTRY(exchange_now(grp, 3, false));
-    for (nq_ctx* x : grp) launch_products(x);
+    for (nq_ctx* x : each(grp)) launch_products(x);
     SLABTRY(exchange_now(grp, 0, true));
-    for (nq_ctx* x : grp) {
+    for (nq_ctx* x : each(grp)) {
       launch_A_m(x, false, {&x->mUc, &x->mVc});
       const YGeom g = geom_half(x);
       if (g.width <= 0) continue;
@@ -2937,25 +2973,26 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
 #undef CALL_
       hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, nwc, 1, 1, x->diag_out + 20);
     }
-    for (nq_ctx* x : grp)                           // the mixed-space rows of the CURRENT state again, for the next step
+    for (nq_ctx* x : each(grp))                           // the mixed-space rows of the CURRENT state again, for the next step
       phase_invert_y(x, x->q.y[x->q.cur], true, x->part0Q, nullptr, x->cq.y[x->cq.cur]);
     SLABTRY(exchange_now(grp, 3, false));
     SLABTRY(slab_allreduce(grp, 5));
+    HIPCHK(c0, hipSetDevice(c0->device));
     HIPCHK(c0, hipMemcpyAsync(out + 16, c0->diag_out + 16, sizeof(double) * 5, hipMemcpyDeviceToHost, c0->stream));
     SLABTRY(slab_settle(grp));
-    for (nq_ctx* x : grp) SLABTRY(nq_sync(x));
+    for (nq_ctx* x : each(grp)) SLABTRY(nq_sync(x));
     return 0;
   }
   if (!waves) return 0;
-  for (nq_ctx* x : grp) {
+  for (nq_ctx* x : each(grp)) {
     if (coupled) launch_xdiag_m<MODE_COUPLED>(x, qbar, abar, x->diag_part);
     else launch_xdiag_m<MODE_UNCOUPLED>(x, qbar, abar, x->diag_part);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, x->stream, x->diag_part, xdiag_blocks(x), 8, 8, x->diag_out + 16);
   }
   for (int which = 0; which < 2; ++which) {
-    for (nq_ctx* x : grp) launch_products(x, which == 0 ? 1.0 : 0.0, which == 0 ? 0.0 : 1.0);
+    for (nq_ctx* x : each(grp)) launch_products(x, which == 0 ? 1.0 : 0.0, which == 0 ? 0.0 : 1.0);
     SLABTRY(exchange_now(grp, 0, true));
-    for (nq_ctx* x : grp) {
+    for (nq_ctx* x : each(grp)) {
       const int nww = (x->Wf / x->CLy) * x->S2;
       launch_A_m(x, false, {&x->mW});
       launch_project(x, x->diag_part);
@@ -2963,8 +3000,9 @@ int nq_slab_diagnostics(nq_ctx* c, double* out) {
     }
   }
   SLABTRY(slab_allreduce(grp, 5));
+  HIPCHK(c0, hipSetDevice(c0->device));
   HIPCHK(c0, hipMemcpyAsync(out + 16, c0->diag_out + 16, sizeof(double) * 16, hipMemcpyDeviceToHost, c0->stream));
-  for (nq_ctx* x : grp) SLABTRY(nq_sync(x));
+  for (nq_ctx* x : each(grp)) SLABTRY(nq_sync(x));
   return 0;
 }
 // Spectra the whole-plane calls of the class API need on a slab model (fft seam, the three Jacobians): the row kernel of
@@ -2980,7 +3018,7 @@ int nq_slab_spectral(nq_ctx* c, int what) {
   if (what < 0 || what > 6) NQ_FAIL(c, -1, "nq_slab_spectral: what = %d", what);
   std::vector<nq_ctx*> grp;
   SLABTRY(slab_group(c, &grp));
-  for (nq_ctx* x : grp) HIPCHK(x, hipSetDevice(x->device));
+  for (nq_ctx* x : each(grp)) HIPCHK(x, hipSetDevice(x->device));
   SLABTRY(slab_settle(grp));
   nq_ctx* c0 = grp[0];
   const bool full = what == 2 || what == 3 || what == 6;
@@ -2988,7 +3026,7 @@ int nq_slab_spectral(nq_ctx* c, int what) {
   if (what == 4 && (c0->p.model != NQ_MODEL_COUPLED || c0->ybj)) NQ_FAIL(c, -4, "jacobian_phic_phi exists only in the coupled model");
   if (what <= 3 && !c0->have_q) NQ_FAIL(c, -4, "nq_slab_spectral: set_q has not been called");
   if ((what == 2 || what == 3 || what == 4) && !c0->have_phi) NQ_FAIL(c, -4, "nq_slab_spectral: set_phi has not been called");
-  for (nq_ctx* x : grp) {
+  for (nq_ctx* x : each(grp)) {
     if (!x->scr_f1) {
       const size_t w = (size_t)(x->Wf > x->Ph ? x->Wf : x->Ph);
       ALLOC(x, x->scr_f1, (size_t)x->N * w);
@@ -3000,7 +3038,7 @@ int nq_slab_spectral(nq_ctx* c, int what) {
     else if (what == 4) launch_wavepv(x);
   }
   SLABTRY(exchange_now(grp, what == 4 ? 2 : 0, true));
-  for (nq_ctx* x : grp) {
+  for (nq_ctx* x : each(grp)) {
     const MArr& m = (what == 0 || what == 5) ? x->mUq : (what == 1 ? x->mVq : (what == 4 ? x->mB : x->mW));
     launch_A_m(x, false, {&m});
     if (full) launch_B_p(x, false, m.ys, m.pitch, x->scr_f1, x->Wf, x->Wf, 1.0);
@@ -3008,7 +3046,7 @@ int nq_slab_spectral(nq_ctx* c, int what) {
     HIPCHK(x, hipGetLastError());
     x->spec_kind = full ? 0 : 1;
   }
-  for (nq_ctx* x : grp) SLABTRY(nq_sync(x));
+  for (nq_ctx* x : each(grp)) SLABTRY(nq_sync(x));
   return 0;
 }
 // this rank's column slab of the last nq_slab_spectral: (nx, wh) for the half-spectrum results, (nx, wf) for the others

@@ -287,7 +287,8 @@ class SlabSimulation(object):
 
     def describe(self):
         how = {"rccl": "grouped ncclSend/ncclRecv issued inside the library",
-               "peers": "peer ranks in one process (device copies)",
+               "peers": "peer ranks in one process (device / peer copies%s)" % (
+                   "" if len(set(r.device for r in self.ranks)) == 1 else " across %d devices" % len(set(r.device for r in self.ranks))),
                "callback": "torch.distributed all_to_all_single from a library callback",
                "null": "NO exchange (one rank of the decomposition measured alone)"}[self.link]
         return "in-library step, %s, %d row chunks per exchange" % (how, int(self.counters()["nchunks"]))
@@ -395,9 +396,11 @@ class SlabSimulation(object):
 
 
 def make_ranks(model, nx, kk, ll, filtr, dt, nranks, device=0, only_rank=None, budgets=True, torch_buffers=False, **phys):
-    """All ranks on one device (peers) or just `only_rank` (real run, one process per GPU)."""
+    """All ranks in this process (peers: on one device, or -- `device` a list -- rank r on device[r]) or just `only_rank` (real run,
+    one process per GPU)."""
     which = range(nranks) if only_rank is None else [only_rank]
-    return [SlabRank(model, nx, kk, ll, filtr, dt, nranks, r, device, budgets=budgets, torch_buffers=torch_buffers, **phys)
+    dev = (lambda r: device[r]) if isinstance(device, (list, tuple)) else (lambda r: device)
+    return [SlabRank(model, nx, kk, ll, filtr, dt, nranks, r, dev(r), budgets=budgets, torch_buffers=torch_buffers, **phys)
             for r in which]
 
 

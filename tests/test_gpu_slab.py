@@ -461,3 +461,32 @@ def test_bench_contract_on_one_gpu():
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak_measured_copy"] > 1000.0
     cb = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+
+
+def test_bench_peers_link_and_rank_of_on_one_gpu():
+    """`bench.py --gpus 2 --link peers`: ONE process drives both ranks (on a multi-GPU node rank r sits on device r and the blocks
+    cross by peer copies; here both share the one device) -- no launcher, no RCCL; `bench.py --rank-of 4`: one rank of the
+    decomposition alone with the null link, next to the single-GPU step of the same run; `bench.py --nx 96`: the any-size path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+
+    def line(*args):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + list(args),
+                             capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert out.returncode == 0, (args, out.stdout[-1500:], out.stderr[-3000:])
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, lines
+        return json.loads(lines[0])
+    d = line("--nx", "256", "--gpus", "2", "--link", "peers")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "peer ranks in one process" in d["config"]["parallelism"]
+    assert d["config"]["exchange_chunks_per_step"] > 0 and d["value"] > 0
+    d = line("--nx", "512", "--rank-of", "4", "--chunks", "1")
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["rank_of"] == 4 and c["rank_compute_ms_per_step"] > 0 and c["single_gpu_ms_per_step_same_run"] > 0
+    assert "NOT a simulation rate" in d["metric"] and c["exchange_GB_sent_per_rank_per_step"] == 0
+    d = line("--nx", "96")
+    assert "ANY-SIZE" in d["metric"] and d["value"] > 0 and d["roofline"]["bound"] == "hbm"

@@ -24,4 +24,14 @@ for n in $GPUS; do
         --chunks $chunks 2>/dev/null | grep '^{' | tee -a $OUT
     done
   done
+  # the other link: ONE process, rank r on device r, blocks cross by peer copies (SDMA over xGMI, no CUs) -- the A/B against RCCL's
+  # send/recv kernels, which compete for CUs with the persistent row kernels
+  for chunks in 1 2 4; do
+    echo "== $n GPUs, --link peers, --chunks $chunks" | tee -a $OUT
+    timeout -k 10 900 python bench.py --gpus $n --link peers --nx $NX --steps 50 --warmup 10 --chunks $chunks 2>/dev/null | grep '^{' | tee -a $OUT
+  done
+  # ... and single-chunk exchanges kept on the exchange stream (they run on the compute stream by default)
+  echo "== $n GPUs, --chunks 1, NIWQG_AMD_SLAB_INLINE=0" | tee -a $OUT
+  NIWQG_AMD_SLAB_INLINE=0 timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n \
+    --master-addr 127.0.0.1 --master-port $((29700 + n)) bench.py --gpus $n --nx $NX --steps 50 --warmup 10 --chunks 1 2>/dev/null | grep '^{' | tee -a $OUT
 done

@@ -222,6 +222,51 @@ __global__ void __launch_bounds__(256) k_any_btranspose(const cd* __restrict__ s
   if (ro < R && co < C) dst[base + (size_t)co * R + ro] = tile[tx][ty];
 }
 
+// Bluestein in ONE kernel for rows whose work length M the row engine takes in registers (M <= 8192): chirp multiply and zero
+// padding on load, FFT_M, multiply by the transformed chirp, inverse FFT_M, chirp multiply on store -- the line never leaves the
+// workgroup between the two transforms (five launches and five passes over rows of length M otherwise).  Rows are contiguous
+// (axis 1); columns go through a transpose of the plane (nq_any_fft).
+template <int M>
+__global__ void __launch_bounds__(XPlan<M>::THREADS)
+k_any_bluestein_rows(const cd* src, cd* dst, int nrows, int n, int pitch, const cd* __restrict__ chirp,
+                     const cd* __restrict__ bhat, const cd* __restrict__ tw, int conj_io, double scale) {
+  typedef XPlan<M> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const int row = blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename X::F::Tw twr;
+  X::F::load_tw(twr, j, tw, 1);
+  const bool ok = row < nrows;
+  cd r[P];
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int k = j + t * T;
+    cd v = cmake(0, 0);
+    if (ok && k < n) {
+      v = src[(size_t)row * pitch + k];
+      if (conj_io) v = cconj(v);
+      v = cmul(v, chirp[k]);
+    }
+    r[t] = v;
+  }
+  X::F::template run<false>(r, j, c, lds, twr);
+#pragma unroll
+  for (int t = 0; t < P; ++t) r[t] = cmul(r[t], bhat[j + t * T]);
+  X::F::template run<true>(r, j, c, lds, twr);
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      const int k = j + t * T;
+      if (k < n) {
+        cd v = cscale(cmul(r[t], chirp[k]), scale);
+        if (conj_io) v = cconj(v);
+        dst[(size_t)row * pitch + k] = v;
+      }
+    }
+  }
+}
+
 }  // namespace nq
 
 struct nq_any {

@@ -3761,6 +3761,19 @@ static int any_rows_fft(nq_any* e, const nq_any::Plan& pl, int nlines, double sc
   }
   return 0;
 }
+// the fused Bluestein row kernel on `nlines` contiguous rows of `n` values (pitch n), in place or src -> dst
+static int any_bluestein_rows(nq_any* e, const nq_any::Plan& pl, const cd* src, cd* dst, int nlines, int n, int inverse) {
+  const double scale = (inverse ? 1.0 / (double)n : 1.0) / (double)pl.M;
+  switch (pl.M) {
+#define CASE_(m, a, b) case m: { typedef XPlan<m> X; \
+      hipLaunchKernelGGL((k_any_bluestein_rows<m>), dim3((nlines + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, e->stream, src, dst, nlines, n, n, \
+                         (const cd*)pl.chirp, (const cd*)pl.bhat, (const cd*)pl.tw, inverse ? 1 : 0, scale); } break;
+    NQ_FOR_SIZES(CASE_)
+#undef CASE_
+    default: ANYFAIL(e, -2, "any-size engine: no fused row plan of length %d", pl.M);
+  }
+  return 0;
+}
 static int any_buf(nq_any* e, cd** buf, size_t* have, size_t elems) {
   if (*have >= elems) return 0;
   if (*buf) {
@@ -3932,10 +3945,33 @@ int nq_any_fft(nq_any* e, void* dst, const void* src, int rows, int cols, int ax
   const nq_any::Plan* pl = nullptr;
   int rc = any_plan(e, n, &pl);
   if (rc) return rc;
+  cd* srcp = reinterpret_cast<cd*>(const_cast<void*>(src));
+  static int fused = -1;
+  if (fused < 0) {
+    const char* ev = getenv("NIWQG_AMD_ANY_FUSED");             // 0: the unfused five-launch form (A/B measurements)
+    fused = (ev && atoi(ev) == 0) ? 0 : 1;
+  }
+  if (fused && !pl->direct && pl->M <= 8192) {
+    // one kernel per line (k_any_bluestein_rows); columns through a transpose of the plane
+    if (axis == 1) {
+      rc = any_bluestein_rows(e, *pl, srcp, reinterpret_cast<cd*>(dst), rows, cols, inverse);
+      if (rc) return rc;
+    } else {
+      rc = any_tmp(e, (size_t)rows * cols);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_any_btranspose, dim3((cols + 15) / 16, (rows + 15) / 16, 1), dim3(256), 0, e->stream, (const cd*)srcp, e->tmp, rows, cols,
+                         (const cd*)nullptr, 0, 0);
+      rc = any_bluestein_rows(e, *pl, e->tmp, e->tmp, cols, rows, inverse);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_any_btranspose, dim3((rows + 15) / 16, (cols + 15) / 16, 1), dim3(256), 0, e->stream, (const cd*)e->tmp, reinterpret_cast<cd*>(dst), cols, rows,
+                         (const cd*)nullptr, 0, 0);
+    }
+    ANYCHK(e, hipGetLastError());
+    return 0;
+  }
   rc = any_tmp(e, (size_t)nlines * pl->M, pl->M == 16384);
   if (rc) return rc;
   const dim3 gp((pl->M + 15) / 16, (nlines + 15) / 16), gu((n + 15) / 16, (nlines + 15) / 16);
-  cd* srcp = reinterpret_cast<cd*>(const_cast<void*>(src));
   if (pl->direct) {          // a power of two the row engine takes (four-step for 16384): no chirp, the inverse by its own kernel
     hipLaunchKernelGGL((k_any_lines<true>), gp, dim3(256), 0, e->stream, srcp, e->tmp, rows, cols, axis, pl->M, (const cd*)nullptr, 0, 1.0);
     rc = inverse ? any_rows_fft<true>(e, *pl, nlines, 1.0 / (double)n) : any_rows_fft<false>(e, *pl, nlines, 1.0);

@@ -13,7 +13,6 @@ projections, its quirks (stale ``phix, phiy`` in UnCoupledModel, ``set_phi`` tha
 stage after a step).  This path is for generality, not speed: a step is a few hundred small launches issued from Python.
 """
 import ctypes
-import weakref
 
 import numpy as np
 
@@ -44,6 +43,8 @@ class Engine(object):
             raise RuntimeError("nq_any_create failed (%d): %s" % (rc, self.L.nq_any_last_error(None).decode()))
         self.h = h
         self.pool = {}
+        self.sc = (ctypes.c_double * 6)()          # the scalars of the next element-wise call (one engine, one host thread)
+        self._ew = self.L.nq_any_ew
 
     def chk(self, rc, what):
         if rc != 0:
@@ -84,20 +85,24 @@ class Engine(object):
             raise ValueError("a plane is two-dimensional")
         isreal = (not np.iscomplexobj(a)) if real is None else bool(real)
         buf = np.ascontiguousarray(a, np.complex128)
-        p = Plane(self, buf.shape, isreal)
+        p = Plane(self, (int(buf.shape[0]), int(buf.shape[1])), isreal)
         self.chk(self.L.nq_any_upload(self.h, p.ptr, _lib._dptr(buf.view(np.float64)), buf.size), "nq_any_upload")
         return p
 
     def zeros(self, shape, real=False):
-        p = Plane(self, shape, real)
+        p = Plane(self, (int(shape[0]), int(shape[1])), bool(real))
         p._ew(EW_SCALE, p, s0=0.0)
         return p
 
 
-def _release(engine_ref, ptr, elems):
-    e = engine_ref()
-    if e is not None and getattr(e, "h", None):
-        e.give(ptr, elems)
+def _set_scalar(sc, i, v):
+    if v.__class__ is float or v.__class__ is int:
+        sc[i] = v
+        sc[i + 1] = 0.0
+    else:
+        v = complex(v)
+        sc[i] = v.real
+        sc[i + 1] = v.imag
 
 
 class Plane(object):
@@ -107,19 +112,34 @@ class Plane(object):
 
     __array_priority__ = 1000        # numpy scalars and arrays defer to the reflected operators below
 
-    def __init__(self, eng, shape, real=False):
-        self.eng, self.shape, self.isreal = eng, (int(shape[0]), int(shape[1])), bool(real)
-        self.size = self.shape[0] * self.shape[1]
-        self.ptr = eng.take(self.size)
-        self._fin = weakref.finalize(self, _release, weakref.ref(eng), self.ptr, self.size)
+    __slots__ = ("eng", "shape", "isreal", "size", "ptr")
 
-    # ---- plumbing
+    def __init__(self, eng, shape, real=False):
+        self.eng, self.shape, self.isreal = eng, shape, real
+        self.size = size = shape[0] * shape[1]
+        free = eng.pool.get(size)
+        self.ptr = free.pop() if free else eng.take(size)
+
+    def __del__(self):
+        # back to the engine's pool (everything runs in order on the engine's stream: a plane handed out again is only written by
+        # work queued after every reader of its previous life)
+        try:
+            eng = self.eng
+            if eng.h:
+                eng.pool.setdefault(self.size, []).append(self.ptr)
+        except Exception:
+            pass
+
+    # ---- plumbing (a Coupled step is ~600 of these calls: kept lean -- the per-call Python cost is what bounds small grids)
     def _ew(self, op, a, b=None, c=None, s0=1.0, s1=0.0, s2=0.0):
-        sc = (ctypes.c_double * 6)(complex(s0).real, complex(s0).imag, complex(s1).real, complex(s1).imag,
-                                   complex(s2).real, complex(s2).imag)
         e = self.eng
-        e.chk(e.L.nq_any_ew(e.h, op, self.ptr, a.ptr, None if b is None else b.ptr, None if c is None else c.ptr, self.size, sc),
-              "nq_any_ew(%d)" % op)
+        sc = e.sc
+        _set_scalar(sc, 0, s0)
+        _set_scalar(sc, 2, s1)
+        _set_scalar(sc, 4, s2)
+        rc = e._ew(e.h, op, self.ptr, a.ptr, None if b is None else b.ptr, None if c is None else c.ptr, self.size, sc)
+        if rc:
+            e.chk(rc, "nq_any_ew(%d)" % op)
         return self
 
     def _new(self, real=False):

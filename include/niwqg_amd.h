@@ -308,7 +308,9 @@ int nq_slab_diagnostics(nq_ctx* ctx, double* out32);
 int nq_slab_local_max(nq_ctx* ctx, double* out3);
 /* counters since the last reset: out[0] host calls of nq_slab_step, [1] steps, [2] exchange chunks issued, [3] bytes this
  * rank sent to OTHER ranks, [4] milliseconds the exchange stream spent in exchanges (HIP events; 0 unless timing was
- * switched on with reset = 2), [5] nchunks in use */
+ * switched on with reset = 2), [5] nchunks in use.  reset = 2 switches the per-exchange event timing ON and it stays on (two events
+ * per exchange chunk and per all-reduce, at most 16384 timed pairs each -- later ones go untimed) until a call with reset = 1,
+ * which zeroes the counters and switches it off again. */
 int nq_slab_counters(nq_ctx* ctx, double* out6, int reset);
 /* out2[0]: milliseconds the exchange stream spent in the all-reduces of the steps since timing was switched on
  * (nq_slab_counters with reset = 2), out2[1]: how many all-reduces that was.  Read before the call that resets. */

@@ -267,6 +267,66 @@ k_any_bluestein_rows(const cd* src, cd* dst, int nrows, int n, int pitch, const 
   }
 }
 
+// Lengths n = R m with a small odd R (3 or 5) and a power of two m the row engine takes (64 <= m <= 2048) need no chirp: the R
+// decimated sub-sequences x[R j + r] are transformed as R m-point problems held in registers side by side, and one radix-R
+// butterfly with the twiddles w_n^(r k) combines them,
+//     X[k + m s] = sum_r w_R^(r s) w_n^(r k) Y_r[k],     k < m, s < R
+// (3 x FFT_1024 instead of 2 x FFT_8192 for n = 3072).  One kernel per line; the inverse is conj(fft(conj x)) / n.
+// twn: exp(-2 pi i q / n), q < n;  twm: the m-point plan's table.
+template <int M, int R>
+__global__ void __launch_bounds__(XPlan<M>::THREADS)
+k_any_split_rows(const cd* src, cd* dst, int nrows, int pitch, const cd* __restrict__ twn, const cd* __restrict__ twm, int conj_io,
+                 double scale) {
+  typedef XPlan<M> X;
+  constexpr int P = X::P, T = X::T;
+  const int j = threadIdx.x % T, c = threadIdx.x / T;
+  const int row = blockIdx.x * X::C + c;
+  cd* lds = reinterpret_cast<cd*>(nq_smem);
+  typename X::F::Tw twr;
+  X::F::load_tw(twr, j, twm, 1);
+  const bool ok = row < nrows;
+  cd y[R][P];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+      cd v = cmake(0, 0);
+      if (ok) {
+        v = src[(size_t)row * pitch + (size_t)R * (j + t * T) + r];
+        if (conj_io) v = cconj(v);
+      }
+      y[r][t] = v;
+    }
+    X::F::template run<false>(y[r], j, c, lds, twr);
+  }
+  if (!ok) return;
+  // w_R^q, q < R (forward sign)
+  cd wr[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    double sn, cs;
+    sincospi(-2.0 * (double)q / (double)R, &sn, &cs);
+    wr[q] = cmake(cs, sn);
+  }
+#pragma unroll
+  for (int t = 0; t < P; ++t) {
+    const int k = j + t * T;
+    cd z[R];
+    z[0] = y[0][t];
+#pragma unroll
+    for (int r = 1; r < R; ++r) z[r] = cmul(y[r][t], twn[(size_t)r * k]);        // r k < R m = n
+#pragma unroll
+    for (int sidx = 0; sidx < R; ++sidx) {
+      cd acc = z[0];
+#pragma unroll
+      for (int r = 1; r < R; ++r) acc = cadd(acc, cmul(z[r], wr[(r * sidx) % R]));
+      acc = cscale(acc, scale);
+      if (conj_io) acc = cconj(acc);
+      dst[(size_t)row * pitch + k + (size_t)M * sidx] = acc;
+    }
+  }
+}
+
 }  // namespace nq
 
 struct nq_any {
@@ -279,6 +339,7 @@ struct nq_any {
   struct Plan {
     int n = 0, M = 0;
     bool direct = false;                 // n itself is a power of two the row engine (or its four-step form) takes: no chirp
+    int split = 0;                       // n = split * M with split = 3 or 5 and M a power of two: k_any_split_rows, no chirp
     nq::cd *chirp = nullptr, *bhat = nullptr, *tw = nullptr;
     nq::cd* tw_small = nullptr;          // M = 16384: the twiddles of the 128-point passes of the four-step transform
   };

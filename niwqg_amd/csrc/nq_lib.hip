@@ -3774,6 +3774,19 @@ static int any_bluestein_rows(nq_any* e, const nq_any::Plan& pl, const cd* src, 
   }
   return 0;
 }
+template <int R>
+static int any_split_rows(nq_any* e, const nq_any::Plan& pl, const cd* src, cd* dst, int nlines, int n, int inverse) {
+  const double scale = inverse ? 1.0 / (double)n : 1.0;
+  switch (pl.M) {
+#define CASE_(m, a, b) case m: { typedef XPlan<m> X; \
+      hipLaunchKernelGGL((k_any_split_rows<m, R>), dim3((nlines + X::C - 1) / X::C), dim3(X::THREADS), X::LDS_BYTES, e->stream, src, dst, nlines, n, \
+                         (const cd*)pl.chirp, (const cd*)pl.tw, inverse ? 1 : 0, scale); } break;
+    M_SMALL(CASE_)
+#undef CASE_
+    default: ANYFAIL(e, -2, "any-size engine: no split row plan of length %d x %d", R, pl.M);
+  }
+  return 0;
+}
 static int any_buf(nq_any* e, cd** buf, size_t* have, size_t elems) {
   if (*have >= elems) return 0;
   if (*buf) {
@@ -3802,8 +3815,21 @@ static int any_plan(nq_any* e, int n, const nq_any::Plan** out) {
   pl.n = n;
   pl.direct = pow2;
   pl.M = 64;
+  static int use_split = -1;
+  if (use_split < 0) {
+    const char* ev = getenv("NIWQG_AMD_ANY_SPLIT");              // 0: Bluestein for 3 m and 5 m as well (A/B measurements)
+    use_split = (ev && atoi(ev) == 0) ? 0 : 1;
+  }
+  for (int R : {3, 5}) {
+    const int m = n / R;
+    if (use_split && !pow2 && n % R == 0 && m >= 64 && m <= 2048 && (m & (m - 1)) == 0) {
+      pl.split = R;
+      pl.M = m;
+      break;
+    }
+  }
   if (pow2) pl.M = n;
-  else
+  else if (!pl.split)
     while (pl.M < 2 * n - 1) pl.M *= 2;
   const int M = pl.M;
   const long double pi = 3.14159265358979323846264338327950288L;
@@ -3825,7 +3851,17 @@ static int any_plan(nq_any* e, int n, const nq_any::Plan** out) {
     ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.tw_small), sizeof(cd) * 128));
     ANYCHK(e, hipMemcpy(pl.tw_small, ts.data(), sizeof(cd) * 128, hipMemcpyHostToDevice));
   }
-  if (!pl.direct) {
+  if (pl.split) {
+    // chirp slot: exp(-2 pi i q / n), q < n -- the twiddles of the radix-R combination
+    std::vector<double> wn(2 * (size_t)n);
+    for (int q = 0; q < n; ++q) {
+      const long double a = -2.0L * pi * (long double)q / (long double)n;
+      wn[2 * q] = (double)cosl(a);
+      wn[2 * q + 1] = (double)sinl(a);
+    }
+    ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&pl.chirp), sizeof(cd) * n));
+    ANYCHK(e, hipMemcpy(pl.chirp, wn.data(), sizeof(cd) * n, hipMemcpyHostToDevice));
+  } else if (!pl.direct) {
     std::vector<double> w(2 * (size_t)n), b(2 * (size_t)M, 0.0);
     for (int j = 0; j < n; ++j) {
       const long long r = ((long long)j * j) % (2LL * n);
@@ -3951,17 +3987,40 @@ int nq_any_fft(nq_any* e, void* dst, const void* src, int rows, int cols, int ax
     const char* ev = getenv("NIWQG_AMD_ANY_FUSED");             // 0: the unfused five-launch form (A/B measurements)
     fused = (ev && atoi(ev) == 0) ? 0 : 1;
   }
-  if (fused && !pl->direct && pl->M <= 8192) {
-    // one kernel per line (k_any_bluestein_rows); columns through a transpose of the plane
+  auto line_kernel = [&](const cd* a, cd* b, int nl, int len) -> int {
+    if (pl->split == 3) return any_split_rows<3>(e, *pl, a, b, nl, len, inverse);
+    if (pl->split == 5) return any_split_rows<5>(e, *pl, a, b, nl, len, inverse);
+    return any_bluestein_rows(e, *pl, a, b, nl, len, inverse);
+  };
+  if ((fused || pl->split) && !pl->direct && pl->M <= 8192) {
+    // one kernel per line (k_any_bluestein_rows / k_any_split_rows); columns through a transpose of the plane
     if (axis == 1) {
-      rc = any_bluestein_rows(e, *pl, srcp, reinterpret_cast<cd*>(dst), rows, cols, inverse);
-      if (rc) return rc;
+      if (pl->split && srcp == reinterpret_cast<cd*>(dst)) {      // the split kernel writes X[k + m s] while other threads still read x[R j + r]: not in place
+        rc = any_tmp(e, (size_t)rows * cols);
+        if (rc) return rc;
+        rc = line_kernel(srcp, e->tmp, rows, cols);
+        if (rc) return rc;
+        ANYCHK(e, hipMemcpyAsync(dst, e->tmp, (size_t)rows * cols * sizeof(cd), hipMemcpyDeviceToDevice, e->stream));
+      } else {
+        rc = line_kernel(srcp, reinterpret_cast<cd*>(dst), rows, cols);
+        if (rc) return rc;
+      }
     } else {
       rc = any_tmp(e, (size_t)rows * cols);
       if (rc) return rc;
       hipLaunchKernelGGL(k_any_btranspose, dim3((cols + 15) / 16, (rows + 15) / 16, 1), dim3(256), 0, e->stream, (const cd*)srcp, e->tmp, rows, cols,
                          (const cd*)nullptr, 0, 0);
-      rc = any_bluestein_rows(e, *pl, e->tmp, e->tmp, cols, rows, inverse);
+      if (pl->split) {                                           // (not in place, see above: tmp -> tmp2)
+        rc = any_buf(e, &e->tmp2, &e->tmp2_elems, (size_t)rows * cols);
+        if (rc) return rc;
+        rc = line_kernel(e->tmp, e->tmp2, cols, rows);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_any_btranspose, dim3((rows + 15) / 16, (cols + 15) / 16, 1), dim3(256), 0, e->stream, (const cd*)e->tmp2, reinterpret_cast<cd*>(dst), cols, rows,
+                           (const cd*)nullptr, 0, 0);
+        ANYCHK(e, hipGetLastError());
+        return 0;
+      }
+      rc = line_kernel(e->tmp, e->tmp, cols, rows);
       if (rc) return rc;
       hipLaunchKernelGGL(k_any_btranspose, dim3((rows + 15) / 16, (cols + 15) / 16, 1), dim3(256), 0, e->stream, (const cd*)e->tmp, reinterpret_cast<cd*>(dst), cols, rows,
                          (const cd*)nullptr, 0, 0);

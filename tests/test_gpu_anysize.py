@@ -19,11 +19,12 @@ def models():
     return niwqg_amd
 
 
-@pytest.mark.parametrize("nx", [4, 6, 10, 16, 30, 32, 48, 96, 100, 192, 250, 384, 1000, 1536, 3000])
+@pytest.mark.parametrize("nx", [4, 6, 10, 16, 30, 32, 48, 96, 100, 192, 250, 320, 384, 640, 1000, 1536, 2560, 3000, 3072])
 def test_fft_seam_of_any_length_against_numpy(nx):
     """Kernel.fft / ifft (numpy.fft.fft2 / ifft2 semantics, ref niwqg/Kernel.py:562-566) and QGModel.fft / ifft (rfft2 / irfft2,
-    QGModel.py:551-552) through Bluestein on the device: lengths with factors 3, 5, 7 ..., powers of two below the fused range,
-    the largest work rows (3000 -> 8192)."""
+    QGModel.py:551-552) on the device: Bluestein for lengths with factors 3, 5, 7 ..., powers of two below the fused range, the
+    largest in-register work rows (3000 -> 8192); the radix-3 / radix-5 split for 3 m and 5 m with m a power of two >= 64 (192, 320,
+    384, 640, 1536, 2560, 3072)."""
     rng = np.random.default_rng(nx)
     m = models().UnCoupledModel.Model(nx=nx)
     assert getattr(m, "_any_size", False) and type(m).__name__ == "Model"

@@ -51,15 +51,17 @@ CANONICAL_B_PER_PT_STEP = {"coupled": 3136, "uncoupled": 2240, "qg": 848, "ybj":
 #  y_A       : in-place radix-S2 sub-pass, 32 B/pt per complex-plane equivalent (16 read + 16 written); per stage
 #              W (1) + uq,vq (2 half = 1) + phi,phiy (2) + a,b (1) + u,psi,q,qw (4 half = 2) = 7 planes in 5 launches
 #  s_phi     : tendency in 16, phi and phi_y out 32, ETDRK4 state + coefficient planes 80/80/112/128 in the four stages
-#              (mean 100), start-of-stage phih for the budget projections 12 (3 of 4 stages)
+#              (mean 100), start-of-stage phih for the budget projections 12 (3 of 4 stages); round 4: rows l and N - l share one
+#              coefficient row (mirrored planes), i.e. the coefficient part (32/32/32/64, mean 40) counts half: 160 -> 140
 #  x_wavepv  : phi, phi_y rows in 32, two half-spectrum rows out 16;  s_q: 2 half rows in 16, state + coefficients 50
+#              (coefficients 20 of them: 66 -> 56 with mirrored rows)
 #  s_invert  : 2 half rows in 16, q-hat 8, filter 4, four half rows out 32, psi-hat and qw-hat stored in the last stage 4
 KERNEL_B_PER_PT = {
-    "coupled": {"x_products": 96.0, "s_phi": 160.0, "x_wavepv": 48.0, "s_q": 66.0, "s_invert": 64.0, "y_A": 7 * 32.0 / 5},
-    "uncoupled": {"x_products": 3 * 8 + 3 * 16 + 2 * 8 + 16, "s_phi": 160.0, "s_q": 66.0, "s_invert": 44.0,
+    "coupled": {"x_products": 96.0, "s_phi": 140.0, "x_wavepv": 48.0, "s_q": 56.0, "s_invert": 64.0, "y_A": 7 * 32.0 / 5},
+    "uncoupled": {"x_products": 3 * 8 + 3 * 16 + 2 * 8 + 16, "s_phi": 140.0, "s_q": 56.0, "s_invert": 44.0,
                   "y_A": (1 + 1 + 2 + 1.5) * 32.0 / 4},
-    "qg": {"x_products": 3 * 8 + 2 * 8, "s_q": 66.0, "s_invert": 44.0, "y_A": (1 + 1.5) * 32.0 / 2},
-    "ybj": {"x_products": 3 * 8 + 3 * 16 + 2 * 8 + 16, "s_phi": 148.0, "y_A": (1 + 2) * 32.0 / 2},
+    "qg": {"x_products": 3 * 8 + 2 * 8, "s_q": 56.0, "s_invert": 44.0, "y_A": (1 + 1.5) * 32.0 / 2},
+    "ybj": {"x_products": 3 * 8 + 3 * 16 + 2 * 8 + 16, "s_phi": 128.0, "y_A": (1 + 2) * 32.0 / 2},
 }
 KERNEL_SYMBOL = {"x_products": "k_x_products", "s_phi": "k_s_phi", "x_wavepv": "k_x_wavepv", "s_q": "k_s_q",
                  "s_invert": "k_s_invert", "y_A": "k_y_A"}

@@ -1928,8 +1928,7 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
     }
   }
   if (p->model < 0 || p->model > 2) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: unknown model %d", p->model);
-  if (P < 1 || rank < 0 || rank >= P || (P & (P - 1)) || p->nx / P < CL ||
-      (P > 1 && (p->nx / 2 + 1 + P - 1) / P >= 2048))
+  if (P < 1 || rank < 0 || rank >= P || (P & (P - 1)) || p->nx / P < CL)
     NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: %d ranks unsupported for nx=%d (power of two, at least %d columns per rank)", P, p->nx, CL);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: no HIP device available");

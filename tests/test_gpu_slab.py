@@ -216,13 +216,14 @@ def test_two_processes_one_gpu_host_staged_collectives(tmp_path):
     assert "two processes agree with one context" in out.stdout
 
 
-def test_config4_8192_on_8_virtual_ranks_against_the_oracle():
-    """BASELINE config 4 (CoupledModel 8192^2 slab-decomposed over 8 ranks), all 8 ranks on this one GPU.
+@pytest.mark.parametrize("nranks,nchunks", [(8, 4), (2, 1), (4, 2)])
+def test_config4_8192_on_virtual_ranks_against_the_oracle(nranks, nchunks):
+    """BASELINE config 4 (CoupledModel 8192^2 slab-decomposed over 8 ranks; also over 2 and 4), all ranks on this one GPU.
     Truth: the reference-pinned oracle at 128^2 on the same band-limited state (the step is exact at any resolution
     that holds the band; see test_gpu_models.test_full_size_parity_through_resolution_independence)."""
     from niwqg_amd import _lib, slab
     from test_gpu_models import _band_limited_state, _low_modes
-    nx, nranks, nsteps = 8192, 8, 2
+    nx, nsteps = 8192, 2
     kw = notebook_kwargs(64, False)
     kw.update(nx=128)
     o = O.NIWQGOracle("coupled", **kw)
@@ -238,7 +239,7 @@ def test_config4_8192_on_8_virtual_ranks_against_the_oracle():
                 nu4w=kw["nu4w"], muw=kw["muw"])
     filtr = np.ones((nx, nx))
     ranks = slab.make_ranks(_lib.COUPLED, nx, big.kk, big.ll, filtr, kw["dt"], nranks, budgets=True, **phys)
-    sim = slab.SlabSimulation(ranks, "peers", nchunks=4)
+    sim = slab.SlabSimulation(ranks, "peers", nchunks=nchunks)
     sim.set_q(q1)
     sim.set_phi(phi1)
     del q1, phi1
@@ -257,7 +258,7 @@ def test_config4_8192_on_8_virtual_ranks_against_the_oracle():
     gotq = qh[np.ix_(rows, np.arange(M + 1))] / nx ** 2 * np.exp(-1j * (big.kk[:M + 1][None, :] * x0
                                                                            + big.ll[rows][:, None] * y0))
     assert np.abs(gotq - refq).max() < 1e-11 * np.abs(refq).max()
-    inc = ranks[3].budget_increments()
+    inc = ranks[nranks - 1].budget_increments()
     o0 = O.NIWQGOracle("coupled", **dict(kw, nx=128))
     o0.set_q(q0)
     o0.set_phi(phi0)

@@ -119,6 +119,11 @@ class Model(object):
             return d[name]
         if name == "lapc" and self.__dict__.get("passive_scalar"):      # the array the reference leaves behind after a tick
             return self.ifft(-self.wv2 * self.ch)
+        if name in ("C2", "gradC2", "Gamma_c") and self.__dict__.get("passive_scalar") and "_ctx" in self.__dict__:
+            # every stage of the reference's step ends in _calc_derived_fields (QGModel.py:351, :365, :378, :391): after a step the
+            # three are those of the NEW c-hat (Gamma_c with the fourth stage's u, v, as at a tick), tick or no tick
+            self._calc_derived_fields()
+            return self.__dict__[name]
         fields = {"q": _lib.F_Q, "qh": _lib.F_QH, "p": _lib.F_P, "ph": _lib.F_PH, "u": _lib.F_U, "v": _lib.F_V}
         if self.__dict__.get("passive_scalar"):
             fields.update(c=_lib.F_C, ch=_lib.F_CH)
@@ -256,6 +261,9 @@ class Model(object):
             self.Ke += self._ctx.scalar(_lib.S_KE)
             if self.passive_scalar:
                 self.cvar += self._ctx.scalar(_lib.S_PW)        # ref: niwqg/QGModel.py:394
+        if self.passive_scalar:
+            for k in ("C2", "gradC2", "Gamma_c"):               # recomputed by the step itself in the reference: lazily here
+                self.__dict__.pop(k, None)
 
     def _snapshot_fields(self):
         """the reference always asks for 't', 'q', 'c' (niwqg/QGModel.py:221); c exists only with the passive scalar"""

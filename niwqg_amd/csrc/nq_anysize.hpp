@@ -88,16 +88,30 @@ __global__ void __launch_bounds__(256) k_any_reduce1(int op, const cd* __restric
     part[2 * blockIdx.x + 1] = sy[0];
   }
 }
-__global__ void k_any_reduce2(int op, const double* __restrict__ part, int nblocks, double* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// stage 2: one workgroup, a fixed tree (thread t takes partials t, t + 256, ... in order, then a power-of-two tree in LDS): the
+// same summation order on every run, a few microseconds instead of a 1024-long serial chain of dependent loads
+__global__ void __launch_bounds__(256) k_any_reduce2(int op, const double* __restrict__ part, int nblocks, double* __restrict__ out) {
   const bool mx = (op == RD_MAXABS || op == RD_MAXABSRE);
   double x = 0.0, y = 0.0;
-  for (int i = 0; i < nblocks; ++i) {
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
     x = mx ? fmax(x, part[2 * i]) : x + part[2 * i];
     y += part[2 * i + 1];
   }
-  out[0] = x;
-  out[1] = y;
+  __shared__ double sx[256], sy[256];
+  sx[threadIdx.x] = x;
+  sy[threadIdx.x] = y;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sx[threadIdx.x] = mx ? fmax(sx[threadIdx.x], sx[threadIdx.x + s]) : sx[threadIdx.x] + sx[threadIdx.x + s];
+      sy[threadIdx.x] += sy[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sx[0];
+    out[1] = sy[0];
+  }
 }
 
 // ---- Bluestein: pack / unpack between a (rows, cols) plane and the work rows tmp[line][M] ------------------------------

@@ -4072,7 +4072,7 @@ int nq_any_reduce(nq_any* e, int op, const void* a, const void* b, long long ele
   const size_t n = (size_t)elems;
   const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(k_any_reduce1, dim3(grid), dim3(256), 0, e->stream, op, reinterpret_cast<const cd*>(a), reinterpret_cast<const cd*>(b), n, e->part);
-  hipLaunchKernelGGL(k_any_reduce2, dim3(1), dim3(64), 0, e->stream, op, (const double*)e->part, grid, e->red);
+  hipLaunchKernelGGL(k_any_reduce2, dim3(1), dim3(256), 0, e->stream, op, (const double*)e->part, grid, e->red);
   ANYCHK(e, hipMemcpyAsync(out2, e->red, sizeof(double) * 2, hipMemcpyDeviceToHost, e->stream));
   return nq_any_sync(e);
 }

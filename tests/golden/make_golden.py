@@ -35,6 +35,10 @@ Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
   g16_coupled_lamb_<nx>_100steps.npz  the REAL reference, CoupledModel LambDipole (filter on) at 1024^2 / 2048^2 after 50 and 100
                           steps: projections, sub-samples, spectral corners, norms, budgets (round 4; not in the default list)
   g17_non_power_of_two.npz  the REAL reference on 96^2 and 192^2 grids, CoupledModel and QGModel, 1 / 10 / 100 steps (round 4)
+  g18_families_1024_100steps.npz  the REAL reference at 1024^2 for the other three model families, 50 and 100 steps with the
+                          diagnostics ticking every 10 steps: UnCoupledModel (BASELINE config 5, member 3), YBJModel (dipole + wave
+                          packet), QGModel with beta and its passive scalar: projections, sub-samples, norms, budgets, the
+                          diagnostics series (round 4; ~15 minutes here; not in the default list)
   g14_instance_attributes.npz  what a freshly constructed instance of each of the four model classes carries (nx = 64, every other
                           argument at its default): names and values of the scalar attributes, names, shapes, dtypes and two
                           checksums of the array attributes
@@ -530,6 +534,58 @@ def g16(sizes=None):
             print("g16: nx", nx, "step", n, "done", flush=True)
         save("g16_coupled_lamb_%d_100steps.npz" % nx, **out)
         del m
+
+
+def g18():
+    """round 4: the REAL reference at 1024^2 for the three model families golden g16 does not cover, 50 and 100 steps,
+    tdiags = 10 (so the diagnostics tick ten times inside the horizon and UnCoupledModel's quirk Q1 -- phix, phiy refreshed only
+    by the tick, niwqg/Kernel.py:608-611 -- acts at size)."""
+    nx = 1024
+    out = {}
+
+    def record(tag, m, fields, scalars):
+        for n in (50, 100):
+            step_to(m, n)
+            t = "%s_s%d_" % (tag, n)
+            norms = []
+            for i, name in enumerate(fields):
+                a = getattr(m, name)
+                out[t + name + "_proj"] = projections(a, 500 + i)
+                out[t + name + "_sub"] = a[::nx // 64, ::a.shape[1] // 64 if a.shape[1] >= 64 else 1].copy()
+                norms.append(np.linalg.norm(a))
+            out[t + "norms"] = np.array(norms)
+            out[t + "scalars"] = np.array([getattr(m, k) for k in scalars], dtype=float)
+            print("g18:", tag, "step", n, "done", flush=True)
+        for name, d in m.diagnostics.items():
+            out["%s_diag_%s" % (tag, name)] = np.asarray(d["value"], dtype=float)
+
+    # UnCoupledModel: BASELINE config 5, member 3 (SURVEY 8d C5; niwqg_amd/ensemble.py config5_member)
+    kw = notebook_kwargs(nx, True, 100, tdiags=10)
+    m = UnCoupledModel.Model(**kw)
+    m.set_q(1e-5 * np.random.default_rng(3).standard_normal((nx, nx)))
+    m.set_phi(0.1 * ic.WavePacket(m, k=3 * K0, l=0, R=L / 6, x0=L / 2, y0=L / 2))
+    record("unc", m, ["q", "phi", "qh", "phih", "phix", "phiy"], ["Ke", "Pw", "Kw"])
+    del m
+    # YBJModel: steady dipole, wave packet on a uniform wave (g8's state at size)
+    kw = notebook_kwargs(nx, True, 100, tdiags=10)
+    kw.update(nu4w=3e9 * (64.0 / nx) ** 4, muw=1e-7)
+    m = YBJModel.Model(**kw)
+    q0 = ic.LambDipole(m, U=U0, R=2 * np.pi / K0)
+    out["ybj_q0_sub"], out["ybj_q0_norm"] = q0[::nx // 64, ::nx // 64].copy(), np.array(np.linalg.norm(q0))
+    m.set_q(q0)
+    m.set_phi(0.2 * ic.WavePacket(m, k=2 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2) + 0.05)
+    record("ybj", m, ["phi", "phih", "phix", "phiy"], ["Ke", "Pw", "Kw"])
+    del m
+    # QGModel with beta and the passive scalar (g10's state at size)
+    dt = 0.05 * TE * 128 / nx / 2
+    m = QGModel.Model(L=L, nx=nx, tmax=(100 - 0.5) * dt, dt=dt, twrite=10 ** 9, nu4=7.5e8 * (256.0 / nx) ** 4, nu=5.0,
+                      mu=1e-8, use_filter=True, U=-U0, tdiags=10, beta=2e-11, passive_scalar=True,
+                      nu4c=3e9 * (64.0 / nx) ** 4, nuc=2.0, muc=1e-8, save_to_disk=False)
+    out["qgc_params"] = np.array([dt, m.nu4, m.nu4c])
+    m.set_q(q0)
+    m.set_c(np.sin(2 * np.pi * 3 * m.x / L) * np.cos(2 * np.pi * 2 * m.y / L) + 0.3)
+    record("qgc", m, ["q", "c", "qh", "ch"], ["Ke", "cvar", "C2", "gradC2"])
+    save("g18_families_1024_100steps.npz", **out)
 
 
 def g17():

@@ -549,6 +549,31 @@ def test_qg_passive_scalar_against_the_reference(golden, use_filter):
         assert np.allclose(np.asarray(m.diagnostics[name]['value']), ref, rtol=tol, atol=1e-30), name
 
 
+def test_qg_passive_scalar_attributes_between_ticks():
+    """Every stage of the reference's QGModel step ends in _calc_derived_fields (ref niwqg/QGModel.py:351, :365, :378, :391,
+    :724-737): C2, gradC2, lapc and Gamma_c (the latter with the fourth stage's u, v) are those of the new c-hat after EVERY
+    step, not only after a diagnostics tick.  Found by golden g18 (tdiags = 10); here against the oracle after steps without a
+    tick, and after a tick."""
+    kw = dict(L=L, nx=64, tmax=1e30, dt=0.05 * TE, twrite=10 ** 9, nu4=7.5e8 * 16, nu=5.0, mu=1e-8, use_filter=True, U=-U0,
+              tdiags=4, beta=2e-11, passive_scalar=True, nu4c=3e9, nuc=2.0, muc=1e-8)
+    o = O.QGOracle(**kw)
+    m = models().QGModel.Model(**kw)
+    q0 = O.lamb_dipole(o.grid, U=U0, R=2 * np.pi / K0)
+    c0 = np.sin(2 * np.pi * 3 * o.grid.x / L) * np.cos(2 * np.pi * 2 * o.grid.y / L) + 0.3
+    for x in (o, m):
+        x.set_q(q0)
+        x.set_c(c0)
+    for n in (1, 3, 5, 8, 9):                      # ticks fall on steps 1, 5, 9 (tc = 0, 4, 8 before the clock advances)
+        while o.tc < n:
+            o._step_forward()
+            m._step_forward()
+        got = [m.C2, m.gradC2, m.Gamma_c, m.cvar]
+        ref = [o.C2, o.gradC2, o.Gamma_c, o.cvar]
+        assert np.allclose(got[:2] + got[3:], ref[:2] + ref[3:], rtol=1e-11), (n, got, ref)
+        assert abs(got[2] - ref[2]) < 1e-7 * abs(ref[2]) + 1e-30, (n, got[2], ref[2])    # a nearly vanishing integral
+        assert rel(m.lapc, o.lapc) < 1e-12
+
+
 def test_long_run_500_steps_stays_within_the_baseline_tolerance():
     """BASELINE asks fp64 field RMS error < 1e-10 over 100 steps; five times that horizon at 128^2 with the wave packet
     (filter on), against the oracle stepping beside it (the budget accumulators included)."""

@@ -53,7 +53,11 @@ enum {
   NQ_F_PHIH_STAGE4 = 17,      /* cplx (ny,nx) phih of that same stage (Kernel family): with NQ_F_QH_STAGE4 it determines the
                                  self.u, self.v a step leaves behind -- the reference's last jacobian_psi_q call of a step is
                                  the fourth stage's (Kernel.py:364-368 vs :381-387), not the new state's                     */
-  NQ_F_QH_MINUS_STAGE4 = 18   /* the second copy (NQ_F_QH_MINUS) of that stage, dual_q contexts                              */
+  NQ_F_QH_MINUS_STAGE4 = 18,  /* the second copy (NQ_F_QH_MINUS) of that stage, dual_q contexts                              */
+  NQ_F_QH_TICK = 19,          /* qh, phih, the second copy of qh and qwh as the last nq_tick_snapshot kept them: what the      */
+  NQ_F_PHIH_TICK = 20,        /* reference's tick-only leftovers (upsilon Kernel.py:618; phq, phw, uq, vq, uw, vw              */
+  NQ_F_QH_MINUS_TICK = 21,    /* CoupledModel.py:99-113; YBJModel's lapphi) are rebuilt from between ticks                     */
+  NQ_F_QWH_TICK = 22
 };
 
 /* scalar ids for nq_get_scalar */
@@ -122,6 +126,11 @@ int nq_step(nq_ctx* ctx, int nsteps);
  * u, v from psi: QGModel.py:621-629; YBJModel's u, v are steady). */
 int nq_request_stage4_max(nq_ctx* ctx);
 int nq_get_stage4_max(nq_ctx* ctx, double* out2);
+/* Keep this rank's qh (both copies), phih and qwh as they are NOW (device-to-device, asynchronous; four planes allocated by the
+ * first call): the host classes call it at every diagnostics tick (Diagnostics.py:41-58), because some of the arrays a tick
+ * leaves on the reference's instance are refreshed by nothing else (see NQ_F_QH_TICK).  Read back with nq_get_field
+ * (NQ_F_*_TICK) or nq_download_spectral (which 9-12). */
+int nq_tick_snapshot(nq_ctx* ctx);
 int nq_sync(nq_ctx* ctx);
 
 /* copy a field to the host in the reference's layout (blocking) */
@@ -229,7 +238,7 @@ int nq_group_buffers(nq_ctx* ctx, int group, void** x_side, void** y_side, long 
 /* local column slab of qh (which 0: (ny, local half-spectrum columns)) or phih (which 1: (ny, nx/nranks)); download also
  * which 2: ph, 3: qwh, 4: the second copy of qh of a dual_q context, 5: ch of QGModel's passive scalar, 6: the q-hat the
  * last step's fourth stage was evaluated at (NQ_F_QH_STAGE4) (half-spectrum slabs like qh), 7: the phih of that stage (like
- * which 1), 8: the second copy of qh of that stage (like which 4) */
+ * which 1), 8: the second copy of qh of that stage (like which 4), 9-12: nq_tick_snapshot's qh, phih, second copy of qh, qwh */
 int nq_upload_spectral(nq_ctx* ctx, int which, const double* host);
 int nq_download_spectral(nq_ctx* ctx, int which, double* host);
 enum {

@@ -28,10 +28,11 @@ class Model(Kernel.Kernel):
 
     def __getattr__(self, name):
         if name in Model._TICK_FIELDS:
+            stale = self.__dict__.get("_tick_stale")            # steps since the last tick: the tick's spectra (Kernel._tick_field)
             if name == "phq":
-                return -self.wv2i * self.qh
+                return -self.wv2i * (self._tick_field("qh") if stale else self.qh)
             if name == "phw":
-                return self.wv2i * self.qwh
+                return self.wv2i * (self._tick_field("qwh") if stale else self.qwh)
             ph = self.phq if name[1] == "q" else self.phw
             return self.ifft((-self.il if name[0] == "u" else self.ik) * ph).real
         return super(Model, self).__getattr__(name)

@@ -46,3 +46,6 @@ def increment_diagnostics(model):
                 d['value'] = 0.5 * (d['value'] + res)
             else:
                 d['value'] = res
+        snap = getattr(model, "_tick_snapshot", None)
+        if snap is not None:                 # what only a tick refreshes stays the tick's until the next one (Kernel._tick_snapshot)
+            snap()

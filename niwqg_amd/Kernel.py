@@ -171,10 +171,17 @@ class Kernel(object):
         if name == "c":                  # the linear operator the reference leaves behind: the wave equation's (Kernel.py:440-442)
             advect = np.zeros((self.nl, self.nk), complex) - 1j * self.k * self.U
             return advect + (-self.nu4w * self.wv4 - 0.5j * self.f * (self.wv2 / self.kappa2) - self.nuw * self.wv2 - self.muw)
-        if name == "lapphi":             # fields the reference leaves behind after a diagnostics tick, on demand
-            return self.ifft(-self.wv2 * self.phih)
+        if name in Kernel._EC_NAMES and self.__dict__.get("_ec_stage4") and "_ctx" in self.__dict__:
+            self._energy_conversion_of_stage4()
+            return self.__dict__[name]
+        if name == "lapphi":             # what the last _calc_energy_conversion left behind: a step's fourth stage's, or a tick's
+            if self.__dict__.get("_ec_stage4"):
+                if "lapphi" not in self._cache:
+                    self._energy_conversion_of_stage4()
+                return self._cache["lapphi"]
+            return self.ifft(-self.wv2 * (self._tick_field("phih") if self.__dict__.get("_tick_stale") else self.phih))
         if name == "upsilon":
-            a2 = np.abs(self.phi) ** 2
+            a2 = np.abs(self._tick_field("phi") if self.__dict__.get("_tick_stale") else self.phi) ** 2
             return a2 - a2.mean()
         if self.__dict__.get("model_id", type(self).model_id) == _lib.COUPLED:
             # what CoupledModel._invert leaves behind (ref: niwqg/CoupledModel.py:83-92), on demand through the FFT seam
@@ -224,22 +231,53 @@ class Kernel(object):
         self._cache.clear()
         self._user.clear()
 
+    def _full_qh(self, half, minus, passenger):
+        """the reference's (ny, nx) qh from the device's half spectrum"""
+        n = self.nx
+        v = hermitian_full(half)
+        if minus is not None:           # k < 0 side from the second copy: qh(-l,-k) = conj(X-(l,k))
+            inner = minus[:, 1:n // 2]
+            v[:, n // 2 + 1:] = np.conj(np.roll(inner[::-1, :], 1, axis=0))[:, ::-1]
+        else:                           # the anti-Hermitian passenger of row ny/2 (ref Kernel.py:471-486, :327), one device row
+            a = passenger[1:n // 2]
+            v[n // 2, 1:n // 2] += a
+            v[n // 2, n // 2 + 1:] -= np.conj(a)[::-1]
+        return v
+
+    # What only a diagnostics tick refreshes on the reference's instance -- upsilon (Kernel.py:618, inside the 'skew' diagnostic),
+    # CoupledModel's phq, phw, uq, vq, uw, vw (CoupledModel.py:99-113), YBJModel's lapphi (its step never calls
+    # _calc_energy_conversion) -- stays the TICK's until the next tick, however many steps follow (golden g19).  The tick keeps the
+    # spectra they derive from on the device (nq_tick_snapshot); the arrays are rebuilt from those on demand.
+    _tick_stale = _tick_taken = False
+
+    def _tick_snapshot(self):
+        self._ctx.tick_snapshot()
+        self._tick_passenger = None if self._dual else self._ctx.qh_passenger()
+        self._tick_taken, self._tick_stale = True, False
+        self._tick_cache = {}
+
+    def _tick_field(self, name):
+        """qh, qwh (full planes), phih, phi of the last tick"""
+        t, c = self._tick_cache, self._ctx
+        if name not in t:
+            if name == "qh":
+                t[name] = self._full_qh(c.field(_lib.F_QH_TICK), c.field(_lib.F_QH_MINUS_TICK) if self._dual else None, self._tick_passenger)
+            elif name == "qwh":
+                t[name] = hermitian_full(c.field(_lib.F_QWH_TICK))
+            elif name == "phih":
+                t[name] = c.field(_lib.F_PHIH_TICK)
+            elif name == "phi":
+                t[name] = self.ifft(self._tick_field("phih"))
+        return t[name]
+
     def _field(self, name):
         if name in self._user:
             return self._user[name]
         if name not in self._cache:
             c = self._ctx
             if name == "qh":
-                v = hermitian_full(c.field(_lib.F_QH))
-                if self._dual:          # k < 0 side from the second copy: qh(-l,-k) = conj(X-(l,k))
-                    n = self.nx
-                    inner = c.field(_lib.F_QH_MINUS)[:, 1:n // 2]
-                    v[:, n // 2 + 1:] = np.conj(np.roll(inner[::-1, :], 1, axis=0))[:, ::-1]
-                else:                   # the anti-Hermitian passenger of row ny/2 (ref Kernel.py:471-486, :327), one device row
-                    n = self.nx
-                    a = c.qh_passenger()[1:n // 2]
-                    v[n // 2, 1:n // 2] += a
-                    v[n // 2, n // 2 + 1:] -= np.conj(a)[::-1]
+                v = self._full_qh(c.field(_lib.F_QH), c.field(_lib.F_QH_MINUS) if self._dual else None,
+                                  None if self._dual else c.qh_passenger())
             elif name == "ph":
                 v = hermitian_full(project_self_mirrored_columns(c.field(_lib.F_PH)))
             elif name == "qwh":
@@ -264,23 +302,52 @@ class Kernel(object):
     _uv_stage4 = False
 
     def _uv_of_stage4(self):
+        return self._fields_of_stage4()[:2]
+
+    def _fields_of_stage4(self):
+        """u, v, q_psi, phi, phih, phix, phiy as the fourth stage of the last step saw them (ref Kernel.py:355-368: the third
+        update, phi = ifft(phih), _invert, _calc_rel_vorticity)"""
         c, n = self._ctx, self.nx
         qh4 = c.field(_lib.F_QH_STAGE4)
         if self._dual:                   # physical space sees the Hermitian part: the mean of the two copies
             qh4[:, 1:n // 2] = 0.5 * (qh4[:, 1:n // 2] + c.field(_lib.F_QH_MINUS_STAGE4)[:, 1:n // 2])
         qh4 = hermitian_full(qh4)
         pv = self.ifft(-(self.wv2i * qh4)).real
+        q4 = self.ifft(qh4).real
+        phih4 = c.field(_lib.F_PHIH_STAGE4)
+        phi4 = self.ifft(phih4)
         if self.model_id == _lib.COUPLED:
-            phih4 = c.field(_lib.F_PHIH_STAGE4)
-            phi4 = self.ifft(phih4)
             phix, phiy = self.ifft(self.ik * phih4), self.ifft(self.il * phih4)
             jh = self.fft((1j * (np.conj(phix) * phiy - np.conj(phiy) * phix)).real)
             jh[0, 0] = 0
             qwh = 0.5 * (0.5 * (-self.wv2 * self.fft(np.abs(phi4) ** 2)) + jh) / self.f
             qwh *= self.filtr
             pv = pv + self.ifft(self.wv2i * qwh).real
+            q4 = q4 - self.ifft(qwh).real                    # q_psi (CoupledModel.py:145-152)
+        else:
+            phix, phiy = self.phix, self.phiy                # as last refreshed (quirk Q1: UnCoupledModel._invert leaves them)
         ph4 = self.fft(pv)
-        return self.ifft(-self.il * ph4).real, self.ifft(self.ik * ph4).real
+        return self.ifft(-self.il * ph4).real, self.ifft(self.ik * ph4).real, q4, phi4, phih4, phix, phiy
+
+    # The same holds for what _calc_energy_conversion leaves behind: _step_etdrk4 calls it at the start of every stage (Kernel.py:
+    # 319, :338, :355, :370), so after a step gamma1, gamma2, xi1, xi2, pi and lapphi are the FOURTH stage's until a diagnostics
+    # tick recomputes them from the new state (golden g19).  Rebuilt on demand with the reference's expressions (Kernel.py:682-701).
+    _EC_NAMES = ("gamma1", "gamma2", "xi1", "xi2", "pi")
+    _ec_stage4 = False
+
+    def _energy_conversion_of_stage4(self):
+        u, v, q_psi, phi, phih, phix, phiy = self._fields_of_stage4()
+        adv = u * phix + v * phiy
+        lapphi = self.ifft(-self.wv2 * phih)
+        diss = -self.nu4w * self.ifft(self.wv4 * phih) + self.nuw * lapphi - self.muw * phi
+        div_fw = 0.5 * self.hslash * (np.conj(phi) * lapphi).imag
+        d = self.__dict__
+        d["gamma1"] = (0.5 * q_psi * div_fw).mean() / self.f
+        d["gamma2"] = 0.5 * self.hslash * ((np.conj(lapphi) * adv).real).mean() / self.f
+        d["xi1"] = (-(diss * np.conj(adv)).imag).mean() / self.f
+        d["xi2"] = (0.5 * (diss * np.conj(phi)).real * q_psi).mean() / self.f
+        d["pi"] = (0.5 * phi.mean() * (q_psi * np.conj(phi)).mean()).imag
+        self._cache["lapphi"] = lapphi
 
     # ------------------------------------------------------------------ public API of the reference
     def fft(self, x):
@@ -369,6 +436,11 @@ class Kernel(object):
     def _after_steps(self):
         self._dirty()
         self._uv_stage4 = self.model_id != _lib.YBJ          # (YBJModel: psi, u, v are steady)
+        self._ec_stage4 = self._uv_stage4                    # (and its step never calls _calc_energy_conversion)
+        self._tick_stale = self._tick_taken
+        if self._ec_stage4:
+            for k in Kernel._EC_NAMES:
+                self.__dict__.pop(k, None)
         if self._ctx.budgets_enabled:
             dKe, dPw, dKw = self._ctx.take_budget_increments()
             self.Ke += dKe
@@ -540,6 +612,7 @@ class Kernel(object):
         F[u phix + v phiy] and F[phi q_psi] on lap_h and diss_h, pi from two domain means."""
         s, M = self._dsums(), float(self.nx) * self.ny
         M2f = self._M2 * self.f
+        self._ec_stage4 = False
         self.gamma2 = 0.5 * self.hslash * s[24] / M2f
         self.xi1 = s[27] / M2f
         self.gamma1 = 0.25 * self.hslash * s[28] / M2f

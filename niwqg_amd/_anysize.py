@@ -330,6 +330,8 @@ def _etd_final(c, y0, N0, Na, Nb, Nc, F):
 class KernelFamily(object):
     """Mix-in over niwqg_amd.Kernel.Kernel (CoupledModel / UnCoupledModel / YBJModel) for grids without a fused plan: every
     method that touches the device is restated on planes, in the reference's own order of operations."""
+    _tick_snapshot = None            # (the literal sequence leaves the reference's own leftovers: nothing to keep at a tick)
+
 
     _any_size = True
     _REAL = ("q", "p", "q_psi", "u", "v", "qw", "pw", "pv", "phi2")
@@ -734,6 +736,8 @@ class QGFamily(object):
     reference's (ny, nx/2+1) shape, ``fft`` / ``ifft`` numpy.fft.rfft2 / irfft2 semantics built from the engine's c2c transforms
     (forward: both axes on the full plane, first nx/2+1 columns kept; inverse: y transform on the half plane, Hermitian extension in
     x with the imaginary parts of columns 0 and nx/2 dropped -- what numpy.fft.irfft does -- then the x transform)."""
+    _tick_snapshot = None            # (the literal sequence leaves the reference's own leftovers: nothing to keep at a tick)
+
 
     _any_size = True
     _uv_stage4 = False

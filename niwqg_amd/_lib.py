@@ -25,11 +25,11 @@ HEADERS = [os.path.join(HERE, "csrc", h) for h in ("nq_fft.hpp", "nq_generic.hpp
 
 COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
 (F_Q, F_QH, F_P, F_PH, F_PHI, F_PHIH, F_U, F_V, F_QPSI, F_QW, F_QWH, F_PHIX, F_PHIY, F_QH_MINUS, F_C, F_CH, F_QH_STAGE4,
- F_PHIH_STAGE4, F_QH_MINUS_STAGE4) = range(19)
+ F_PHIH_STAGE4, F_QH_MINUS_STAGE4, F_QH_TICK, F_PHIH_TICK, F_QH_MINUS_TICK, F_QWH_TICK) = range(23)
 (S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL, S_MAX_PHI) = range(8)
 
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
-           "nq_step", "nq_request_stage4_max", "nq_get_stage4_max", "nq_sync", "nq_get_field", "nq_get_qh_passenger", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
+           "nq_step", "nq_request_stage4_max", "nq_get_stage4_max", "nq_tick_snapshot", "nq_sync", "nq_get_field", "nq_get_qh_passenger", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
            "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_c", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_coeff_near_contour", "nq_coeff_patch", "nq_diagnostics",
            "nq_stream_copy_gbs", "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
@@ -107,6 +107,7 @@ def lib():
         getattr(L, name).argtypes = [vp, dp, dp]
     L.nq_step.argtypes = [vp, ctypes.c_int]
     L.nq_request_stage4_max.argtypes = [vp]
+    L.nq_tick_snapshot.argtypes = [vp]
     L.nq_get_stage4_max.argtypes = [vp, dp]
     L.nq_get_field.argtypes = [vp, ctypes.c_int, dp]
     L.nq_field_doubles.argtypes = [vp, ctypes.c_int]
@@ -300,6 +301,10 @@ class Context:
     def sync(self):
         self._chk(self.L.nq_sync(self.h), "nq_sync")
 
+    def tick_snapshot(self):
+        """keep qh, phih, qwh as the diagnostics tick sees them (include/niwqg_amd.h: nq_tick_snapshot)"""
+        self._chk(self.L.nq_tick_snapshot(self.h), "nq_tick_snapshot")
+
     def request_stage4_max(self):
         """the last step of the next step() call also records max |u|, max |v| of its fourth stage (include/niwqg_amd.h)"""
         self._chk(self.L.nq_request_stage4_max(self.h), "nq_request_stage4_max")
@@ -313,7 +318,7 @@ class Context:
 
     # --- reads
     _REAL = (F_Q, F_P, F_U, F_V, F_QPSI, F_QW, F_C)
-    _HALF = (F_QH, F_PH, F_QWH, F_QH_MINUS, F_CH, F_QH_STAGE4, F_QH_MINUS_STAGE4)
+    _HALF = (F_QH, F_PH, F_QWH, F_QH_MINUS, F_CH, F_QH_STAGE4, F_QH_MINUS_STAGE4, F_QH_TICK, F_QH_MINUS_TICK, F_QWH_TICK)
 
     def field(self, fid):
         n, h = self.nx, self.nx // 2 + 1

@@ -88,6 +88,8 @@ struct nq_ctx {
   double* filt_m = nullptr;                                                 // filter at (-l, -k)
   // half-spectrum aux spectra
   cd *qwh = nullptr, *ph = nullptr;
+  // nq_tick_snapshot: qh (both copies), phih, qwh as the last diagnostics tick saw them (allocated by the first call)
+  cd *tick_qh = nullptr, *tick_q2 = nullptr, *tick_w = nullptr, *tick_qwh = nullptr;
   // slab decomposition; P == 1: one rank owns everything
   int P = 1, rank = 0;
   int Nloc = 0;          // local rows on the X side
@@ -2546,8 +2548,35 @@ int nq_download_spectral(nq_ctx* c, int which, double* host) {
     if (!c->kernel_family) NQ_FAIL(c, -4, "no wave field in QGModel");
     const cd* src = which == 1 ? c->w.y[c->w.cur] : c->w.y[(c->w.cur + 2) % 3];
     HIPCHK(c, hipMemcpyAsync(host, src, sizeof(cd) * (size_t)c->N * c->Wf, hipMemcpyDeviceToHost, c->stream));
+  } else if (which == 9 || which == 11 || which == 12) {      // nq_tick_snapshot: qh, its second copy, qwh
+    const cd* src = which == 9 ? c->tick_qh : (which == 11 ? c->tick_q2 : c->tick_qwh);
+    if (!src) NQ_FAIL(c, -4, "nq_download_spectral: which = %d: no nq_tick_snapshot yet (or no such plane in this context)", which);
+    if (c->Wh > 0) HIPCHK(c, hipMemcpy2DAsync(host, sizeof(cd) * c->Wh, src, sizeof(cd) * c->Ph, sizeof(cd) * c->Wh, c->N, hipMemcpyDeviceToHost, c->stream));
+  } else if (which == 10) {                                   // ... and phih
+    if (!c->tick_w) NQ_FAIL(c, -4, "nq_download_spectral: which = 10: no nq_tick_snapshot yet (or no wave field)");
+    HIPCHK(c, hipMemcpyAsync(host, c->tick_w, sizeof(cd) * (size_t)c->N * c->Wf, hipMemcpyDeviceToHost, c->stream));
   } else NQ_FAIL(c, -1, "nq_download_spectral: which = %d", which);
   return nq_sync(c);
+}
+// What only a diagnostics tick refreshes in the reference (upsilon: Kernel.py:618; phq, phw, uq, vq, uw, vw: CoupledModel.py:
+// 99-113; YBJModel's lapphi: Kernel.py:685 through the tick's _calc_energy_conversion) stays the TICK's until the next one, however
+// many steps follow.  The host classes rebuild those arrays on demand; this keeps the spectra they derive from: device-to-device
+// copies of this rank's qh (both copies), phih and qwh on the context's stream (planes allocated by the first call).
+int nq_tick_snapshot(nq_ctx* c) {
+  if (!c) return -1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t full = (size_t)c->N * c->Wf, half = (size_t)c->N * c->Ph;
+  if (!c->tick_qh) {
+    ALLOC(c, c->tick_qh, half);
+    if (c->dual) ALLOC(c, c->tick_q2, half);
+    if (c->kernel_family) ALLOC(c, c->tick_w, full);
+    if (c->qwh) ALLOC(c, c->tick_qwh, half);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->tick_qh, c->q.y[c->q.cur], sizeof(cd) * half, hipMemcpyDeviceToDevice, c->stream));
+  if (c->tick_q2) HIPCHK(c, hipMemcpyAsync(c->tick_q2, c->q2.y[c->q2.cur], sizeof(cd) * half, hipMemcpyDeviceToDevice, c->stream));
+  if (c->tick_w) HIPCHK(c, hipMemcpyAsync(c->tick_w, c->w.y[c->w.cur], sizeof(cd) * full, hipMemcpyDeviceToDevice, c->stream));
+  if (c->tick_qwh) HIPCHK(c, hipMemcpyAsync(c->tick_qwh, c->qwh, sizeof(cd) * half, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
 }
 
 // One phase of the distributed step (see "phases of one ETDRK4 stage").  Asynchronous on the stream.
@@ -3278,6 +3307,15 @@ int nq_get_field(nq_ctx* c, int id, double* host) {
       if (!waves) NQ_FAIL(c, -4, "no wave field in QGModel");
       HIPCHK(c, hipMemcpyAsync(host, c->w.y[(c->w.cur + 2) % 3], sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
       return nq_sync(c);
+    case NQ_F_QH_TICK: case NQ_F_QH_MINUS_TICK: case NQ_F_QWH_TICK: {
+      const cd* src = id == NQ_F_QH_TICK ? c->tick_qh : (id == NQ_F_QH_MINUS_TICK ? c->tick_q2 : c->tick_qwh);
+      if (!src) NQ_FAIL(c, -4, "field %d: no nq_tick_snapshot yet (or no such plane in this context)", id);
+      return get_half_spec(c, src, host);
+    }
+    case NQ_F_PHIH_TICK:
+      if (!c->tick_w) NQ_FAIL(c, -4, "NQ_F_PHIH_TICK: no nq_tick_snapshot yet (or no wave field)");
+      HIPCHK(c, hipMemcpyAsync(host, c->tick_w, sizeof(cd) * full, hipMemcpyDeviceToHost, c->stream));
+      return nq_sync(c);
     case NQ_F_C:
       if (!c->passive) NQ_FAIL(c, -4, "no passive scalar in this context");
       return get_real_from_half(c, c->cq.y[c->cq.cur], 0, host);
@@ -3700,8 +3738,9 @@ long long nq_field_doubles(const nq_ctx* c, int id) {
   const long long n = c->N, h = c->N / 2 + 1;
   switch (id) {
     case NQ_F_Q: case NQ_F_P: case NQ_F_U: case NQ_F_V: case NQ_F_QPSI: case NQ_F_QW: case NQ_F_C: return n * n;
-    case NQ_F_QH: case NQ_F_PH: case NQ_F_QWH: case NQ_F_QH_MINUS: case NQ_F_CH: case NQ_F_QH_STAGE4: case NQ_F_QH_MINUS_STAGE4: return 2 * n * h;
-    case NQ_F_PHI: case NQ_F_PHIH: case NQ_F_PHIX: case NQ_F_PHIY: case NQ_F_PHIH_STAGE4: return 2 * n * n;
+    case NQ_F_QH: case NQ_F_PH: case NQ_F_QWH: case NQ_F_QH_MINUS: case NQ_F_CH: case NQ_F_QH_STAGE4: case NQ_F_QH_MINUS_STAGE4:
+    case NQ_F_QH_TICK: case NQ_F_QH_MINUS_TICK: case NQ_F_QWH_TICK: return 2 * n * h;
+    case NQ_F_PHI: case NQ_F_PHIH: case NQ_F_PHIX: case NQ_F_PHIY: case NQ_F_PHIH_STAGE4: case NQ_F_PHIH_TICK: return 2 * n * n;
     default: return -1;
   }
 }

@@ -104,7 +104,7 @@ class SlabRank(object):
         self._chk(self.L.nq_upload_spectral(self.h, which, _lib._dptr(arr.view(np.float64))), "nq_upload_spectral")
 
     def download(self, which):
-        w = self.wf if which in (1, 7) else self.wh     # 0: qh, 2: ph, 3: qwh ... (half-spectrum slabs); 1, 7: phih
+        w = self.wf if which in (1, 7, 10) else self.wh     # 0: qh, 2: ph, 3: qwh ... (half-spectrum slabs); 1, 7, 10: phih
         out = np.empty((self.nx, w), np.complex128)
         self._chk(self.L.nq_download_spectral(self.h, which, _lib._dptr(out.view(np.float64))), "nq_download_spectral")
         return out
@@ -350,6 +350,10 @@ class SlabSimulation(object):
     def request_stage4_max(self):
         self.lead._chk(self.L.nq_request_stage4_max(self.lead.h), "nq_request_stage4_max")
 
+    def tick_snapshot(self):
+        for r in self.ranks:
+            r._chk(self.L.nq_tick_snapshot(r.h), "nq_tick_snapshot")
+
     def status_cfl_max(self):
         """Context.status_cfl_max over the ranks: the fourth stage's max |u|, |v| with the new state's max |phi|"""
         return float(np.max(self.max_over_ranks([list(r.stage4_max()) + [r.local_max()[2]] for r in self.ranks])))
@@ -499,6 +503,9 @@ class SlabContext(object):
     def request_stage4_max(self):
         self.sim.request_stage4_max()
 
+    def tick_snapshot(self):
+        self.sim.tick_snapshot()
+
     def status_cfl_max(self):
         return self.sim.status_cfl_max()
 
@@ -515,7 +522,7 @@ class SlabContext(object):
             q = self.sim.gather_rows(L.F_Q)
             return q - self.sim.gather_rows(L.F_QW) if self.model == L.COUPLED else q
         which = {L.F_QH: 0, L.F_PHIH: 1, L.F_PH: 2, L.F_QWH: 3, L.F_QH_MINUS: 4, L.F_CH: 5, L.F_QH_STAGE4: 6, L.F_PHIH_STAGE4: 7,
-                 L.F_QH_MINUS_STAGE4: 8}.get(fid)
+                 L.F_QH_MINUS_STAGE4: 8, L.F_QH_TICK: 9, L.F_PHIH_TICK: 10, L.F_QH_MINUS_TICK: 11, L.F_QWH_TICK: 12}.get(fid)
         if which is None:
             raise RuntimeError("field %d is not available on a slab-decomposed model" % fid)
         return self.sim.gather_spectral(which)

@@ -39,6 +39,8 @@ Files written (all numpy ``.npz``, loadable with ``allow_pickle=False``):
                           diagnostics ticking every 10 steps: UnCoupledModel (BASELINE config 5, member 3), YBJModel (dipole + wave
                           packet), QGModel with beta and its passive scalar: projections, sub-samples, norms, budgets, the
                           diagnostics series (round 4; ~15 minutes here; not in the default list)
+  g19_attributes_after_steps_without_ticks.npz  the g15 inventory with tdiags = 3 and no status lines: what the reference's
+                          instances carry after two steps without a diagnostics tick (round 4)
   g14_instance_attributes.npz  what a freshly constructed instance of each of the four model classes carries (nx = 64, every other
                           argument at its default): names and values of the scalar attributes, names, shapes, dtypes and two
                           checksums of the array attributes
@@ -495,6 +497,33 @@ def g15():
         return m
     attribute_inventory(out, "", stepped)
     save("g15_attributes_after_three_steps.npz", **out)
+
+
+def g19():
+    """round 4: the g15 inventory after steps WITHOUT a diagnostics tick or a status line -- tdiags = 3, twrite = 10**9, three
+    steps: the only tick is the first step's (tc = 0), the second and third steps leave behind what the step itself refreshes
+    (found by golden g18: QGModel's step recomputes C2, gradC2, lapc, Gamma_c in every stage, niwqg/QGModel.py:351-391)."""
+    out = {}
+
+    def stepped(mod):
+        if mod is QGModel:
+            m = mod.Model(L=L, nx=64, tmax=1e30, dt=0.05 * TE * 2, twrite=10 ** 9, nu4=7.5e8 * 16, nu=5.0, mu=1e-8, use_filter=True,
+                          U=-U0, tdiags=3, beta=2e-11, passive_scalar=True, nu4c=3e9, nuc=2.0, muc=1e-8, save_to_disk=False)
+        else:
+            kw = notebook_kwargs(64, True, 10, tdiags=3)
+            kw.update(nu4w=1e10, mu=1e-8, muw=2e-8, twrite=10 ** 9)
+            m = mod.Model(**kw)
+        rng = np.random.default_rng(19)
+        m.set_q(ic.LambDipole(m, U=U0, R=2 * np.pi / K0) + 1e-6 * rng.standard_normal((64, 64)))
+        if mod is QGModel:
+            m.set_c(1.0 + 0.3 * rng.standard_normal((64, 64)))
+        else:
+            m.set_phi(ic.WavePacket(m, k=2 * K0, l=K0, R=L / 6, x0=L / 2, y0=L / 2) * 0.1
+                      + 0.01 * (rng.standard_normal((64, 64)) + 1j * rng.standard_normal((64, 64))))
+        step_to(m, 3)
+        return m
+    attribute_inventory(out, "", stepped)
+    save("g19_attributes_after_steps_without_ticks.npz", **out)
 
 
 def g16(sizes=None):

@@ -76,12 +76,18 @@ class _FakeCtx(object):
     def request_stage4_max(self):
         self.requests = getattr(self, "requests", []) + [getattr(self, "done", 0) + 1]     # the step it will be recorded in
 
+    def tick_snapshot(self):
+        self.snapshots = getattr(self, "snapshots", []) + [getattr(self, "done", 0)]       # after how many steps
+
+    def qh_passenger(self):
+        return np.zeros(3, complex)
+
 
 def _bare_kernel(tdiags, twrite, dt, tmax):
     from niwqg_amd import Kernel
     k = object.__new__(Kernel.Kernel)
     k.__dict__.update(tdiags=tdiags, twrite=twrite, dt=dt, tmax=tmax, t=0, tc=0, _cache={}, _user={},
-                      _ctx=_FakeCtx(), diagnostics={}, save_to_disk=False, tsnaps=10, _pending_snapshots=[])
+                      _ctx=_FakeCtx(), diagnostics={}, save_to_disk=False, tsnaps=10, _pending_snapshots=[], _dual=False)
     k.ticks, k.status = [], []
     k._calc_derived_fields = lambda: k.ticks.append(k.tc)
     k._print_status_orig = Kernel.Kernel._print_status

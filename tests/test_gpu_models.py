@@ -1022,6 +1022,24 @@ def random_call_sequence_against_the_oracle(seed, on_slabs=False, nx_force=None)
             if o.tc % twrite == 0:                # a status line was due: its values, the CFL at 1e-12
                 assert abs(m.cfl - o.cfl) <= 1e-12 * abs(o.cfl), (where, m.cfl, o.cfl)
                 assert abs(m.ke - o.ke) <= 1e-10 * abs(o.ke), where
+            if arng.integers(0, 2):               # what the step (and the last tick) LEFT on the instance, read right after the step:
+                # the fourth stage's energy conversions and lapphi (Kernel.py:319-370), the new c-hat's C2 ... (QGModel.py:351-391),
+                # the last tick's phq (CoupledModel.py:105) -- golden g19 pins the same against the reference itself
+                left = dict(coupled=["gamma1", "gamma2", "xi1", "xi2", "pi", "lapphi", "phq", "q_psi", "qw", "pw", "pv", "phix", "phiy"],
+                            uncoupled=["gamma1", "gamma2", "xi1", "xi2", "pi", "lapphi", "q_psi", "phix", "phiy"],
+                            ybj=["lapphi", "phix", "phiy"],
+                            qg=["C2", "gradC2", "Gamma_c", "lapc"] if kw.get("passive_scalar") else ["p"])[kind]
+                nm = str(arng.choice(left))
+                # (one corner is documented, not reproduced -- DESIGN.md section 7: UnCoupledModel's conversions are rebuilt with the
+                # phix, phiy of the moment they are read; a status line between the step and the read has refreshed those, quirk Q1)
+                corner = kind == "uncoupled" and o.tc % twrite == 0 and nm in ("gamma1", "gamma2", "xi1", "xi2", "pi")
+                if hasattr(o, nm) and not corner:
+                    a, b = getattr(m, nm), getattr(o, nm)
+                    if np.ndim(b):
+                        assert rel(a, b) < 1e-10, (where, nm)
+                    else:
+                        scale = max(abs(getattr(o, k, 0.0)) for k in ("gamma1", "gamma2", "xi1", "xi2", nm))
+                        assert abs(a - b) <= 1e-7 * abs(b) + 1e-9 * scale + 1e-300, (where, nm, a, b)
         elif a == "jq":
             assert rel(m.jacobian_psi_q(), o.jacobian_psi_q()) < 1e-10, where
             assert rel(m.u, o.u) < 1e-10 and rel(m.v, o.v) < 1e-10, where

@@ -366,7 +366,8 @@ enum {  /* nq_any_ew: d = ... element by element; s0, s1, s2 complex scalars (sc
   NQ_EW_CONJ = 8,      /* conj(a)                             */
   NQ_EW_ADDS = 9,      /* a + s0                              */
   NQ_EW_IMAG = 10,     /* Im a (as a real value)              */
-  NQ_EW_MULADD = 11    /* s0 a b + s1 c                       */
+  NQ_EW_MULADD = 11,   /* s0 a b + s1 c                       */
+  NQ_EW_FILL = 12      /* s0 (a is not read)                  */
 };
 enum {  /* nq_any_reduce: out2 = (re, im) */
   NQ_RD_SUM = 0, NQ_RD_SUMABS2 = 1, NQ_RD_DOT = 2 /* sum a b */, NQ_RD_DOTC = 3 /* sum conj(a) b */, NQ_RD_MAXABS = 4,

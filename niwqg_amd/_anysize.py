@@ -19,7 +19,7 @@ import numpy as np
 from . import _etdrk4, _lib
 
 (EW_COPY, EW_MUL, EW_MULCONJ, EW_AXPBY, EW_AXPBYPCZ, EW_REAL, EW_ABS2, EW_SCALE, EW_CONJ, EW_ADDS, EW_IMAG,
- EW_MULADD) = range(12)
+ EW_MULADD, EW_FILL) = range(13)
 RD_SUM, RD_SUMABS2, RD_DOT, RD_DOTC, RD_MAXABS, RD_WSUMABS2, RD_MAXABSRE = range(7)
 
 NX_MAX = 8192
@@ -91,7 +91,7 @@ class Engine(object):
 
     def zeros(self, shape, real=False):
         p = Plane(self, (int(shape[0]), int(shape[1])), bool(real))
-        p._ew(EW_SCALE, p, s0=0.0)
+        p._ew(EW_FILL, p, s0=0.0)              # (not 0 * x: a pooled plane may hold anything, NaN included)
         return p
 
 

@@ -24,7 +24,7 @@ namespace nq {
 
 enum {  // element-wise operations (include/niwqg_amd.h: NQ_EW_*)
   EW_COPY = 0, EW_MUL = 1, EW_MULCONJ = 2, EW_AXPBY = 3, EW_AXPBYPCZ = 4, EW_REAL = 5, EW_ABS2 = 6, EW_SCALE = 7, EW_CONJ = 8,
-  EW_ADDS = 9, EW_IMAG = 10, EW_MULADD = 11
+  EW_ADDS = 9, EW_IMAG = 10, EW_MULADD = 11, EW_FILL = 12
 };
 enum { RD_SUM = 0, RD_SUMABS2 = 1, RD_DOT = 2, RD_DOTC = 3, RD_MAXABS = 4, RD_WSUMABS2 = 5, RD_MAXABSRE = 6 };
 
@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(256) k_any_ew(int op, cd* __restrict__ d, cons
       case EW_CONJ: r = cconj(a[i]); break;
       case EW_ADDS: r = cadd(a[i], s0); break;
       case EW_MULADD: r = cadd(cmul(s0, cmul(a[i], b[i])), cmul(s1, c[i])); break;      // s0 a b + s1 c
+      case EW_FILL: r = s0; break;                                                       // (a is not read: no 0 * NaN)
       default: r = cmake(0, 0);
     }
     d[i] = r;

@@ -3825,6 +3825,21 @@ static int any_split_rows(nq_any* e, const nq_any::Plan& pl, const cd* src, cd* 
   }
   return 0;
 }
+// device temporaries of one call: freed when the call returns, on the error paths too
+struct AnyScratch {
+  std::vector<void*> held;
+  ~AnyScratch() {
+    for (void* q : held) (void)hipFree(q);
+  }
+  template <typename T>
+  hipError_t get(T** out, size_t count) {
+    void* q = nullptr;
+    const hipError_t r = hipMalloc(&q, count * sizeof(T));
+    if (r == hipSuccess) held.push_back(q);
+    *out = static_cast<T*>(q);
+    return r;
+  }
+};
 static int any_buf(nq_any* e, cd** buf, size_t* have, size_t elems) {
   if (*have >= elems) return 0;
   if (*buf) {
@@ -4092,7 +4107,7 @@ int nq_any_fft(nq_any* e, void* dst, const void* src, int rows, int cols, int ax
 // d <- op(a, b, c; scalars) element by element over `elems` complex values (NQ_EW_* in the header); operands the op does not use
 // may be NULL; d may alias an operand
 int nq_any_ew(nq_any* e, int op, void* d, const void* a, const void* b, const void* c, long long elems, const double* scalars6) {
-  if (!e || !d || !a || elems <= 0 || op < 0 || op > EW_MULADD) return -1;
+  if (!e || !d || !a || elems <= 0 || op < 0 || op > EW_FILL) return -1;
   const bool need_b = (op == EW_MUL || op == EW_MULCONJ || op == EW_AXPBY || op == EW_AXPBYPCZ || op == EW_MULADD);
   const bool need_c = (op == EW_AXPBYPCZ || op == EW_MULADD);
   if ((need_b && !b) || (need_c && !c)) ANYFAIL(e, -1, "nq_any_ew: op %d needs more operands", op);
@@ -4143,9 +4158,10 @@ int nq_any_etdrk4(nq_any* e, int eq, const nq_params* p, const double* kk, const
   double *dk = nullptr, *dl = nullptr;
   cd* dc = nullptr;
   int *cnt = nullptr, *lo = nullptr, *ko = nullptr;
-  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dk), sizeof(double) * cols));
-  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dl), sizeof(double) * n));
-  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dc), sizeof(cd) * 32));
+  AnyScratch tmp;
+  ANYCHK(e, tmp.get(&dk, cols));
+  ANYCHK(e, tmp.get(&dl, n));
+  ANYCHK(e, tmp.get(&dc, 32));
   ANYCHK(e, hipMemcpy(dk, kk, sizeof(double) * cols, hipMemcpyHostToDevice));
   ANYCHK(e, hipMemcpy(dl, ll, sizeof(double) * n, hipMemcpyHostToDevice));
   ANYCHK(e, hipMemcpy(dc, contour32, sizeof(cd) * 32, hipMemcpyHostToDevice));
@@ -4155,9 +4171,9 @@ int nq_any_etdrk4(nq_any* e, int eq, const nq_params* p, const double* kk, const
                      (const double*)nullptr, (const cd*)dc, o[0], o[1], o[2], o[3], o[4], o[5]);
   int found = 0;
   if (near_count && near_l && near_k && cap > 0) {
-    ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&cnt), sizeof(int)));
-    ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&lo), sizeof(int) * cap));
-    ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&ko), sizeof(int) * cap));
+    ANYCHK(e, tmp.get(&cnt, 1));
+    ANYCHK(e, tmp.get(&lo, cap));
+    ANYCHK(e, tmp.get(&ko, cap));
     ANYCHK(e, hipMemsetAsync(cnt, 0, sizeof(int), e->stream));
     hipLaunchKernelGGL(k_coeff_flag, dim3((cols + 63) / 64, n), dim3(64), 0, e->stream, eq, n, cols, 0, *p, (const double*)dk, (const double*)dl, (const cd*)dc,
                        delta * delta, cap, cnt, lo, ko);
@@ -4171,8 +4187,6 @@ int nq_any_etdrk4(nq_any* e, int eq, const nq_params* p, const double* kk, const
     *near_count = found;
   }
   ANYCHK(e, hipStreamSynchronize(e->stream));
-  (void)hipFree(dk); (void)hipFree(dl); (void)hipFree(dc);
-  if (cnt) { (void)hipFree(cnt); (void)hipFree(lo); (void)hipFree(ko); }
   ANYCHK(e, hipGetLastError());
   return 0;
 }
@@ -4182,16 +4196,16 @@ int nq_any_etdrk4_patch(nq_any* e, void* const* out6, int cols, int count, const
   if (count == 0) return 0;
   int *dl = nullptr, *dk = nullptr;
   cd* dv = nullptr;
-  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dl), sizeof(int) * count));
-  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dk), sizeof(int) * count));
-  ANYCHK(e, hipMalloc(reinterpret_cast<void**>(&dv), sizeof(cd) * 4 * count));
+  AnyScratch tmp;
+  ANYCHK(e, tmp.get(&dl, count));
+  ANYCHK(e, tmp.get(&dk, count));
+  ANYCHK(e, tmp.get(&dv, (size_t)4 * count));
   ANYCHK(e, hipMemcpy(dl, l, sizeof(int) * count, hipMemcpyHostToDevice));
   ANYCHK(e, hipMemcpy(dk, k, sizeof(int) * count, hipMemcpyHostToDevice));
   ANYCHK(e, hipMemcpy(dv, vals, sizeof(cd) * 4 * count, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_coeff_patch, dim3((count + 255) / 256), dim3(256), 0, e->stream, count, (const int*)dl, (const int*)dk, (const cd*)dv, cols, cols, 0,
                      (const double*)nullptr, reinterpret_cast<cd*>(out6[2]), reinterpret_cast<cd*>(out6[3]), reinterpret_cast<cd*>(out6[4]), reinterpret_cast<cd*>(out6[5]), 0);
   ANYCHK(e, hipStreamSynchronize(e->stream));
-  (void)hipFree(dl); (void)hipFree(dk); (void)hipFree(dv);
   return 0;
 }
 

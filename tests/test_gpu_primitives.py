@@ -204,7 +204,8 @@ def test_every_export_survives_a_null_context():
              lambda: lib.nq_slab_info(None, (ctypes.c_int * 8)()),
              lambda: lib.nq_group_buffers(None, 0, ctypes.byref(vp), ctypes.byref(vp), ctypes.byref(ll_)),
              lambda: lib.nq_upload_spectral(None, 0, d), lambda: lib.nq_download_spectral(None, 0, d),
-             lambda: lib.nq_phase(None, 0, 0), lambda: lib.nq_reduce_buffer(None, 0, ctypes.byref(vp), ctypes.byref(n))]
+             lambda: lib.nq_phase(None, 0, 0), lambda: lib.nq_reduce_buffer(None, 0, ctypes.byref(vp), ctypes.byref(n)),
+             lambda: lib.nq_tick_snapshot(None), lambda: lib.nq_request_stage4_max(None), lambda: lib.nq_get_stage4_max(None, d)]
     for i, call in enumerate(calls):
         assert call() < 0, i
     # and a live context with NULL output pointers
@@ -212,6 +213,14 @@ def test_every_export_survives_a_null_context():
     for fn in (lib.nq_jacobian_psi_q, lib.nq_jacobian_psi_phi, lib.nq_jacobian_phic_phi, lib.nq_products_uq_vq,
                lib.nq_refraction, lib.nq_diagnostics):
         assert fn(cw.h, None) < 0
+    # the tick's spectra do not exist before the first nq_tick_snapshot: an error with text, not a read of nothing
+    big = np.zeros(2 * 64 * 64)
+    for fid in (_lib.F_QH_TICK, _lib.F_PHIH_TICK, _lib.F_QWH_TICK):
+        assert lib.nq_get_field(cw.h, fid, _lib._dptr(big)) == -4 and b"nq_tick_snapshot" in lib.nq_last_error(cw.h)
+    assert lib.nq_get_field(cw.h, _lib.F_QH_MINUS_TICK, _lib._dptr(big)) == -4              # (and never in a context without dual_q)
+    assert lib.nq_tick_snapshot(cw.h) == 0 and lib.nq_sync(cw.h) == 0
+    assert lib.nq_get_field(cw.h, _lib.F_PHIH_TICK, _lib._dptr(big)) == 0
+    assert lib.nq_get_field(cw.h, _lib.F_QH_MINUS_TICK, _lib._dptr(big)) == -4
 
 
 @pytest.mark.parametrize("kind", ["coupled", "qg"])
@@ -250,8 +259,10 @@ def test_documented_buffer_sizes_are_exact(kind):
     for which in range(6):
         guarded(half, lambda p: lib.nq_get_coeff(ctx.h, 0, which, p))
     fields = [_lib.F_Q, _lib.F_QH, _lib.F_P, _lib.F_PH, _lib.F_U, _lib.F_V, _lib.F_QPSI]
+    assert lib.nq_tick_snapshot(ctx.h) == 0
+    fields += [_lib.F_QH_TICK]
     if kind == "coupled":
-        fields += [_lib.F_PHI, _lib.F_PHIH, _lib.F_QW, _lib.F_QWH, _lib.F_PHIX, _lib.F_PHIY]
+        fields += [_lib.F_PHI, _lib.F_PHIH, _lib.F_QW, _lib.F_QWH, _lib.F_PHIX, _lib.F_PHIY, _lib.F_PHIH_TICK, _lib.F_QWH_TICK]
     for fid in fields:
         nd = lib.nq_field_doubles(ctx.h, fid)
         assert nd > 0

@@ -681,7 +681,9 @@ def main():
                 {"coupled": "Coupled", "uncoupled": "UnCoupled", "qg": "QG", "ybj": "YBJ"}[args.model], args.nx),
             "value": sps, "unit": "steps/s", "n_gpus": peers_n or world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * s_per_step, "higher_is_better": True,
-            "scaling": "strong" if sim is not None else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # --gpus N runs ONE simulation of the same grid on N slab ranks: the series 1, 2, 4, 8 is strong scaling (total work fixed),
+            # its N = 1 member included; only --replicas (one full problem per GPU) is weak
+            "scaling": "weak" if (args.replicas and world > 1) else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%sModel %s %d^2 fp64, ETDRK4, filter %s, budgets %s"
                                    % (args.model, "random-q" if (args.model == "qg" and args.nx == 2048) else "LambDipole",
                                       args.nx, "on" if c3_kwargs(args.nx, phys_model)["use_filter"] else "off",

@@ -1932,6 +1932,17 @@ static int create_impl(const nq_params* p_in, const double* kk, const double* ll
   if (p->model < 0 || p->model > 2) NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: unknown model %d", p->model);
   if (P < 1 || rank < 0 || rank >= P || (P & (P - 1)) || p->nx / P < CL)
     NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: %d ranks unsupported for nx=%d (power of two, at least %d columns per rank)", P, p->nx, CL);
+  if (P > 1) {
+    // the row kernels find the block of a half-spectrum column with kx / Wl = (kx * ceil(2^24 / Wl)) >> 24 (MArr::magic, Wl is not
+    // a power of two): checked here for every column this grid has, not trusted (exact while kx * Wl < 2^24)
+    const int whg = p->nx / 2 + 1, wl = (whg + P - 1) / P;
+    if (wl & (wl - 1)) {
+      const unsigned magic = (unsigned)(((1u << 24) + wl - 1) / wl);
+      for (int kx = 0; kx < whg; ++kx)
+        if ((int)(((unsigned)kx * magic) >> 24) != kx / wl)
+          NQ_FAIL((nq_ctx*)nullptr, -2, "nq_create: %d ranks unsupported for nx=%d (block index of column %d)", P, p->nx, kx);
+    }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: no HIP device available");
   if (device < 0 || device >= ndev) NQ_FAIL((nq_ctx*)nullptr, -3, "nq_create: device %d out of range (%d devices)", device, ndev);

@@ -36,7 +36,7 @@ struct MArr {
   int pitch;         // row pitch of the group (elements)
   int W;             // columns of this array owned by one rank
   int shift;         // kx / W = kx >> shift when >= 0 (power-of-two W, or 30 when P == 1)
-  unsigned magic;    // else kx / W = (kx * magic) >> 24, magic = ceil(2^24 / W); exact for kx < 8192, W < 2048
+  unsigned magic;    // else kx / W = (kx * magic) >> 24, magic = ceil(2^24 / W); exact while kx * W < 2^24 (nq_create checks every column)
   long long blk;     // X-side block stride = local rows * pitch
 };
 // One local row of an MArr on the X side.  SLAB = false (one rank: a single block) makes at() a plain `p + kx`: the

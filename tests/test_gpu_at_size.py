@@ -298,19 +298,23 @@ def test_config4_grid_on_eight_slab_ranks_equals_the_single_context_8192():
     q0 = 1e-5 * rng.standard_normal((nx, nx))
     phi0 = 0.05 * (rng.standard_normal((nx, nx)) + 1j * rng.standard_normal((nx, nx)))
     res = {}
-    for tag, slab in (("one", False), ("slab8", 8)):
-        m = niwqg_amd.CoupledModel.Model(slab=slab, nchunks=4, **kw)
+    # (two ranks: 2049 half-spectrum columns per rank, a width that is not a power of two and the largest the block-index
+    # division of the row kernels ever sees -- MArr::magic, checked column by column in nq_create)
+    for tag, slab, nch in (("one", False, 4), ("slab8", 8, 4), ("slab2", 2, 1)):
+        m = niwqg_amd.CoupledModel.Model(slab=slab, nchunks=nch, **kw)
         m.set_q(q0)
         m.set_phi(phi0)
         steps(m, 1)
         res[tag] = (m.q.copy(), m.phi.copy(), m.phih.copy(), m.qh.copy(), [m.Ke, m.Pw, m.Kw])
         m._ctx.close()
         del m
-    a, b = res["one"], res["slab8"]
-    errs = [rel(b[i], a[i]) for i in range(4)]
-    print("8192^2 white noise, 8 slab ranks x 4 chunks vs one context: q %.2e phi %.2e phih %.2e qh %.2e" % tuple(errs))
-    assert max(errs) < 1e-13
-    assert np.allclose(b[4], a[4], rtol=1e-11)
+    a = res["one"]
+    for tag in ("slab8", "slab2"):
+        b = res[tag]
+        errs = [rel(b[i], a[i]) for i in range(4)]
+        print("8192^2 white noise, %s vs one context: q %.2e phi %.2e phih %.2e qh %.2e" % ((tag,) + tuple(errs)))
+        assert max(errs) < 1e-13, tag
+        assert np.allclose(b[4], a[4], rtol=1e-11), tag
     # the state compared is rough: the filter band and the Nyquist row carry data
     k65 = int(0.65 * nx / 2) + 3
     assert np.abs(a[2][k65, k65]) > 0 and np.abs(a[3][nx // 2, 5]) > 0

@@ -254,12 +254,22 @@ struct ArrayList {        // up to 6 arrays processed by one launch (blockIdx.z 
   cd* ptr[6];
   int width[6];
   int pitch[6];
+  static constexpr bool REDIR = false;
+};
+// Slab ranks, inside a step: the rows [own0, own1) of an exchange-group array are this rank's OWN block, which sits at the same
+// offset on the X side (alt) as on the Y side (ptr).  The forward sub-pass, first consumer after an x -> y exchange, reads those
+// rows from the X side; the inverse sub-pass, last producer before a y -> x exchange, writes them to the X side: the device copy
+// of the own block that every exchange used to make is not needed.
+struct ArrayListR : ArrayList {
+  cd* alt[6];
+  int own0, own1;
+  static constexpr bool REDIR = true;
 };
 
 // "A" sub-pass, in place.  grid = (col tiles, S1, narrays); S2 = transform length.
-template <int S2, bool INV>
+template <int S2, bool INV, typename AL = ArrayList>
 __global__ void __launch_bounds__(YPlan<S2>::THREADS)
-k_y_A(ArrayList al, int S1, const cd* __restrict__ tw, int tw_step_N /* NT/N */) {
+k_y_A(AL al, int S1, const cd* __restrict__ tw, int tw_step_N /* NT/N */) {
   typedef YPlan<S2> Y;
   constexpr int P = Y::P, T = Y::T;
   const int c = threadIdx.x % CL, j = threadIdx.x / CL;
@@ -274,10 +284,20 @@ k_y_A(ArrayList al, int S1, const cd* __restrict__ tw, int tw_step_N /* NT/N */)
   typename Y::F::Tw twr;
   Y::F::load_tw(twr, j, tw, tw_step_N * (N / S2));
   cd r[P];
+  cd* other = data;                                 // where the rank's own rows are read from (forward) / written to (inverse)
+  int own0 = 0, own1 = 0;
+  if constexpr (AL::REDIR) {
+    other = al.alt[blockIdx.z];
+    own0 = al.own0;
+    own1 = al.own1;
+  }
 #pragma unroll
   for (int t = 0; t < P; ++t) {
     const int i2 = j + t * T;                       // y2 (forward) or l1 (inverse)
-    cd v = ok ? data[(size_t)(y1 + S1 * i2) * pitch + col] : cmake(0, 0);
+    const int row = y1 + S1 * i2;
+    const cd* src = data;
+    if constexpr (AL::REDIR && !INV) src = (row >= own0 && row < own1) ? other : data;
+    cd v = ok ? src[(size_t)row * pitch + col] : cmake(0, 0);
     if (INV) v = cmulc(v, tw[(size_t)(y1 * i2) * tw_step_N]);
     r[t] = v;
   }
@@ -286,9 +306,12 @@ k_y_A(ArrayList al, int S1, const cd* __restrict__ tw, int tw_step_N /* NT/N */)
 #pragma unroll
     for (int t = 0; t < P; ++t) {
       const int o2 = j + t * T;                     // l1 (forward) or y2 (inverse)
+      const int row = y1 + S1 * o2;
       cd v = r[t];
       if (!INV) v = cmul(v, tw[(size_t)(y1 * o2) * tw_step_N]);
-      data[(size_t)(y1 + S1 * o2) * pitch + col] = v;
+      cd* dst = data;
+      if constexpr (AL::REDIR && INV) dst = (row >= own0 && row < own1) ? other : data;
+      dst[(size_t)row * pitch + col] = v;
     }
   }
 }

@@ -88,6 +88,9 @@ struct nq_ctx {
   double* filt_m = nullptr;                                                 // filter at (-l, -k)
   // half-spectrum aux spectra
   cd *qwh = nullptr, *ph = nullptr;
+  // inside a slab step the A sub-passes read / write the rank's own block on the X side directly and the exchanges skip its
+  // device copy (ArrayListR; NIWQG_AMD_SLAB_OWN_REDIRECT=0 keeps the copy): set by nq_slab_step while it issues steps
+  bool redir_now = false;
   // nq_tick_snapshot: qh (both copies), phih, qwh as the last diagnostics tick saw them (allocated by the first call)
   cd *tick_qh = nullptr, *tick_q2 = nullptr, *tick_w = nullptr, *tick_qwh = nullptr;
   // slab decomposition; P == 1: one rank owns everything
@@ -764,14 +767,15 @@ static void launch_x_c2r(nq_ctx* c, const cd* in, double* out, double scale) {
   }
 }
 
-template <int S>
-static void launch_A_s(nq_ctx* c, bool inv, const ArrayList& al, int n, int maxw) {
+template <int S, typename AL>
+static void launch_A_s(nq_ctx* c, bool inv, const AL& al, int n, int maxw) {
   typedef YPlan<S> Y;
   dim3 grid((maxw + CL - 1) / CL, c->S1, n), block(Y::THREADS);
-  if (inv) hipLaunchKernelGGL((k_y_A<S, true>), grid, block, Y::LDS_BYTES, c->stream, al, c->S1, c->tw, 1);
-  else hipLaunchKernelGGL((k_y_A<S, false>), grid, block, Y::LDS_BYTES, c->stream, al, c->S1, c->tw, 1);
+  if (inv) hipLaunchKernelGGL((k_y_A<S, true, AL>), grid, block, Y::LDS_BYTES, c->stream, al, c->S1, c->tw, 1);
+  else hipLaunchKernelGGL((k_y_A<S, false, AL>), grid, block, Y::LDS_BYTES, c->stream, al, c->S1, c->tw, 1);
 }
-static void launch_A_list(nq_ctx* c, bool inv, const ArrayList& al, int n, int maxw) {
+template <typename AL>
+static void launch_A_list(nq_ctx* c, bool inv, const AL& al, int n, int maxw) {
   if (c->S2 == 1) return;                  // single-pass columns: the B sub-pass is the whole y transform
   ProfScope ps(c, PK_A);
   switch (c->S2) {
@@ -804,17 +808,22 @@ static int y_width(const nq_ctx* c, const MArr& m) {
 }
 // A sub-pass on the Y side of exchange-group arrays
 static void launch_A_m(nq_ctx* c, bool inv, std::initializer_list<const MArr*> arrs) {
-  ArrayList al;
+  ArrayListR al;
   int n = 0, maxw = 0;
   for (const MArr* m : arrs) {
     al.ptr[n] = m->ys;
+    al.alt[n] = m->xs;
     al.width[n] = y_width(c, *m);
     al.pitch[n] = m->pitch;
     maxw = al.width[n] > maxw ? al.width[n] : maxw;
     ++n;
   }
-  for (int i = n; i < 6; ++i) { al.ptr[i] = nullptr; al.width[i] = 0; al.pitch[i] = 0; }
-  if (maxw > 0) launch_A_list(c, inv, al, n, maxw);
+  for (int i = n; i < 6; ++i) { al.ptr[i] = al.alt[i] = nullptr; al.width[i] = 0; al.pitch[i] = 0; }
+  al.own0 = c->rank * c->Nloc;
+  al.own1 = al.own0 + c->Nloc;
+  if (maxw <= 0) return;
+  if (c->redir_now) launch_A_list(c, inv, al, n, maxw);                               // (see ArrayListR)
+  else launch_A_list(c, inv, static_cast<const ArrayList&>(al), n, maxw);
 }
 template <int S, int CLX = CL>
 static void launch_B_s(nq_ctx* c, bool inv, const cd* in, int pin, cd* out, int pout, int width, double scale) {
@@ -1043,7 +1052,9 @@ static void launch_sphi_s(nq_ctx* c, const EtdArrays& ea, int stage, const cd* y
   typedef YPlanT<S, CLX> Y;
   BudgetW bw = budget_w(c, c->partW + (size_t)stage * c->nww * NQ_PARTW, y_start);
   const cd* jpass = c->ybj ? nullptr : c->mUq.ys + c->mUq.W;     // YBJModel.jacobian_psi_phi keeps [0,0] (YBJModel.py:123-133)
-  hipLaunchKernelGGL((k_s_phi<S, CLX>), dim3(c->Wf / CLX, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mW, jpass, c->mUq.pitch, ea, stage, geom_full(c), ophi, ophiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
+  const cd* jown = (jpass && c->redir_now) ? c->mUq.xs + c->mUq.W : jpass;     // the own block was not copied across (ArrayListR)
+  const int own0 = c->redir_now ? c->rank * c->Nloc : 0, own1 = c->redir_now ? own0 + c->Nloc : 0;
+  hipLaunchKernelGGL((k_s_phi<S, CLX>), dim3(c->Wf / CLX, c->S2), dim3(Y::THREADS), Y::LDS_BYTES, c->stream, c->mW, jpass, jown, own0, own1, c->mUq.pitch, ea, stage, geom_full(c), ophi, ophiy, 1.0 / ((double)c->N * c->N), c->kk, c->ll, c->tw, 1, bw);
 }
 template <int S, int CLX>
 static void launch_emit_phi_s(nq_ctx* c, const cd* phih) {
@@ -1503,11 +1514,13 @@ static int issue_chunk(std::vector<nq_ctx*>& grp, int g, bool to_y, int i, int n
         for (nq_ctx* s : grp)
           if (!(inl && s == c)) HIPCHK(c, hipStreamWaitEvent(xs, to_y ? s->ev_prod[i] : s->ev_col, 0));
         for (nq_ctx* s : grp) {
+          if (s == c && c->redir_now) continue;  // the own block: the A sub-passes use it where it is (ArrayListR)
           const cd* src = (to_y ? s->G[g].bx : s->G[g].by) + (size_t)c->rank * blk + off;
           HIPCHK(c, hipMemcpyAsync(recv + (size_t)s->rank * blk + off, src, cblk * sizeof(cd), hipMemcpyDeviceToDevice, xs));
         }
       } else if (c->link == LINK_NULL) {         // one rank of P measured alone: only its own block crosses (device copy)
-        HIPCHK(c, hipMemcpyAsync(recv + (size_t)c->rank * blk + off, send + (size_t)c->rank * blk + off, cblk * sizeof(cd), hipMemcpyDeviceToDevice, xs));
+        if (!c->redir_now)
+          HIPCHK(c, hipMemcpyAsync(recv + (size_t)c->rank * blk + off, send + (size_t)c->rank * blk + off, cblk * sizeof(cd), hipMemcpyDeviceToDevice, xs));
       } else {                                   // RCCL: one grouped send/recv pair per peer, the own block by a device copy
         NCCLCHK(c, g_rccl.GroupStart());
         for (int p = 0; p < c->P; ++p) {
@@ -1516,7 +1529,8 @@ static int issue_chunk(std::vector<nq_ctx*>& grp, int g, bool to_y, int i, int n
           NCCLCHK(c, g_rccl.Recv(recv + (size_t)p * blk + off, 2 * cblk, kNcclDouble, p, c->comm, xs));
         }
         NCCLCHK(c, g_rccl.GroupEnd());
-        HIPCHK(c, hipMemcpyAsync(recv + (size_t)c->rank * blk + off, send + (size_t)c->rank * blk + off, cblk * sizeof(cd), hipMemcpyDeviceToDevice, xs));
+        if (!c->redir_now)
+          HIPCHK(c, hipMemcpyAsync(recv + (size_t)c->rank * blk + off, send + (size_t)c->rank * blk + off, cblk * sizeof(cd), hipMemcpyDeviceToDevice, xs));
       }
     }
     c->n_exch += 1;
@@ -2769,11 +2783,24 @@ int nq_slab_step(nq_ctx* c, int nsteps) {
   SLABTRY(slab_group(c, &grp));
   for (nq_ctx* x : each(grp)) HIPCHK(x, hipSetDevice(x->device));
   c->n_calls += 1;
-  for (int i = 0; i < nsteps; ++i) {
+  // inside the step every exchange has an A sub-pass next to it on the Y side: the rank's own block is used where it lies
+  // (ArrayListR) instead of being copied across -- not with caller-moved buffers (the callback moves the own block too) and not
+  // on plans without an A sub-pass (single-pass columns)
+  static int redirect_on = -1;
+  if (redirect_on < 0) {
+    const char* e = getenv("NIWQG_AMD_SLAB_OWN_REDIRECT");
+    redirect_on = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  const bool redir = redirect_on && c->link != LINK_CALLBACK && c->link != LINK_NONE && c->S2 > 1 && c->P > 1;
+  for (nq_ctx* x : each(grp)) x->redir_now = redir;
+  int step_rc = 0;
+  for (int i = 0; i < nsteps && step_rc == 0; ++i) {
     const bool now = c->want_uv4 && i == nsteps - 1 && c->kernel_family && !c->ybj;
     for (nq_ctx* x : each(grp)) x->uv4_now = now;
-    SLABTRY(slab_step_once(grp));
+    step_rc = slab_step_once(grp);
   }
+  for (nq_ctx* x : each(grp)) x->redir_now = false;
+  if (step_rc) return step_rc;
   if (nsteps > 0)
     for (nq_ctx* x : each(grp)) {
       x->stepped = true;

@@ -1330,7 +1330,7 @@ __device__ __forceinline__ void phi_outputs(const cd (&y)[P], cd (&a)[P], cd (&b
 
 template <int S1, int CLX = CL>
 __global__ void __launch_bounds__((YPlanT<S1, CLX>::THREADS))
-k_s_phi(MArr Hw, const cd* __restrict__ jpass, int jpitch, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphiy,
+k_s_phi(MArr Hw, const cd* __restrict__ jpass, const cd* __restrict__ jpass_own, int own0, int own1, int jpitch, EtdArrays ea, int stage, YGeom g, MArr Hphi, MArr Hphiy,
         double invM, const double* __restrict__ kk, const double* __restrict__ ll, const cd* __restrict__ tw,
         int tw_step_N, BudgetW bw) {
   typedef YPlanT<S1, CLX> Y;
@@ -1352,7 +1352,8 @@ k_s_phi(MArr Hw, const cd* __restrict__ jpass, int jpitch, EtdArrays ea, int sta
   double jfix[2] = {0.0, 0.0};
   if (jpass != nullptr && g.k0 == 0 && blockIdx.x == 0 && l1 == 0) {   // jpass == null: YBJModel keeps [0,0]
     for (int yy = threadIdx.x; yy < N; yy += Y::THREADS) {
-      const cd z = jpass[(size_t)yy * jpitch];
+      // (rows [own0, own1): this rank's own block, still on the X side when the step skips its copy -- ArrayListR)
+      const cd z = ((yy >= own0 && yy < own1) ? jpass_own : jpass)[(size_t)yy * jpitch];
       jfix[0] += z.x;
       jfix[1] += z.y;
     }

@@ -10,9 +10,10 @@ fp64 (BASELINE.json configs[2]: LambDipole q, uniform phi, filter on), state res
   The K steps are issued as 5 blocks with a HIP event between blocks (no synchronisation inside the region):
   `blocks_ms_per_step` / `median_block_steps_per_s` are SURVEY 8d's "median of 5".
 * `roofline` describes the DOMINANT kernel class (largest total time among all six classes in an untimed pass with every
-  launch bracketed by HIP events on the context's stream); INSIDE the timed region the launches of that class -- and only
-  those: bracketing all 44 launches of a step costs 4.6 % of it -- are bracketed again, and achieved = algorithmic bytes
-  per launch / their average duration.  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC summary, used
+  launch bracketed by HIP events on the context's stream); INSIDE the timed region every 7th launch of that class is
+  bracketed again (`--region-stride`; an event pair costs the stream ~9 us: all 44 launches of a step 4.6 % of it, all 20 of
+  the dominant class ~1 %, and 10 % of a rank's step on eight slab ranks; 7 is coprime with the 20 launches of a step, so every
+  position is sampled equally often), and achieved = algorithmic bytes per launch / the average duration of those launches.  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC summary, used
   only if that summary was taken from the very sources that are running (sha256 of niwqg_amd/csrc + include/ stamped
   into it), else null.  `peak_measured_copy` = a 1r + 1w stream copy timed in the untimed part of the same run.
 * `cpu_baseline` times the numpy oracle in its reference-faithful mode (104 c2c numpy.fft transforms per step, one thread)
@@ -170,7 +171,7 @@ class _SlabCtxView(object):
         self.r, self.L, self.h = rank, rank.L, rank.h
         self.budgets_enabled = rank.budgets
         self.KERNEL_CLASSES = _lib.Context.KERNEL_CLASSES
-        for name in ("sync", "timer_start", "timer_stop", "profile_enable", "profile_read", "profile_read_all",
+        for name in ("sync", "timer_start", "timer_stop", "profile_enable", "profile_stride", "profile_read", "profile_read_all",
                      "device_bytes", "event_record", "event_elapsed", "_chk"):
             setattr(self, name, getattr(_lib.Context, name).__get__(self))
 
@@ -447,6 +448,8 @@ def main():
                     "blocks cross by peer copies (SDMA over xGMI, no CUs): no torchrun, no RCCL")
     ap.add_argument("--rank-only", action="store_true", help="with --rank-of: skip the single-GPU step of the same run (so that a "
                     "kernel trace of the run holds the slab instantiations only)")
+    ap.add_argument("--region-stride", type=int, default=7, help="inside the timed region bracket every n-th launch of the "
+                    "dominant kernel class with HIP events (1 = every launch, as rounds 1-3 did)")
     ap.add_argument("--replicas", action="store_true", help="with --gpus N > 1: N independent replicas instead of one "
                                                             "slab-decomposed simulation")
     args = ap.parse_args()
@@ -571,9 +574,19 @@ def main():
         classes_all = ctx.profile_read_all()
         live = [k for k in classes_all if classes_all[k][0] > 0]
         dom_class = max(live, key=lambda k: classes_all[k][1])
-        ctx.profile_enable(ctx.KERNEL_CLASSES[dom_class])   # timed region: the dominant class only
+        ctx.profile_enable(ctx.KERNEL_CLASSES[dom_class])   # timed region: the dominant class only ...
+        # ... and of its launches every REGION_STRIDE-th: an event pair costs the stream ~9 us, i.e. 2 % of a 4096^2 step with
+        # all 20 A sub-passes of a step bracketed, 10 % of a rank's step on eight slab ranks (round 4).  7 is coprime with the 5
+        # launches per stage / 20 per step of that class, so every position of the step is sampled equally often.
+        ctx.profile_stride(args.region_stride)
+    xt = None
     if sim is not None:
-        sim.counters(reset=2)                               # count host calls / exchange chunks / bytes, time the exchange stream
+        # the exchange stream's own time (two event records per exchange) is taken in a short UNTIMED pass, not in the region
+        sim.counters(reset=2)
+        advance(min(args.steps, 5))
+        sim.sync()
+        xt = sim.counters()
+        sim.counters(reset=1)                               # the region itself: count host calls / exchange chunks / bytes only
     barrier()
     t0 = time.perf_counter()
     ctx.event_record(0)
@@ -594,6 +607,7 @@ def main():
         advance(ksteps)
     classes = ctx.profile_read_all()
     ctx.profile_enable(-1)
+    ctx.profile_stride(1)
     dom_timed = None
     if events_in_region:                                    # `classes` holds the dominant class over the timed region only
         dom_timed = (dom_class, classes[dom_class])
@@ -615,8 +629,8 @@ def main():
         compute_ms = sum(v[1] for v in classes.values()) / ksteps
         extra.update(host_dispatches_per_step=cnt["host_calls"] / nst,
                      exchange_chunks_per_step=cnt["exchange_chunks"] / nst,
-                     exchange_ms_per_step=cnt["exchange_ms"] / nst,
-                     allreduce_ms_per_step=cnt["allreduce_ms"] / nst,
+                     exchange_ms_per_step=xt["exchange_ms"] / max(xt["steps"], 1),          # (untimed pass right before the region)
+                     allreduce_ms_per_step=xt["allreduce_ms"] / max(xt["steps"], 1),
                      compute_ms_per_step=compute_ms,
                      exposed_exchange_ms_per_step=dev_ms / args.steps - compute_ms,
                      exchange_GB_sent_per_rank_per_step=cnt["bytes_sent"] / nst / 1e9)
@@ -696,9 +710,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_note,
                          "launches": launches, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
-                         "kernel_events": ("dominant class bracketed inside the timed region (%d launches); per-class table from an untimed pass of "
-                                           "%d steps right before it (bracketing all six classes in the region costs 4.6 %% of the step)"
-                                           % (launches, ksteps)) if events_in_region
+                         "kernel_events": ("every %d-th launch of the dominant class bracketed inside the timed region (%d launches sampled, all "
+                                           "positions of the step equally often); per-class table from an untimed pass of %d steps right before "
+                                           "it (an event pair costs the stream ~9 us: all six classes in the region 4.6 %% of the step, all launches "
+                                           "of the dominant class 2 %%)" % (args.region_stride, launches, ksteps)) if events_in_region
                                           else "separate pass of %d steps after the timed region" % ksteps,
                          "per_kernel_ms_per_step": {k: round(v[1] / ksteps, 4) for k, v in classes.items()},
                          "per_kernel_frac_of_peak": {k: round(table[k] * npts / share / (classes[k][1] / classes[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -339,6 +339,9 @@ int nq_event_elapsed(nq_ctx* ctx, int slot_a, int slot_b, float* elapsed_ms);
  * of bytes moved (read + written): the copy rate of THIS device, bench.py's second roofline denominator */
 int nq_stream_copy_gbs(nq_ctx* ctx, long long bytes, int reps, double* gbs_out);
 int nq_profile_enable(nq_ctx* ctx, int kernel_class);     /* -1 disables, -2 brackets every class */
+/* bracket only every stride-th launch of the enabled class(es) (>= 1; 1 = every launch): keeps the cost of measuring a kernel
+ * live inside a timed region below 1 % (an event pair costs the stream ~9 us) */
+int nq_profile_stride(nq_ctx* ctx, int stride);
 int nq_profile_read(nq_ctx* ctx, int* launches, float* total_ms);   /* synchronises, then resets */
 int nq_profile_read_all(nq_ctx* ctx, int* launches6, float* total_ms6);   /* per class, after nq_profile_enable(-2) */
 /* bytes of device memory held by the context */

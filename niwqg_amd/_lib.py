@@ -29,7 +29,7 @@ COUPLED, UNCOUPLED, QG, YBJ = 0, 1, 2, 3
 (S_KE, S_PW, S_KW, S_KE_QG, S_KE_NIW, S_PE_NIW, S_CFL, S_MAX_PHI) = range(8)
 
 EXPORTS = ["nq_create", "nq_destroy", "nq_last_error", "nq_set_q", "nq_set_c", "nq_set_phi", "nq_invert", "nq_refresh_grad_phi",
-           "nq_step", "nq_request_stage4_max", "nq_get_stage4_max", "nq_tick_snapshot", "nq_sync", "nq_get_field", "nq_get_qh_passenger", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
+           "nq_step", "nq_profile_stride", "nq_request_stage4_max", "nq_get_stage4_max", "nq_tick_snapshot", "nq_sync", "nq_get_field", "nq_get_qh_passenger", "nq_get_scalar", "nq_fft2", "nq_ifft2", "nq_rfft2",
            "nq_irfft2", "nq_jacobian_psi_q", "nq_jacobian_psi_c", "nq_jacobian_psi_phi", "nq_jacobian_phic_phi", "nq_products_uq_vq", "nq_refraction", "nq_field_doubles", "nq_get_coeff", "nq_coeff_near_contour", "nq_coeff_patch", "nq_diagnostics",
            "nq_stream_copy_gbs", "nq_timer_start", "nq_timer_stop", "nq_event_record", "nq_event_elapsed", "nq_profile_enable", "nq_profile_read", "nq_profile_read_all", "nq_group_elems", "nq_create_slab",
            "nq_slab_info", "nq_group_buffers", "nq_upload_spectral", "nq_download_spectral", "nq_phase",
@@ -107,6 +107,7 @@ def lib():
         getattr(L, name).argtypes = [vp, dp, dp]
     L.nq_step.argtypes = [vp, ctypes.c_int]
     L.nq_request_stage4_max.argtypes = [vp]
+    L.nq_profile_stride.argtypes = [vp, ctypes.c_int]
     L.nq_tick_snapshot.argtypes = [vp]
     L.nq_get_stage4_max.argtypes = [vp, dp]
     L.nq_get_field.argtypes = [vp, ctypes.c_int, dp]
@@ -300,6 +301,10 @@ class Context:
 
     def sync(self):
         self._chk(self.L.nq_sync(self.h), "nq_sync")
+
+    def profile_stride(self, stride):
+        """bracket only every stride-th launch of the enabled kernel class(es) (include/niwqg_amd.h: nq_profile_stride)"""
+        self._chk(self.L.nq_profile_stride(self.h, int(stride)), "nq_profile_stride")
 
     def tick_snapshot(self):
         """keep qh, phih, qwh as the diagnostics tick sees them (include/niwqg_amd.h: nq_tick_snapshot)"""

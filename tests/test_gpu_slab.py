@@ -216,6 +216,52 @@ def test_two_processes_one_gpu_host_staged_collectives(tmp_path):
     assert "two processes agree with one context" in out.stdout
 
 
+COPY_PATH_WORKER = r"""
+import sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import numpy as np
+from niwqg_amd import _lib, slab
+from test_gpu_slab import setup_case
+from test_oracle_golden import rel
+worst = 0.0
+for kind, nranks, nchunks in (("coupled", 4, 2), ("uncoupled", 2, 1), ("qg", 4, 1)):
+    model, o, dt, phys, q0, phi0 = setup_case(kind, 256)
+    one = _lib.Context(model, 256, o.kk, o.ll, o.filtr, dt, budgets=True, **phys)
+    ranks = slab.make_ranks(model, 256, o.kk, o.ll, o.filtr, dt, nranks, budgets=True, **phys)
+    sim = slab.SlabSimulation(ranks, "peers", nchunks=nchunks)
+    for x in (one, sim):
+        x.set_q(q0)
+        if phi0 is not None:
+            x.set_phi(phi0)
+    one.step(3)
+    sim.step(3)
+    sim.sync()
+    worst = max(worst, rel(sim.gather_qh(), one.field(_lib.F_QH)))
+    if phi0 is not None:
+        worst = max(worst, rel(sim.gather_phih(), one.field(_lib.F_PHIH)))
+print("own blocks copied across: worst relative difference %%.2e" %% worst)
+assert worst < 1e-13
+print("copy path agrees with one context")
+"""
+
+
+def test_own_block_copy_path_still_agrees(tmp_path):
+    """NIWQG_AMD_SLAB_OWN_REDIRECT=0: the rank's own block is copied across at every exchange as in rounds 2-3 (by default the A
+    sub-passes read / write it on the row side and nothing moves it: ArrayListR).  The switch is read once per process, hence a
+    child process; every other slab test runs the default."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "copy_path.py"
+    script.write_text(COPY_PATH_WORKER % (root, os.path.join(root, "tests")))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, NIWQG_AMD_SLAB_OWN_REDIRECT="0"))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "copy path agrees with one context" in out.stdout
+
+
 @pytest.mark.parametrize("nranks,nchunks", [(8, 4), (2, 1), (4, 2)])
 def test_config4_8192_on_virtual_ranks_against_the_oracle(nranks, nchunks):
     """BASELINE config 4 (CoupledModel 8192^2 slab-decomposed over 8 ranks; also over 2 and 4), all ranks on this one GPU.

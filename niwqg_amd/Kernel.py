@@ -324,8 +324,8 @@ class Kernel(object):
             qwh *= self.filtr
             pv = pv + self.ifft(self.wv2i * qwh).real
             q4 = q4 - self.ifft(qwh).real                    # q_psi (CoupledModel.py:145-152)
-        else:
-            phix, phiy = self.phix, self.phiy                # as last refreshed (quirk Q1: UnCoupledModel._invert leaves them)
+        else:                                                # as last refreshed BEFORE the stage (quirk Q1: UnCoupledModel._invert
+            phix, phiy = self.__dict__.get("_ec_grad") or (self.phix, self.phiy)    # leaves them; see _keep_stage4_grad_phi)
         ph4 = self.fft(pv)
         return self.ifft(-self.il * ph4).real, self.ifft(self.ik * ph4).real, q4, phi4, phih4, phix, phiy
 
@@ -334,6 +334,15 @@ class Kernel(object):
     # tick recomputes them from the new state (golden g19).  Rebuilt on demand with the reference's expressions (Kernel.py:682-701).
     _EC_NAMES = ("gamma1", "gamma2", "xi1", "xi2", "pi")
     _ec_stage4 = False
+
+    def _keep_stage4_grad_phi(self):
+        """UnCoupledModel, before anything refreshes phix, phiy (a status line's or set_phi's _calc_pe_niw, Kernel.py:610): the fourth
+        stage's conversions were formed with the gradients as they are NOW.  If nobody has read them yet, keep those gradients (two
+        planes to the host: only on a status line or a set_phi that follows a step without a diagnostics tick)."""
+        d = self.__dict__
+        if (self.model_id == _lib.UNCOUPLED and d.get("_ec_stage4") and "_ec_grad" not in d
+                and not all(k in d for k in Kernel._EC_NAMES)):
+            d["_ec_grad"] = (self.phix, self.phiy)
 
     def _energy_conversion_of_stage4(self):
         u, v, q_psi, phi, phih, phix, phiy = self._fields_of_stage4()
@@ -369,6 +378,7 @@ class Kernel(object):
 
     def set_phi(self, phi):
         """ref: niwqg/Kernel.py:538-551 -- does NOT re-invert (quirk Q2)"""
+        self._keep_stage4_grad_phi()
         self._ctx.set_phi(phi)
         keep = {k: v for k, v in self._cache.items() if k not in ("phi", "phih", "phix", "phiy", "_dsums")}
         keepu = {k: v for k, v in self._user.items() if k != "phi"}
@@ -437,6 +447,7 @@ class Kernel(object):
         self._dirty()
         self._uv_stage4 = self.model_id != _lib.YBJ          # (YBJModel: psi, u, v are steady)
         self._ec_stage4 = self._uv_stage4                    # (and its step never calls _calc_energy_conversion)
+        self.__dict__.pop("_ec_grad", None)
         self._tick_stale = self._tick_taken
         if self._ec_stage4:
             for k in Kernel._EC_NAMES:
@@ -531,6 +542,7 @@ class Kernel(object):
 
     def _calc_pe_niw(self):
         """ref: niwqg/Kernel.py:608-611 -- including its side effect on phix/phiy (quirk Q1)"""
+        self._keep_stage4_grad_phi()
         self._ctx.refresh_grad_phi()
         self._cache.pop("phix", None)
         self._cache.pop("phiy", None)
@@ -613,6 +625,7 @@ class Kernel(object):
         s, M = self._dsums(), float(self.nx) * self.ny
         M2f = self._M2 * self.f
         self._ec_stage4 = False
+        self.__dict__.pop("_ec_grad", None)
         self.gamma2 = 0.5 * self.hslash * s[24] / M2f
         self.xi1 = s[27] / M2f
         self.gamma1 = 0.25 * self.hslash * s[28] / M2f

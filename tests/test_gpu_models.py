@@ -1030,10 +1030,9 @@ def random_call_sequence_against_the_oracle(seed, on_slabs=False, nx_force=None)
                             ybj=["lapphi", "phix", "phiy"],
                             qg=["C2", "gradC2", "Gamma_c", "lapc"] if kw.get("passive_scalar") else ["p"])[kind]
                 nm = str(arng.choice(left))
-                # (one corner is documented, not reproduced -- DESIGN.md section 7: UnCoupledModel's conversions are rebuilt with the
-                # phix, phiy of the moment they are read; a status line between the step and the read has refreshed those, quirk Q1)
-                corner = kind == "uncoupled" and o.tc % twrite == 0 and nm in ("gamma1", "gamma2", "xi1", "xi2", "pi")
-                if hasattr(o, nm) and not corner:
+                # (UnCoupledModel: a status line between the step and this read has refreshed phix, phiy, quirk Q1 -- the conversions
+                # are still those formed with the old ones: Kernel._keep_stage4_grad_phi)
+                if hasattr(o, nm):
                     a, b = getattr(m, nm), getattr(o, nm)
                     if np.ndim(b):
                         assert rel(a, b) < 1e-10, (where, nm)
